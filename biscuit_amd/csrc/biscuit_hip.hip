@@ -1,0 +1,636 @@
+// C ABI of libbiscuit_hip.so (see include/biscuit_hip.h): context, BQW1 weight blob,
+// the Xception launch schedule, the MC-dropout head and event-based per-kernel timing.
+#include "../../include/biscuit_hip.h"
+#include "bq_common.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct Blob { const unsigned char* p = nullptr; size_t n = 0; };
+
+struct GemmLayer {
+    std::string name;
+    const void* wp = nullptr;
+    const float* scale = nullptr;
+    const float* bias = nullptr;
+    const float* dw = nullptr;
+    int cin = 0, cout = 0;   // true channel counts
+    int kpad = 0;            // padded contraction length
+    int nfp = 0;             // padded n-frags in wp
+};
+
+struct ProfRec { int cls; hipEvent_t a, b; };
+
+}  // namespace
+
+struct bq_ctx {
+    bq_config cfg{};
+    int device = 0;
+    std::string err;
+    unsigned char* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    std::map<std::string, Blob> entries;
+    std::map<std::string, GemmLayer> layers;
+    const float* stem_w = nullptr; const float* stem_s = nullptr; const float* stem_b = nullptr;
+    const float* logits_w = nullptr; const float* logits_b = nullptr;
+    bool loaded = false;
+    // profiling
+    bool prof = false;
+    std::vector<std::string> prof_names;
+    std::vector<double> prof_flops, prof_bytes;
+    std::vector<int64_t> prof_launches;
+    std::vector<double> prof_ms;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int fail(bq_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                 \
+    do {                                                                                \
+        hipError_t _e = (hipError_t)(expr);                                             \
+        if (_e != hipSuccess)                                                           \
+            return fail((c), BQ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int pad16(int c) { return (c + 15) / 16 * 16; }
+inline size_t esize(const bq_ctx* c) { return c->cfg.dtype == BQ_DTYPE_BF16 ? 2 : 4; }
+
+constexpr long long kStaged = 3LL * 299 * 299;
+constexpr long long kMaxAct = 147LL * 147 * 128;
+constexpr long long kMaxRes = 74LL * 74 * 128;
+
+struct WsLayout {
+    size_t a, b, c, r, staged, feat, hpart, h0, h1, state, total;
+};
+
+WsLayout ws_layout(const bq_ctx* c, int n, int mc) {
+    const size_t es = esize(c);
+    WsLayout L{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+    L.a = take((size_t)n * kMaxAct * es);
+    L.b = take((size_t)n * kMaxAct * es);
+    L.c = take((size_t)n * kMaxAct * es);
+    L.r = take((size_t)n * kMaxRes * es);
+    L.staged = take((size_t)n * kStaged * es);
+    L.feat = take((size_t)n * 2048 * 4);
+    const size_t rows = (size_t)n * (mc > 0 ? mc : 1);
+    L.hpart = take(rows * 1024 * 4);
+    L.h0 = take(rows * 1024 * 4);
+    L.h1 = take(rows * 1024 * 4);
+    L.state = take((size_t)n * 5 * 4);
+    L.total = off;
+    return L;
+}
+
+// ---- profiling -----------------------------------------------------------------
+int prof_class(bq_ctx* c, const std::string& name, double flops, double bytes) {
+    for (size_t i = 0; i < c->prof_names.size(); ++i)
+        if (c->prof_names[i] == name) return (int)i;
+    c->prof_names.push_back(name);
+    c->prof_flops.push_back(flops);
+    c->prof_bytes.push_back(bytes);
+    c->prof_launches.push_back(0);
+    c->prof_ms.push_back(0.0);
+    return (int)c->prof_names.size() - 1;
+}
+
+struct ProfScope {
+    bq_ctx* c; hipStream_t s; int cls = -1; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(bq_ctx* c_, hipStream_t s_, const std::string& name, double flops, double bytes)
+        : c(c_), s(s_) {
+        if (!c->prof) return;
+        if (c->ev_used + 2 > c->ev_pool.size()) {
+            for (int i = 0; i < 256; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return;
+                c->ev_pool.push_back(e);
+            }
+        }
+        cls = prof_class(c, name, flops, bytes);
+        a = c->ev_pool[c->ev_used++];
+        b = c->ev_pool[c->ev_used++];
+        hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (cls < 0) return;
+        hipEventRecord(b, s);
+        c->prof_recs.push_back({cls, a, b});
+    }
+};
+
+// ---- GEMM layer launch -----------------------------------------------------------
+int pick_shape(const bq_ctx* c, int prod, int nfp) {
+    if (prod == PROD_IM2COL) return SHAPE_A;
+    if (c->cfg.dtype == BQ_DTYPE_BF16) {
+        switch (nfp) {
+            case 4: return SHAPE_B;
+            case 8: return SHAPE_C;
+            case 24: return SHAPE_D;
+            case 32: return SHAPE_E;
+            case 48: return SHAPE_F;
+            case 64: return SHAPE_G;
+        }
+        return -1;
+    }
+    if (prod == PROD_DROPOUT) return SHAPE_H;
+    if (nfp == 4) return SHAPE_B;
+    if (nfp == 8) return SHAPE_C;
+    return SHAPE_H;
+}
+
+struct ConvArgs {
+    const char* layer;
+    int prod;
+    const void* in; void* out; const void* residual; void* split_tmp;
+    int n, H, W, Hi, Wi;   // output / input spatial dims
+    int ldi, ldo;          // row strides (elements)
+    int relu;
+};
+
+int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
+    auto it = c->layers.find(a.layer);
+    if (it == c->layers.end()) return fail(c, BQ_ERR_WEIGHTS, std::string("layer not loaded: ") + a.layer);
+    const GemmLayer& L = it->second;
+    const int dtype = c->cfg.dtype;
+    const int shape = pick_shape(c, a.prod, L.nfp);
+    if (shape < 0) return fail(c, BQ_ERR_ARG, std::string("no kernel shape for ") + a.layer);
+    const int vec = dtype == BQ_DTYPE_BF16 ? 8 : 4;
+    int nsplit = 1;
+    while (gemm_lds_bytes(dtype, shape, L.kpad / nsplit) > 160 * 1024) {
+        nsplit *= 2;
+        if ((L.kpad / nsplit) % (2 * vec) != 0 || nsplit > 8)
+            return fail(c, BQ_ERR_ARG, std::string("cannot split K for ") + a.layer);
+    }
+    if (nsplit > 1 && (a.residual || !a.split_tmp))
+        return fail(c, BQ_ERR_ARG, std::string("split-K needs a temp and no residual: ") + a.layer);
+
+    GemmParams p{};
+    p.in = a.in; p.wp = L.wp; p.dw = L.dw;
+    p.M = a.n * a.H * a.W;
+    p.KBtot = L.kpad / (2 * vec);
+    p.NFp = L.nfp; p.Nstore = a.ldo; p.ldo = a.ldo; p.ldi = a.ldi;
+    p.H = a.H; p.W = a.W; p.Hi = a.Hi; p.Wi = a.Wi;
+    const double es = (double)esize(c);
+    const double M = (double)p.M;
+    const bool dwp = a.prod == PROD_DW || a.prod == PROD_DW_RELU;
+    const double flops = 2.0 * M * L.cin * L.cout + (dwp ? 18.0 * M * L.cin : 0.0);
+    const double in_rows = (double)a.n * a.Hi * a.Wi;
+    const double kin = a.prod == PROD_IM2COL ? (double)a.ldi : (double)L.cin;
+    const double bytes = es * (in_rows * kin + M * L.cout * (a.residual ? 2.0 : 1.0)) +
+                         es * (double)L.cin * L.cout;
+    char cls[96];
+    snprintf(cls, sizeof cls, "%s_k%d_n%d_%dx%d",
+             a.prod == PROD_S2 ? "res1x1s2" : (a.prod == PROD_IM2COL ? "conv3x3" : "sepconv"), L.cin,
+             L.cout, a.H, a.W);
+    ProfScope ps(c, s, cls, flops, bytes);
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const bool last = sp == nsplit - 1;
+        p.K = L.kpad / nsplit;
+        p.k_off = sp * p.K;
+        p.kb0 = sp * (p.K / (2 * vec));
+        p.scale = L.scale;
+        p.bias = last ? L.bias : nullptr;
+        p.relu = last ? a.relu : 0;
+        p.residual = last ? (nsplit > 1 ? a.split_tmp : a.residual) : (sp > 0 ? a.split_tmp : nullptr);
+        p.out = last ? a.out : a.split_tmp;
+        const int e = launch_gemm(dtype, a.prod, shape, p, s);
+        if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch ") + a.layer + ": " +
+                                                   hipGetErrorString((hipError_t)e));
+    }
+    return BQ_OK;
+}
+
+struct Tap {
+    const char* want = nullptr;   // requested activation name (null: none)
+    float* out = nullptr;
+    size_t out_elems = 0;
+    int64_t written = -1;
+};
+
+// returns 1 if the tap matched (caller stops), 0 otherwise, <0 on error
+int tap_nhwc(bq_ctx* c, Tap* t, const char* name, const void* buf, int n, int H, int W, int C, int ld,
+             hipStream_t s) {
+    if (!t || !t->want || strcmp(t->want, name) != 0) return 0;
+    const long long rows = (long long)n * H * W;
+    if ((size_t)(rows * C) > t->out_elems) return fail(c, BQ_ERR_ARG, "debug output too small");
+    const int e = launch_to_f32_nhwc(buf, rows, C, ld, t->out, c->cfg.dtype, s);
+    if (e) return fail(c, BQ_ERR_HIP, "debug copy failed");
+    t->written = rows * C;
+    return 1;
+}
+
+#define RUN(expr) do { int _r = (expr); if (_r != BQ_OK) return _r; } while (0)
+#define TAP(name, buf, H, W, C, ld) \
+    do { int _t = tap_nhwc(c, tap, name, buf, n, H, W, C, ld, s); if (_t) return _t < 0 ? _t : BQ_OK; } while (0)
+
+int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned char* ws, hipStream_t s,
+                  Tap* tap) {
+    const WsLayout L = ws_layout(c, n, 1);
+    void* A = ws + L.a; void* B = ws + L.b; void* C = ws + L.c; void* R = ws + L.r;
+    const int dt = c->cfg.dtype;
+    const double es = (double)esize(c);
+    if (tap && tap->want && strcmp(tap->want, "staged") == 0) {
+        if ((size_t)n * kStaged > tap->out_elems) return fail(c, BQ_ERR_ARG, "debug output too small");
+        if (launch_nchw_to_f32_nhwc(in_nchw, n, 3, 299 * 299, tap->out, dt, s))
+            return fail(c, BQ_ERR_HIP, "debug copy failed");
+        tap->written = (int64_t)n * kStaged;
+        return BQ_OK;
+    }
+    {   // block1_conv1 + bn + relu  (vector ALU)
+        const double px = (double)n * 149 * 149;
+        ProfScope ps(c, s, "stem_conv1_3x3s2", 2.0 * px * 27 * 32, es * ((double)n * kStaged + px * 32));
+        if (launch_stem1(in_nchw, n, c->stem_w, c->stem_s, c->stem_b, A, dt, s))
+            return fail(c, BQ_ERR_HIP, "stem1 launch failed");
+    }
+    TAP("block1_conv1", A, 149, 149, 32, 32);
+    RUN(run_conv(c, {"block1_conv2", PROD_IM2COL, A, B, nullptr, nullptr, n, 147, 147, 149, 149, 32, 64, 1}, s));
+    TAP("block1_conv2", B, 147, 147, 64, 64);
+
+    // entry flow: blocks 2-4.  x lives in B.
+    struct Entry { int block, cin, cout, Hi; };
+    const Entry entry[3] = {{2, 64, 128, 147}, {3, 128, 256, 74}, {4, 256, 728, 37}};
+    for (const Entry& e : entry) {
+        const int Ho = (e.Hi + 1) / 2;
+        const int ci = pad16(e.cin), co = pad16(e.cout);
+        char nm[64], tn[64];
+        snprintf(nm, sizeof nm, "block%d_res", e.block);
+        RUN(run_conv(c, {nm, PROD_S2, B, R, nullptr, nullptr, n, Ho, Ho, e.Hi, e.Hi, ci, co, 0}, s));
+        TAP(nm, R, Ho, Ho, e.cout, co);
+        snprintf(nm, sizeof nm, "block%d_sepconv1", e.block);
+        RUN(run_conv(c, {nm, e.block == 2 ? PROD_DW : PROD_DW_RELU, B, A, nullptr, nullptr, n, e.Hi, e.Hi,
+                         e.Hi, e.Hi, ci, co, 1}, s));
+        TAP(nm, A, e.Hi, e.Hi, e.cout, co);
+        snprintf(nm, sizeof nm, "block%d_sepconv2", e.block);
+        RUN(run_conv(c, {nm, PROD_DW, A, C, nullptr, nullptr, n, e.Hi, e.Hi, e.Hi, e.Hi, co, co, 0}, s));
+        TAP(nm, C, e.Hi, e.Hi, e.cout, co);
+        {
+            const double px = (double)n * Ho * Ho * co;
+            snprintf(tn, sizeof tn, "maxpool_add_%d_c%d", e.Hi, e.cout);
+            ProfScope ps(c, s, tn, 9.0 * px, es * ((double)n * e.Hi * e.Hi * co + 2.0 * px));
+            if (launch_pool_add(C, R, B, n, e.Hi, e.Hi, co, dt, s))
+                return fail(c, BQ_ERR_HIP, "pool_add launch failed");
+        }
+        snprintf(nm, sizeof nm, "block%d_out", e.block);
+        TAP(nm, B, Ho, Ho, e.cout, co);
+    }
+    // middle flow: blocks 5-12 at 19x19x728 (stride 736)
+    void* X = B; void* Y = A;
+    for (int block = 5; block <= 12; ++block) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "block%d_sepconv1", block);
+        RUN(run_conv(c, {nm, PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1}, s));
+        snprintf(nm, sizeof nm, "block%d_sepconv2", block);
+        RUN(run_conv(c, {nm, PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1}, s));
+        snprintf(nm, sizeof nm, "block%d_sepconv3", block);
+        RUN(run_conv(c, {nm, PROD_DW, C, Y, X, nullptr, n, 19, 19, 19, 19, 736, 736, 0}, s));
+        void* t = X; X = Y; Y = t;
+        snprintf(nm, sizeof nm, "block%d_out", block);
+        TAP(nm, X, 19, 19, 728, 736);
+    }
+    // exit flow
+    RUN(run_conv(c, {"block13_res", PROD_S2, X, R, nullptr, nullptr, n, 10, 10, 19, 19, 736, 1024, 0}, s));
+    RUN(run_conv(c, {"block13_sepconv1", PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1}, s));
+    RUN(run_conv(c, {"block13_sepconv2", PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 1024, 0}, s));
+    {
+        const double px = (double)n * 100 * 1024;
+        ProfScope ps(c, s, "maxpool_add_19_c1024", 9.0 * px, es * ((double)n * 361 * 1024 + 2.0 * px));
+        if (launch_pool_add(C, R, X, n, 19, 19, 1024, dt, s)) return fail(c, BQ_ERR_HIP, "pool_add launch failed");
+    }
+    TAP("block13_out", X, 10, 10, 1024, 1024);
+    RUN(run_conv(c, {"block14_sepconv1", PROD_DW, X, Y, nullptr, C, n, 10, 10, 10, 10, 1024, 1536, 1}, s));
+    TAP("block14_sepconv1", Y, 10, 10, 1536, 1536);
+    RUN(run_conv(c, {"block14_sepconv2", PROD_DW, Y, C, nullptr, X, n, 10, 10, 10, 10, 1536, 2048, 1}, s));
+    TAP("block14_sepconv2", C, 10, 10, 2048, 2048);
+    {
+        ProfScope ps(c, s, "global_avg_pool", (double)n * 100 * 2048, es * (double)n * 100 * 2048 + 4.0 * n * 2048);
+        if (launch_gap(C, n, 100, 2048, 2048, feat, dt, s)) return fail(c, BQ_ERR_HIP, "gap launch failed");
+    }
+    if (tap && tap->want) return fail(c, BQ_ERR_ARG, std::string("unknown activation: ") + tap->want);
+    return BQ_OK;
+}
+
+int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int pass0, uint64_t seed,
+              int init, int finalize, float* state, float* mean2, float* std2, unsigned char* ws,
+              hipStream_t s) {
+    const WsLayout L = ws_layout(c, n, mc_n);
+    float* hpart = (float*)(ws + L.hpart);
+    float* h0 = (float*)(ws + L.h0);
+    float* h1 = (float*)(ws + L.h1);
+    const double rate = (double)c->cfg.dropout;
+    double t = floor(rate * 4294967296.0);
+    if (t < 0) t = 0; if (t > 4294967295.0) t = 4294967295.0;
+    const unsigned thresh = (unsigned)t;
+    const float dscale = (float)(1.0 / (1.0 - rate));
+    const int rows = n * mc_n;
+    const char* names[2] = {"hidden_0", "hidden_1"};
+    for (int layer = 0; layer < 2; ++layer) {
+        auto it = c->layers.find(names[layer]);
+        if (it == c->layers.end()) return fail(c, BQ_ERR_WEIGHTS, "head weights not loaded");
+        const GemmLayer& G = it->second;
+        const int K = G.kpad;                    // 2048 / 1024
+        const int nsplit = K / 1024;             // K handled per launch = 1024 (131.6 KB of LDS)
+        ProfScope ps(c, s, layer == 0 ? "mc_head_dense0" : "mc_head_dense1", 2.0 * rows * (double)K * 1024,
+                     4.0 * ((layer == 0 ? (double)n : (double)rows) * K + (double)rows * 1024 + (double)K * 1024));
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const bool last = sp == nsplit - 1;
+            GemmParams p{};
+            p.in = layer == 0 ? (const void*)feat : (const void*)h0;
+            p.wp = G.wp;
+            p.scale = nullptr;
+            p.bias = last ? G.bias : nullptr;
+            p.residual = sp > 0 ? hpart : nullptr;
+            p.out = last ? (layer == 0 ? h0 : h1) : hpart;
+            p.M = rows; p.K = 1024; p.KBtot = K / 8; p.kb0 = sp * 128; p.k_off = sp * 1024;
+            p.NFp = G.nfp; p.Nstore = 1024; p.ldo = 1024; p.ldi = K;
+            p.relu = last ? 1 : 0;
+            p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32);
+            p.thresh = thresh; p.dscale = dscale; p.layer = layer; p.mc_n = mc_n; p.pass0 = pass0;
+            p.in_row_is_tile = layer == 0 ? 1 : 0; p.tile0 = tile0;
+            const int e = launch_gemm(BQ_DTYPE_F32, PROD_DROPOUT, SHAPE_H, p, s);
+            if (e) return fail(c, BQ_ERR_HIP, std::string("head dense launch: ") + hipGetErrorString((hipError_t)e));
+        }
+    }
+    {
+        ProfScope ps(c, s, "mc_head_softmax_welford", 2.0 * rows * 1024 * 2, 4.0 * rows * 1024);
+        if (launch_head_final(h1, n, mc_n, pass0, tile0, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32),
+                              thresh, dscale, c->logits_w, c->logits_b, init, finalize, state, mean2, std2, s))
+            return fail(c, BQ_ERR_HIP, "head_final launch failed");
+    }
+    return BQ_OK;
+}
+
+const float* entry_f32(bq_ctx* c, const std::string& name) {
+    auto it = c->entries.find(name);
+    return it == c->entries.end() ? nullptr : reinterpret_cast<const float*>(it->second.p);
+}
+
+int register_gemm_layer(bq_ctx* c, const std::string& name, int cin, int cout, int kpad, bool has_dw,
+                        int vec, int elt) {
+    GemmLayer L;
+    L.name = name; L.cin = cin; L.cout = cout; L.kpad = kpad;
+    auto w = c->entries.find(name + "/wp");
+    if (w == c->entries.end()) return fail(c, BQ_ERR_WEIGHTS, "missing " + name + "/wp");
+    const size_t per_nf = (size_t)(kpad / (2 * vec)) * 64 * vec * elt;
+    if (per_nf == 0 || w->second.n % per_nf) return fail(c, BQ_ERR_WEIGHTS, "bad size for " + name + "/wp");
+    L.nfp = (int)(w->second.n / per_nf);
+    if (L.nfp * 32 < cout) return fail(c, BQ_ERR_WEIGHTS, "too few output fragments in " + name);
+    L.wp = w->second.p;
+    L.scale = entry_f32(c, name + "/scale");
+    L.bias = entry_f32(c, name + "/bias");
+    if (!L.scale || !L.bias) return fail(c, BQ_ERR_WEIGHTS, "missing scale/bias for " + name);
+    if (has_dw) {
+        L.dw = entry_f32(c, name + "/dw");
+        if (!L.dw) return fail(c, BQ_ERR_WEIGHTS, "missing " + name + "/dw");
+    }
+    c->layers[name] = L;
+    return BQ_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+bq_ctx* bq_create(int device_id, const bq_config* cfg) {
+    if (!cfg) { g_create_error = "cfg is null"; return nullptr; }
+    if (cfg->tile_px != 299 || cfg->n_classes != 2 ||
+        (cfg->dtype != BQ_DTYPE_F32 && cfg->dtype != BQ_DTYPE_BF16) || !(cfg->dropout >= 0.f) ||
+        !(cfg->dropout < 1.f)) {
+        g_create_error = "unsupported config (need tile_px=299, n_classes=2, dtype f32|bf16, 0<=dropout<1)";
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
+        g_create_error = "no such HIP device";
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return nullptr; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("libbiscuit_hip is built for gfx950 only, device is ") + prop.gcnArchName;
+        return nullptr;
+    }
+    bq_ctx* c = new (std::nothrow) bq_ctx();
+    if (!c) { g_create_error = "out of host memory"; return nullptr; }
+    c->cfg = *cfg;
+    c->device = device_id;
+    return c;
+}
+
+void bq_destroy(bq_ctx* c) {
+    if (!c) return;
+    if (c->d_blob) hipFree(c->d_blob);
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    delete c;
+}
+
+const char* bq_last_error(bq_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+size_t bq_workspace_bytes(bq_ctx* c, int batch, int mc_n) {
+    if (!c || batch <= 0) return 0;
+    return ws_layout(c, batch, mc_n).total;
+}
+
+int bq_load_weights(bq_ctx* c, const void* host_blob, size_t nbytes) {
+    if (!c || !host_blob || nbytes < 16) return fail(c, BQ_ERR_ARG, "bad weight blob");
+    const unsigned char* hb = (const unsigned char*)host_blob;
+    uint32_t ver, cnt, dt;
+    if (memcmp(hb, "BQW1", 4) != 0) return fail(c, BQ_ERR_WEIGHTS, "bad magic (want BQW1)");
+    memcpy(&ver, hb + 4, 4); memcpy(&cnt, hb + 8, 4); memcpy(&dt, hb + 12, 4);
+    if (ver != 1 || (size_t)16 + (size_t)cnt * 64 > nbytes) return fail(c, BQ_ERR_WEIGHTS, "bad header");
+    if ((int)dt != c->cfg.dtype) return fail(c, BQ_ERR_WEIGHTS, "blob dtype does not match context dtype");
+    int prev = 0;
+    HIPCHK(c, hipGetDevice(&prev));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->d_blob) { hipFree(c->d_blob); c->d_blob = nullptr; }
+    c->entries.clear(); c->layers.clear(); c->loaded = false;
+    HIPCHK(c, hipMalloc((void**)&c->d_blob, nbytes));
+    HIPCHK(c, hipMemcpy(c->d_blob, hb, nbytes, hipMemcpyHostToDevice));
+    hipSetDevice(prev);
+    c->blob_bytes = nbytes;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const unsigned char* e = hb + 16 + (size_t)i * 64;
+        char name[49]; memcpy(name, e, 48); name[48] = 0;
+        uint64_t off, len; memcpy(&off, e + 48, 8); memcpy(&len, e + 56, 8);
+        if (off + len > nbytes || (off & 255)) return fail(c, BQ_ERR_WEIGHTS, std::string("bad entry ") + name);
+        c->entries[name] = Blob{c->d_blob + off, (size_t)len};
+    }
+    const int vec = c->cfg.dtype == BQ_DTYPE_BF16 ? 8 : 4;
+    const int elt = c->cfg.dtype == BQ_DTYPE_BF16 ? 2 : 4;
+    c->stem_w = entry_f32(c, "block1_conv1/w");
+    c->stem_s = entry_f32(c, "block1_conv1/scale");
+    c->stem_b = entry_f32(c, "block1_conv1/bias");
+    c->logits_w = entry_f32(c, "logits/w");
+    c->logits_b = entry_f32(c, "logits/bias");
+    if (!c->stem_w || !c->stem_s || !c->stem_b || !c->logits_w || !c->logits_b)
+        return fail(c, BQ_ERR_WEIGHTS, "missing stem/logits tensors");
+    RUN(register_gemm_layer(c, "block1_conv2", 32, 64, 288, false, vec, elt));
+    const int res[4][3] = {{2, 64, 128}, {3, 128, 256}, {4, 256, 728}, {13, 728, 1024}};
+    for (auto& r : res)
+        RUN(register_gemm_layer(c, "block" + std::to_string(r[0]) + "_res", r[1], r[2], pad16(r[1]), false, vec, elt));
+    struct S { int block, idx, cin, cout; };
+    std::vector<S> seps = {{2, 1, 64, 128}, {2, 2, 128, 128}, {3, 1, 128, 256}, {3, 2, 256, 256},
+                           {4, 1, 256, 728}, {4, 2, 728, 728}};
+    for (int b = 5; b <= 12; ++b) for (int i = 1; i <= 3; ++i) seps.push_back({b, i, 728, 728});
+    seps.push_back({13, 1, 728, 728}); seps.push_back({13, 2, 728, 1024});
+    seps.push_back({14, 1, 1024, 1536}); seps.push_back({14, 2, 1536, 2048});
+    for (auto& sp : seps)
+        RUN(register_gemm_layer(c, "block" + std::to_string(sp.block) + "_sepconv" + std::to_string(sp.idx),
+                                sp.cin, sp.cout, pad16(sp.cin), true, vec, elt));
+    RUN(register_gemm_layer(c, "hidden_0", 2048, 1024, 2048, false, 4, 4));
+    RUN(register_gemm_layer(c, "hidden_1", 1024, 1024, 1024, false, 4, 4));
+    c->loaded = true;
+    return BQ_OK;
+}
+
+int bq_stage(bq_ctx* c, const uint8_t* d_tiles, int n, void* d_out, bq_stream_t stream) {
+    if (!c || !d_tiles || !d_out || n < 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_stage: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(c, s, "stage_u8_standardize", 4.0 * n * kStaged, (double)n * kStaged * (1.0 + esize(c)));
+    if (launch_stage_u8(d_tiles, n, 299, d_out, c->cfg.dtype, nullptr, s)) return fail(c, BQ_ERR_HIP, "stage launch failed");
+    return BQ_OK;
+}
+
+int bq_stage_f32(bq_ctx* c, const float* d_tiles, int n, void* d_out, bq_stream_t stream) {
+    if (!c || !d_tiles || !d_out || n < 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_stage_f32: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(c, s, "stage_f32_to_planar", 0.0, (double)n * kStaged * (4.0 + esize(c)));
+    if (launch_stage_f32(d_tiles, n, 299, d_out, c->cfg.dtype, s)) return fail(c, BQ_ERR_HIP, "stage launch failed");
+    return BQ_OK;
+}
+
+int bq_backbone(bq_ctx* c, const void* d_in, int n, float* d_feat, void* d_ws, size_t ws_bytes,
+                bq_stream_t stream) {
+    if (!c || !d_in || !d_feat || !d_ws || n <= 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_backbone: bad argument");
+    if (!c->loaded) return fail(c, BQ_ERR_WEIGHTS, "weights not loaded");
+    if (ws_bytes < ws_layout(c, n, 1).total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
+    return backbone_impl(c, d_in, n, d_feat, (unsigned char*)d_ws, (hipStream_t)stream, nullptr);
+}
+
+int bq_mc_head(bq_ctx* c, const float* d_feat, int n, int64_t tile_idx0, int mc_n, int pass0, uint64_t seed,
+               int init, int finalize, float* d_state, float* d_mean2, float* d_std2, void* d_ws,
+               size_t ws_bytes, bq_stream_t stream) {
+    if (!c || !d_feat || !d_state || !d_ws || n <= 0 || mc_n <= 0 || n > c->cfg.max_batch ||
+        mc_n > c->cfg.max_mc || pass0 < 0 || (finalize && (!d_mean2 || !d_std2)))
+        return fail(c, BQ_ERR_ARG, "bq_mc_head: bad argument");
+    if (!c->loaded) return fail(c, BQ_ERR_WEIGHTS, "weights not loaded");
+    if (ws_bytes < ws_layout(c, n, mc_n).total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
+    return head_impl(c, d_feat, n, tile_idx0, mc_n, pass0, seed, init, finalize, d_state, d_mean2, d_std2,
+                     (unsigned char*)d_ws, (hipStream_t)stream);
+}
+
+int bq_mc_infer(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int mc_n, uint64_t seed,
+                int mc_mode, float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes, bq_stream_t stream) {
+    if (!c || !d_tiles || !d_mean2 || !d_std2 || !d_ws || n <= 0 || mc_n <= 0 || n > c->cfg.max_batch ||
+        mc_n > c->cfg.max_mc || (mc_mode != BQ_MC_HEAD && mc_mode != BQ_MC_FULL))
+        return fail(c, BQ_ERR_ARG, "bq_mc_infer: bad argument");
+    if (!c->loaded) return fail(c, BQ_ERR_WEIGHTS, "weights not loaded");
+    const WsLayout L = ws_layout(c, n, mc_n);
+    if (ws_bytes < L.total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
+    unsigned char* ws = (unsigned char*)d_ws;
+    hipStream_t s = (hipStream_t)stream;
+    void* staged = ws + L.staged;
+    float* feat = (float*)(ws + L.feat);
+    float* state = (float*)(ws + L.state);
+    if (mc_mode == BQ_MC_HEAD) {
+        RUN(bq_stage(c, d_tiles, n, staged, stream));
+        RUN(backbone_impl(c, staged, n, feat, ws, s, nullptr));
+        return head_impl(c, feat, n, tile_idx0, mc_n, 0, seed, 1, 1, state, d_mean2, d_std2, ws, s);
+    }
+    // BQ_MC_FULL: the reference's loop structure -- the whole network once per pass.
+    for (int p = 0; p < mc_n; ++p) {
+        RUN(bq_stage(c, d_tiles, n, staged, stream));
+        RUN(backbone_impl(c, staged, n, feat, ws, s, nullptr));
+        RUN(head_impl(c, feat, n, tile_idx0, 1, p, seed, p == 0, p == mc_n - 1, state, d_mean2, d_std2, ws, s));
+    }
+    return BQ_OK;
+}
+
+int bq_slide_reduce(bq_ctx* c, const float* d_mean2, const float* d_std2, const int32_t* d_slide_idx, int n,
+                    int n_slides, float tile_uq, int64_t* d_acc_pred, int64_t* d_acc_unc, int32_t* d_count,
+                    bq_stream_t stream) {
+    if (!c || !d_mean2 || !d_std2 || !d_slide_idx || !d_acc_pred || !d_acc_unc || !d_count || n < 0 || n_slides <= 0)
+        return fail(c, BQ_ERR_ARG, "bq_slide_reduce: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(c, s, "slide_reduce", 2.0 * n, 20.0 * n);
+    if (launch_slide_reduce(d_mean2, d_std2, d_slide_idx, n, n_slides, tile_uq, (long long*)d_acc_pred,
+                            (long long*)d_acc_unc, d_count, s))
+        return fail(c, BQ_ERR_HIP, "slide_reduce launch failed");
+    return BQ_OK;
+}
+
+int bq_slide_finish(bq_ctx* c, const int64_t* d_acc_pred, const int64_t* d_acc_unc, const int32_t* d_count,
+                    int n_slides, double* d_mean_pred, double* d_mean_unc, bq_stream_t stream) {
+    if (!c || !d_acc_pred || !d_acc_unc || !d_count || !d_mean_pred || !d_mean_unc || n_slides <= 0)
+        return fail(c, BQ_ERR_ARG, "bq_slide_finish: bad argument");
+    if (launch_slide_finish((const long long*)d_acc_pred, (const long long*)d_acc_unc, d_count, n_slides,
+                            d_mean_pred, d_mean_unc, (hipStream_t)stream))
+        return fail(c, BQ_ERR_HIP, "slide_finish launch failed");
+    return BQ_OK;
+}
+
+int bq_profile_enable(bq_ctx* c, int on) {
+    if (!c) return BQ_ERR_ARG;
+    c->prof = on != 0;
+    if (on) {
+        c->prof_recs.clear(); c->ev_used = 0;
+        c->prof_names.clear(); c->prof_flops.clear(); c->prof_bytes.clear();
+        c->prof_launches.clear(); c->prof_ms.clear();
+    }
+    return BQ_OK;
+}
+
+int bq_profile_read(bq_ctx* c, bq_prof_entry* out, int max_entries) {
+    if (!c || !out || max_entries <= 0) return BQ_ERR_ARG;
+    for (const ProfRec& r : c->prof_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return fail(c, BQ_ERR_HIP, "event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return fail(c, BQ_ERR_HIP, "event elapsed failed");
+        c->prof_ms[r.cls] += ms;
+        c->prof_launches[r.cls] += 1;
+    }
+    c->prof_recs.clear();
+    c->ev_used = 0;
+    int k = 0;
+    for (size_t i = 0; i < c->prof_names.size() && k < max_entries; ++i, ++k) {
+        memset(&out[k], 0, sizeof out[k]);
+        strncpy(out[k].name, c->prof_names[i].c_str(), sizeof out[k].name - 1);
+        out[k].launches = c->prof_launches[i];
+        out[k].ms = c->prof_ms[i];
+        out[k].flops = c->prof_flops[i];
+        out[k].bytes = c->prof_bytes[i];
+    }
+    return k;
+}
+
+int64_t bq_debug_activation(bq_ctx* c, const char* name, const void* d_in, int n, void* d_ws, size_t ws_bytes,
+                            float* d_out, size_t out_elems, bq_stream_t stream) {
+    if (!c || !name || !d_in || !d_ws || !d_out || n <= 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_debug_activation: bad argument");
+    if (!c->loaded) return fail(c, BQ_ERR_WEIGHTS, "weights not loaded");
+    const WsLayout L = ws_layout(c, n, 1);
+    if (ws_bytes < L.total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
+    Tap t; t.want = name; t.out = d_out; t.out_elems = out_elems;
+    unsigned char* ws = (unsigned char*)d_ws;
+    const int r = backbone_impl(c, d_in, n, (float*)(ws + L.feat), ws, (hipStream_t)stream, &t);
+    if (r != BQ_OK) return r;
+    return t.written;
+}
+
+}  // extern "C"

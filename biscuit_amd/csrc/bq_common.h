@@ -1,0 +1,105 @@
+// Shared declarations of libbiscuit_hip.so (gfx950 only; no CUDA/dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- fused "producer -> LDS A tile -> MFMA" kernel -------------------------------
+enum BqProducer : int {
+    PROD_DW = 0,      // depthwise 3x3 'same' of an NHWC map (SeparableConv2D first half)
+    PROD_DW_RELU = 1, // same, ReLU applied to the input on load (block*_sepconv1_act)
+    PROD_S2 = 2,      // 1x1 / stride-2 gather (residual Conv2D(1, strides=2, 'same'))
+    PROD_IM2COL = 3,  // 3x3 valid im2col, K = 9*C (block1_conv2)
+    PROD_DROPOUT = 4  // Philox inverted dropout of fp32 rows (MC head Dense layers)
+};
+
+enum BqShape : int {       // MF, WM, WN, RN   (tile rows = 32*MF, waves = WM*WN)
+    SHAPE_A = 0,           // 4, 2, 2, 1   N = 64           (block1_conv2)
+    SHAPE_B = 1,           // 4, 1, 4, 1   N = 128
+    SHAPE_C = 2,           // 4, 1, 4, 2   N = 256
+    SHAPE_D = 3,           // 3, 1, 8, 3   N = 768 per pass (728-wide layers)
+    SHAPE_E = 4,           // 3, 1, 8, 2   N = 512 per pass
+    SHAPE_F = 5,           // 2, 1, 8, 3
+    SHAPE_G = 6,           // 1, 1, 8, 4
+    SHAPE_H = 7            // 1, 1, 4, 2   fp32 fallback / MC head
+};
+
+struct GemmParams {
+    const void* in;        // producer input
+    const void* wp;        // fragment-packed weights [NFp][KBtot][64][VEC]
+    const float* scale;    // per-cout, may be null (=1)
+    const float* bias;     // per-cout, may be null (=0)
+    const float* dw;       // [9][ldi] depthwise taps (PROD_DW*)
+    const void* residual;  // optional [M][ldo], added before ReLU
+    void* out;             // [M][ldo]
+    int M;                 // rows (pixels, or tile*pass rows for the head)
+    int K;                 // contraction length handled by this launch (multiple of 2*VEC)
+    int KBtot;             // k-blocks per n-frag in wp (stride), kb0 = first block used
+    int kb0;
+    int k_off;             // first input channel / unit handled (split-K launches)
+    int NFp;               // n-frags to compute (multiple of WN*RN)
+    int Nstore;            // output channels actually stored (multiple of 4, <= ldo)
+    int ldo;               // output row stride (elements)
+    int ldi;               // input row stride (elements)
+    int H, W;              // output spatial size
+    int Hi, Wi;            // input spatial size
+    int relu;              // ReLU in the epilogue
+    // PROD_DROPOUT
+    unsigned seed_lo, seed_hi, thresh;
+    float dscale;
+    int layer, mc_n, pass0, in_row_is_tile;
+    long long tile0;
+};
+
+size_t gemm_lds_bytes(int dtype, int shape, int K);
+// Returns hipError_t as int.
+int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t s);
+int gemm_tile_rows(int shape);
+
+// ---- small kernels (kernels_misc.hip) ----------------------------------------------
+int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, double* stats_scratch,
+                    hipStream_t s);
+int launch_stage_f32(const float* tiles, int n, int px, void* out, int dtype, hipStream_t s);
+int launch_stem1(const void* in_nchw, int n, const float* w27x32, const float* scale,
+                 const float* bias, void* out_nhwc, int dtype, hipStream_t s);
+int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, int Wi, int C,
+                    int dtype, hipStream_t s);
+int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s);
+int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0,
+                      unsigned seed_lo, unsigned seed_hi, unsigned thresh, float dscale,
+                      const float* w2, const float* b2, int init, int finalize, float* state,
+                      float* mean2, float* std2, hipStream_t s);
+int launch_slide_reduce(const float* mean2, const float* std2, const int32_t* slide_idx, int n,
+                        int n_slides, float tile_uq, long long* acc_pred, long long* acc_unc,
+                        int32_t* count, hipStream_t s);
+int launch_slide_finish(const long long* acc_pred, const long long* acc_unc, const int32_t* count,
+                        int n_slides, double* mean_pred, double* mean_unc, hipStream_t s);
+int launch_to_f32_nhwc(const void* x, long long rows, int C, int ld, float* out, int dtype,
+                       hipStream_t s);
+int launch_nchw_to_f32_nhwc(const void* x, int n, int C, int HW, float* out, int dtype,
+                            hipStream_t s);
+
+// ---- device helpers ----------------------------------------------------------------
+#define BQ_FIXED_SHIFT 40
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned)b) << 16);
+}
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                              unsigned k0, unsigned k1, unsigned (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}

@@ -1,0 +1,417 @@
+// Fused "producer -> LDS A tile -> MFMA" kernel: the workhorse of the Xception backbone
+// (SeparableConv2D = depthwise 3x3 + pointwise 1x1 + folded BN [+ residual] [+ ReLU],
+// residual 1x1/s2 convs, block1_conv2 as im2col) and of the MC-dropout Dense layers.
+//
+// Design (gfx950 / CDNA4, wave64):
+//  * One workgroup owns MT = 32*MF output pixels and ALL output channels.  Phase 1
+//    builds the [MT][K] A operand in LDS once (depthwise 3x3 on the vector ALU, a
+//    stride-2 gather, an im2col gather, or Philox dropout), so the depthwise result never
+//    touches HBM and is not recomputed per output-channel tile.
+//  * Phase 2: every wave owns RN 32-wide output-channel fragments per pass and all RM
+//    row fragments; weights were pre-swizzled on the host into MFMA fragment order, so a
+//    B fragment is ONE coalesced 1 KiB global load straight into VGPRs (L2-resident
+//    weights, no LDS hop), prefetched PF k-blocks ahead through a register ring.
+//  * MFMA orientation D[cout][pixel] = W[cout][k] * A[k][pixel]: each lane then holds
+//    4 consecutive output channels of one pixel per accumulator quad, i.e. 8-byte (bf16)
+//    or 16-byte (fp32) NHWC stores instead of 2-byte ones.
+//  * LDS row stride is an odd number of 16-byte slots: ds_read_b128 of 16 distinct rows
+//    is bank-conflict free (MI355X guide, LDS section).
+//  * bf16 uses v_mfma_f32_32x32x16_bf16; fp32 (parity mode and the MC head) uses four
+//    exact-fp32 v_mfma_f32_32x32x2_f32 per 16-byte fragment with the k order permuted
+//    identically on both operands.
+#include "bq_common.h"
+
+namespace {
+
+template <typename T> struct TT;
+template <> struct TT<bf16_t> { static constexpr int VEC = 8; };
+template <> struct TT<float> { static constexpr int VEC = 4; };
+
+template <typename T> __device__ __forceinline__ void unpack(const uint4& v, float* f);
+template <> __device__ __forceinline__ void unpack<bf16_t>(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack<float>(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+    f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const unsigned short a = __builtin_bit_cast(unsigned short, (bf16_t)lo);
+    const unsigned short b = __builtin_bit_cast(unsigned short, (bf16_t)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+template <typename T> __device__ __forceinline__ uint4 pack(const float* f);
+template <> __device__ __forceinline__ uint4 pack<bf16_t>(const float* f) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                      pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+template <> __device__ __forceinline__ uint4 pack<float>(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                      __float_as_uint(f[3]));
+}
+
+// 4 consecutive output channels of one pixel
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
+    const float4 u = *reinterpret_cast<const float4*>(p);
+    v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <typename T>
+__device__ __forceinline__ void mma(f32x16& acc, const uint4& w, const uint4& a);
+template <> __device__ __forceinline__ void mma<bf16_t>(f32x16& acc, const uint4& w, const uint4& a) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w),
+                                                   __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const uint4& w, const uint4& a) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
+}
+
+// Row iterator over flattened (image, y, x) pixel indices of an H x W map.
+struct PixIt {
+    int img, y, x;
+    __device__ __forceinline__ void init(int p, int H, int W) {
+        const int hw = H * W;
+        img = p / hw;
+        const int rem = p - img * hw;
+        y = rem / W;
+        x = rem - y * W;
+    }
+    __device__ __forceinline__ void advance(int step, int H, int W) {
+        x += step;
+        while (x >= W) { x -= W; ++y; }
+        while (y >= H) { y -= H; ++img; }
+    }
+};
+
+// ------------------------------------------------------------------ producers
+template <typename T, int PROD, int MT, int NT>
+__device__ __forceinline__ void produce(const GemmParams& p, unsigned char* smem, int stride,
+                                        int m0, int tid) {
+    constexpr int VEC = TT<T>::VEC;
+    const int CH = p.K / VEC;
+    const int cpp = CH < NT ? CH : NT;  // chunk columns handled per sweep
+    const int RF = NT / cpp;            // rows in flight
+    const int tc = tid % cpp, tr = tid / cpp;
+    if (tr >= RF) return;
+    const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
+    const int ldi = p.ldi;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    for (int c = tc; c < CH; c += cpp) {
+        const int ch0 = p.k_off + c * VEC;  // first input channel / unit of this chunk
+        if constexpr (PROD == PROD_DW || PROD == PROD_DW_RELU) {
+            const int H = p.H, W = p.W;
+            float w[9][VEC];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < VEC; j += 4) {
+                    const float4 wv = *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + ch0 + j);
+                    w[t][j] = wv.x; w[t][j + 1] = wv.y; w[t][j + 2] = wv.z; w[t][j + 3] = wv.w;
+                }
+            PixIt it;
+            it.init(m0 + tr, H, W);
+            for (int r = tr; r < MT; r += RF) {
+                if (m0 + r < p.M) {
+                    float acc[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+                    uint4 v[9];
+                    bool ok[9];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int yy = it.y + dy - 1;
+                        const bool vy = (unsigned)yy < (unsigned)H;
+                        const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int xx = it.x + dx - 1;
+                            ok[dy * 3 + dx] = vy && ((unsigned)xx < (unsigned)W);
+                            const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+                            const size_t off = ((size_t)(it.img * H + yc) * W + xc) * ldi + ch0;
+                            v[dy * 3 + dx] = *reinterpret_cast<const uint4*>(in + off);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const uint4 vv = ok[t] ? v[t] : zero4;
+                        float f[VEC];
+                        unpack<T>(vv, f);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            if (PROD == PROD_DW_RELU) f[j] = fmaxf(f[j], 0.f);
+                            acc[j] = fmaf(w[t][j], f[j], acc[j]);
+                        }
+                    }
+                    *reinterpret_cast<uint4*>(smem + (size_t)r * stride + c * 16) = pack<T>(acc);
+                }
+                it.advance(RF, H, W);
+            }
+        } else if constexpr (PROD == PROD_S2) {
+            const int H = p.H, W = p.W;  // output map
+            PixIt it;
+            it.init(m0 + tr, H, W);
+            for (int r = tr; r < MT; r += RF) {
+                if (m0 + r < p.M) {
+                    const size_t off = ((size_t)(it.img * p.Hi + 2 * it.y) * p.Wi + 2 * it.x) * ldi + ch0;
+                    *reinterpret_cast<uint4*>(smem + (size_t)r * stride + c * 16) =
+                        *reinterpret_cast<const uint4*>(in + off);
+                }
+                it.advance(RF, H, W);
+            }
+        } else if constexpr (PROD == PROD_IM2COL) {
+            const int H = p.H, W = p.W;  // output map (valid conv: Hi = H + 2)
+            const int tap = ch0 / ldi, cc = ch0 - tap * ldi;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            PixIt it;
+            it.init(m0 + tr, H, W);
+            for (int r = tr; r < MT; r += RF) {
+                if (m0 + r < p.M) {
+                    const size_t off = ((size_t)(it.img * p.Hi + it.y + dy) * p.Wi + it.x + dx) * ldi + cc;
+                    *reinterpret_cast<uint4*>(smem + (size_t)r * stride + c * 16) =
+                        *reinterpret_cast<const uint4*>(in + off);
+                }
+                it.advance(RF, H, W);
+            }
+        } else {  // PROD_DROPOUT (T = float): Philox4x32-10 inverted dropout
+            for (int r = tr; r < MT; r += RF) {
+                const int m = m0 + r;
+                if (m < p.M) {
+                    const int tile = m / p.mc_n;
+                    const int pass = p.pass0 + (m - tile * p.mc_n);
+                    const size_t row = p.in_row_is_tile ? (size_t)tile : (size_t)m;
+                    const uint4 vv = *reinterpret_cast<const uint4*>(in + row * ldi + ch0);
+                    unsigned rnd[4];
+                    philox4x32_10((unsigned)(ch0 >> 2), (unsigned)p.layer, (unsigned)pass,
+                                  (unsigned)(p.tile0 + tile), p.seed_lo, p.seed_hi, rnd);
+                    float f[4];
+                    f[0] = __uint_as_float(vv.x); f[1] = __uint_as_float(vv.y);
+                    f[2] = __uint_as_float(vv.z); f[3] = __uint_as_float(vv.w);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f[j] = (rnd[j] >= p.thresh) ? f[j] * p.dscale : 0.f;
+                    *reinterpret_cast<uint4*>(smem + (size_t)r * stride + c * 16) =
+                        make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]),
+                                   __float_as_uint(f[2]), __float_as_uint(f[3]));
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the kernel
+template <typename T, int PROD, int MF, int WM, int WN, int RN, int PF>
+__global__ void __launch_bounds__(64 * WM * WN) gemm_fused_kernel(const GemmParams p) {
+    constexpr int VEC = TT<T>::VEC;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int MT = 32 * MF;
+    constexpr int RM = MF / WM;
+    static_assert(MF % WM == 0, "row fragments must split evenly over WM");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    // XCD-aware block -> tile map (bijective): blocks b, b+8, ... share an XCD/L2, give
+    // them neighbouring pixel tiles so depthwise halos are L2 hits.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int m0 = tile * MT;
+    const int CH = p.K / VEC;
+    const int stride = (CH | 1) * 16;
+
+    produce<T, PROD, MT, NT>(p, smem, stride, m0, tid);
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int KB = p.K / (2 * VEC);
+    const unsigned char* a_base = smem + (size_t)(wm * RM * 32 + r32) * stride + h * 16;
+    const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(p.wp);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+
+    for (int nfb = wn * RN; nfb < p.NFp; nfb += WN * RN) {
+        f32x16 acc[RM][RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        const uint4* bp[RN];
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+            bp[j] = wp + ((size_t)(nfb + j) * p.KBtot + p.kb0) * 64 + lane;
+
+        uint4 bq[PF][RN];
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int idx = d < KB ? d : KB - 1;
+#pragma unroll
+            for (int j = 0; j < RN; ++j) bq[d][j] = bp[j][(size_t)idx * 64];
+        }
+
+        int kb = 0;
+        for (; kb + PF <= KB; kb += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                uint4 a[RM];
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+                    a[i] = *reinterpret_cast<const uint4*>(a_base + (size_t)i * 32 * stride + (kb + d) * 32);
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) mma<T>(acc[i][j], bq[d][j], a[i]);
+                const int nx = kb + d + PF;
+                const int idx = nx < KB ? nx : KB - 1;
+#pragma unroll
+                for (int j = 0; j < RN; ++j) bq[d][j] = bp[j][(size_t)idx * 64];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            if (kb + d < KB) {
+                uint4 a[RM];
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+                    a[i] = *reinterpret_cast<const uint4*>(a_base + (size_t)i * 32 * stride + (kb + d) * 32);
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) mma<T>(acc[i][j], bq[d][j], a[i]);
+            }
+        }
+
+        // epilogue: folded BN, residual, ReLU, NHWC store (4 channels per lane per quad)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = (nfb + j) * 32 + g * 8 + h * 4;
+                if (n0 < p.Nstore) {
+                    float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.scale) {
+                        const float4 t = *reinterpret_cast<const float4*>(p.scale + n0);
+                        sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w;
+                    }
+                    if (p.bias) {
+                        const float4 t = *reinterpret_cast<const float4*>(p.bias + n0);
+                        bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) {
+                        const int m = m0 + (wm * RM + i) * 32 + r32;
+                        if (m < p.M) {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[i][j][g * 4 + e], sc[e], bi[e]);
+                            const size_t o = (size_t)m * p.ldo + n0;
+                            if (res) {
+                                float rv[4];
+                                load4<T>(res + o, rv);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                            }
+                            if (p.relu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            store4<T>(out + o, v);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+struct ShapeDesc { int MF, WM, WN, RN; };
+constexpr ShapeDesc kShapes[8] = {{4, 2, 2, 1}, {4, 1, 4, 1}, {4, 1, 4, 2}, {3, 1, 8, 3},
+                                  {3, 1, 8, 2}, {2, 1, 8, 3}, {1, 1, 8, 4}, {1, 1, 4, 2}};
+
+template <typename T, int PROD, int SH>
+int launch_inst(const GemmParams& p, hipStream_t s) {
+    constexpr ShapeDesc d = kShapes[SH];
+    constexpr int PF = 4;
+    auto kern = gemm_fused_kernel<T, PROD, d.MF, d.WM, d.WN, d.RN, PF>;
+    const int vec = TT<T>::VEC;
+    const size_t lds = (size_t)(((p.K / vec) | 1) * 16) * (32 * d.MF);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_set = lds;
+    }
+    if (p.NFp % (d.WN * d.RN) != 0 || p.K % (2 * vec) != 0 || lds > 160 * 1024)
+        return (int)hipErrorInvalidValue;
+    const int mt = 32 * d.MF;
+    const int grid = (p.M + mt - 1) / mt;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * d.WM * d.WN), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int gemm_tile_rows(int shape) { return 32 * kShapes[shape].MF; }
+
+size_t gemm_lds_bytes(int dtype, int shape, int K) {
+    const int vec = dtype == 1 ? 8 : 4;
+    return (size_t)(((K / vec) | 1) * 16) * (32 * kShapes[shape].MF);
+}
+
+#define BQ_CASE(T, PROD, SH) \
+    if (prod == PROD && shape == SH) return launch_inst<T, PROD, SH>(p, s);
+
+int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t s) {
+    if (dtype == 1) {
+        BQ_CASE(bf16_t, PROD_IM2COL, SHAPE_A)
+        BQ_CASE(bf16_t, PROD_DW, SHAPE_B)
+        BQ_CASE(bf16_t, PROD_S2, SHAPE_B)
+        BQ_CASE(bf16_t, PROD_DW, SHAPE_C)
+        BQ_CASE(bf16_t, PROD_DW_RELU, SHAPE_C)
+        BQ_CASE(bf16_t, PROD_S2, SHAPE_C)
+        BQ_CASE(bf16_t, PROD_DW, SHAPE_D)
+        BQ_CASE(bf16_t, PROD_DW_RELU, SHAPE_D)
+        BQ_CASE(bf16_t, PROD_S2, SHAPE_D)
+        BQ_CASE(bf16_t, PROD_DW, SHAPE_E)
+        BQ_CASE(bf16_t, PROD_S2, SHAPE_E)
+        BQ_CASE(bf16_t, PROD_DW, SHAPE_F)
+        BQ_CASE(bf16_t, PROD_DW, SHAPE_G)
+    } else {
+        BQ_CASE(float, PROD_IM2COL, SHAPE_A)
+        BQ_CASE(float, PROD_DW, SHAPE_B)
+        BQ_CASE(float, PROD_S2, SHAPE_B)
+        BQ_CASE(float, PROD_DW, SHAPE_C)
+        BQ_CASE(float, PROD_DW_RELU, SHAPE_C)
+        BQ_CASE(float, PROD_S2, SHAPE_C)
+        BQ_CASE(float, PROD_DW, SHAPE_H)
+        BQ_CASE(float, PROD_DW_RELU, SHAPE_H)
+        BQ_CASE(float, PROD_S2, SHAPE_H)
+        BQ_CASE(float, PROD_DROPOUT, SHAPE_H)
+    }
+    return (int)hipErrorInvalidValue;
+}

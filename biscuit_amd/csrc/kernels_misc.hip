@@ -1,0 +1,447 @@
+// HBM-bound kernels around the MFMA path: tile staging (K0), the 3->32 stem conv (K1a),
+// max-pool + residual add (K4), global average pool (K5), the MC head's last layer with
+// softmax + Welford fold (K6 tail) and the slide-level segmented reduce (K7).
+#include "bq_common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ T from_f32(float f);
+template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) { return (bf16_t)f; }
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    const unsigned short a = __builtin_bit_cast(unsigned short, (bf16_t)lo);
+    const unsigned short b = __builtin_bit_cast(unsigned short, (bf16_t)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+// ---------------------------------------------------------------- K0 staging
+// One workgroup per tile.  Pass 1: exact integer sum / sum of squares of the uint8
+// bytes (order-independent, so the statistics are bit-reproducible), pass 2 re-reads the
+// (now L2-resident) 268 KB tile, standardises and writes three contiguous planes.
+template <typename T>
+__global__ void __launch_bounds__(512) stage_u8_kernel(const uint8_t* __restrict__ tiles, int px,
+                                                       T* __restrict__ out) {
+    const int npix = px * px;
+    const int nbytes = npix * 3;
+    const uint8_t* src = tiles + (size_t)blockIdx.x * nbytes;
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    unsigned long long s1 = 0, s2 = 0;
+    // aligned 4-byte body, scalar head/tail
+    const int head = (int)((4 - ((uintptr_t)src & 3)) & 3);
+    const int body = (nbytes - head) >> 2;
+    if (tid < head) { const unsigned v = src[tid]; s1 += v; s2 += v * v; }
+    const unsigned* w = reinterpret_cast<const unsigned*>(src + head);
+    for (int i = tid; i < body; i += nt) {
+        const unsigned u = w[i];
+        const unsigned a = u & 255u, b = (u >> 8) & 255u, c = (u >> 16) & 255u, d = u >> 24;
+        s1 += a + b + c + d;
+        s2 += a * a + b * b + c * c + d * d;
+    }
+    const int tail0 = head + body * 4;
+    if (tid < nbytes - tail0) { const unsigned v = src[tail0 + tid]; s1 += v; s2 += v * v; }
+
+    __shared__ unsigned long long red[2][8];
+    __shared__ float stat[2];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long a = 0, b = 0;
+        for (int i = 0; i < nt / 64; ++i) { a += red[0][i]; b += red[1][i]; }
+        const double n = (double)nbytes;
+        const double mean = (double)a / n;
+        double var = (double)b / n - mean * mean;
+        if (var < 0) var = 0;
+        const double sd = sqrt(var);
+        const double floor_sd = 1.0 / sqrt(n);  // tf.image.per_image_standardization
+        stat[0] = (float)mean;
+        stat[1] = (float)(1.0 / (sd > floor_sd ? sd : floor_sd));
+    }
+    __syncthreads();
+    const float mean = stat[0], inv = stat[1];
+    T* o0 = out + (size_t)blockIdx.x * nbytes;
+    for (int p = tid; p < npix; p += nt) {
+        const uint8_t* q = src + p * 3;
+        o0[p] = from_f32<T>(((float)q[0] - mean) * inv);
+        o0[npix + p] = from_f32<T>(((float)q[1] - mean) * inv);
+        o0[2 * npix + p] = from_f32<T>(((float)q[2] - mean) * inv);
+    }
+}
+
+template <typename T>
+__global__ void stage_f32_kernel(const float* __restrict__ tiles, long long total_pix, int npix,
+                                 T* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_pix) return;
+    const long long img = i / npix;
+    const int p = (int)(i - img * npix);
+    const float* q = tiles + i * 3;
+    T* o0 = out + img * 3 * npix;
+    o0[p] = from_f32<T>(q[0]);
+    o0[npix + p] = from_f32<T>(q[1]);
+    o0[2 * npix + p] = from_f32<T>(q[2]);
+}
+
+// ---------------------------------------------------------------- K1a stem conv1
+// Conv2D(32, 3x3, strides 2, 'valid', no bias) + folded BN + ReLU on the planar staged
+// tile.  0.2 % of the FLOPs: vector ALU, one output pixel x 32 channels per lane, weights
+// through the scalar cache (uniform addresses), NHWC store of 32 contiguous channels.
+template <typename T>
+__global__ void __launch_bounds__(256) stem1_kernel(const T* __restrict__ in, int n, int px,
+                                                    const float* __restrict__ w,
+                                                    const float* __restrict__ scale,
+                                                    const float* __restrict__ bias,
+                                                    T* __restrict__ out) {
+    const int po = (px - 3) / 2 + 1;  // 149
+    const long long total = (long long)n * po * po;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int img = (int)(gid / (po * po));
+    const int rem = (int)(gid - (long long)img * po * po);
+    const int yo = rem / po, xo = rem - yo * po;
+    const T* base = in + (size_t)img * 3 * px * px;
+    float x[27];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                x[(dy * 3 + dx) * 3 + c] = to_f32<T>(base[(size_t)c * px * px + (2 * yo + dy) * px + 2 * xo + dx]);
+    float acc[32];
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[co] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+#pragma unroll
+        for (int co = 0; co < 32; ++co) acc[co] = fmaf(x[k], w[k * 32 + co], acc[co]);
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[co] = fmaxf(fmaf(acc[co], scale[co], bias[co]), 0.f);
+    T* o = out + (size_t)gid * 32;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < 32; j += 8)
+            *reinterpret_cast<uint4*>(o + j) =
+                make_uint4(pk_bf16(acc[j], acc[j + 1]), pk_bf16(acc[j + 2], acc[j + 3]),
+                           pk_bf16(acc[j + 4], acc[j + 5]), pk_bf16(acc[j + 6], acc[j + 7]));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; j += 4)
+            *reinterpret_cast<float4*>(o + j) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
+    }
+}
+
+// ---------------------------------------------------------------- K4 maxpool + add
+// MaxPooling2D(3, strides 2, 'same') with TensorFlow's asymmetric padding (odd input:
+// pad (1,1); even input: pad (0,1); padded value -inf) fused with the residual add.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) pool_add_kernel(const T* __restrict__ y, const T* __restrict__ res,
+                                                       T* __restrict__ out, int n, int Hi, int Wi,
+                                                       int Ho, int Wo, int C) {
+    const int chunks = C / VEC;
+    const long long total = (long long)n * Ho * Wo * chunks;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % chunks);
+    const long long pix = gid / chunks;
+    const int xo = (int)(pix % Wo);
+    const int yo = (int)((pix / Wo) % Ho);
+    const int img = (int)(pix / ((long long)Wo * Ho));
+    const int pt = (Hi & 1) ? 1 : 0, pl = (Wi & 1) ? 1 : 0;
+    float m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = 2 * yo + dy - pt;
+        if ((unsigned)yy >= (unsigned)Hi) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = 2 * xo + dx - pl;
+            if ((unsigned)xx >= (unsigned)Wi) continue;
+            const T* q = y + ((size_t)(img * Hi + yy) * Wi + xx) * C + c * VEC;
+            const uint4 u = *reinterpret_cast<const uint4*>(q);
+            const T* e = reinterpret_cast<const T*>(&u);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) m[j] = fmaxf(m[j], to_f32<T>(e[j]));
+        }
+    }
+    const size_t o = (size_t)pix * C + c * VEC;
+    const uint4 ru = *reinterpret_cast<const uint4*>(res + o);
+    const T* re = reinterpret_cast<const T*>(&ru);
+    uint4 ou;
+    T* oe = reinterpret_cast<T*>(&ou);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) oe[j] = from_f32<T>(m[j] + to_f32<T>(re[j]));
+    *reinterpret_cast<uint4*>(out + o) = ou;
+}
+
+// ---------------------------------------------------------------- K5 global average pool
+template <typename T>
+__global__ void __launch_bounds__(256) gap_kernel(const T* __restrict__ x, int n, int HW, int C, int ld,
+                                                  float* __restrict__ feat) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)n * C) return;
+    const int img = (int)(gid / C), c = (int)(gid - (long long)img * C);
+    const T* p = x + (size_t)img * HW * ld + c;
+    float s = 0.f;
+    for (int i = 0; i < HW; ++i) s += to_f32<T>(p[(size_t)i * ld]);
+    feat[gid] = s / (float)HW;
+}
+
+// ---------------------------------------------------------------- K6 tail
+// One wave per tile: for each MC pass, dropout(hidden_1 row) . W2 -> 2 logits ->
+// softmax -> Welford update (count, mean[2], M2[2]) carried in registers; W2 lives in
+// registers (16 k per lane x 2 classes).  state layout [n][5] fp32.
+__global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict__ h1, int n, int mc_n,
+                                                         int pass0, long long tile0, unsigned seed_lo,
+                                                         unsigned seed_hi, unsigned thresh, float dscale,
+                                                         const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, int init,
+                                                         int finalize, float* __restrict__ state,
+                                                         float* __restrict__ mean2,
+                                                         float* __restrict__ std2) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= n) return;
+    float wa[16], wb[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * (lane + 64 * j) + e;
+            wa[j * 4 + e] = w2[k * 2];
+            wb[j * 4 + e] = w2[k * 2 + 1];
+        }
+    float cnt = 0.f, mu0 = 0.f, mu1 = 0.f, q0 = 0.f, q1 = 0.f;
+    if (!init) {
+        const float* st = state + (size_t)tile * 5;
+        cnt = st[0]; mu0 = st[1]; mu1 = st[2]; q0 = st[3]; q1 = st[4];
+    }
+    for (int p = 0; p < mc_n; ++p) {
+        const float* row = h1 + ((size_t)tile * mc_n + p) * 1024;
+        float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = lane + 64 * j;  // Philox group = unit / 4
+            const float4 v = *reinterpret_cast<const float4*>(row + 4 * g);
+            unsigned r[4];
+            philox4x32_10((unsigned)g, 2u, (unsigned)(pass0 + p), (unsigned)(tile0 + tile), seed_lo,
+                          seed_hi, r);
+            const float f0 = r[0] >= thresh ? v.x * dscale : 0.f;
+            const float f1 = r[1] >= thresh ? v.y * dscale : 0.f;
+            const float f2 = r[2] >= thresh ? v.z * dscale : 0.f;
+            const float f3 = r[3] >= thresh ? v.w * dscale : 0.f;
+            z0 = fmaf(f0, wa[j * 4], z0); z0 = fmaf(f1, wa[j * 4 + 1], z0);
+            z0 = fmaf(f2, wa[j * 4 + 2], z0); z0 = fmaf(f3, wa[j * 4 + 3], z0);
+            z1 = fmaf(f0, wb[j * 4], z1); z1 = fmaf(f1, wb[j * 4 + 1], z1);
+            z1 = fmaf(f2, wb[j * 4 + 2], z1); z1 = fmaf(f3, wb[j * 4 + 3], z1);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            z0 += __shfl_xor(z0, o);
+            z1 += __shfl_xor(z1, o);
+        }
+        z0 += b2[0];
+        z1 += b2[1];
+        const float zm = fmaxf(z0, z1);
+        const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+        const float inv = 1.f / (e0 + e1);
+        const float p0 = e0 * inv, p1 = e1 * inv;
+        cnt += 1.f;
+        const float d0 = p0 - mu0, d1 = p1 - mu1;
+        mu0 += d0 / cnt;
+        mu1 += d1 / cnt;
+        q0 = fmaf(d0, p0 - mu0, q0);
+        q1 = fmaf(d1, p1 - mu1, q1);
+    }
+    if (lane == 0) {
+        float* st = state + (size_t)tile * 5;
+        st[0] = cnt; st[1] = mu0; st[2] = mu1; st[3] = q0; st[4] = q1;
+        if (finalize) {
+            mean2[tile * 2] = mu0;
+            mean2[tile * 2 + 1] = mu1;
+            std2[tile * 2] = sqrtf(fmaxf(q0, 0.f) / cnt);      // population std (ddof = 0)
+            std2[tile * 2 + 1] = sqrtf(fmaxf(q1, 0.f) / cnt);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K7 slide reduce
+// Fixed-point (2^-40) 64-bit integer atomics: the sum is exact per addend and associative,
+// so slide means are bit-reproducible whatever the arrival order.
+__global__ void __launch_bounds__(256) slide_reduce_kernel(const float* __restrict__ mean2,
+                                                           const float* __restrict__ std2,
+                                                           const int32_t* __restrict__ slide_idx, int n,
+                                                           int n_slides, float tile_uq, int use_uq,
+                                                           unsigned long long* acc_pred,
+                                                           unsigned long long* acc_unc, int32_t* count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = slide_idx[i];
+    if ((unsigned)s >= (unsigned)n_slides) return;
+    const float yp = mean2[i * 2 + 1];  // P(class 1): utils.py:27-28 y_pred1
+    const float un = std2[i * 2 + 1];   // utils.py:19-20 uncertainty1
+    if (use_uq && !(un < tile_uq)) return;  // strict '<' (threshold.py:298)
+    const double sc = (double)(1ull << BQ_FIXED_SHIFT);
+    const long long a = __double2ll_rn((double)yp * sc);
+    const long long b = __double2ll_rn((double)un * sc);
+    atomicAdd(acc_pred + s, (unsigned long long)a);
+    atomicAdd(acc_unc + s, (unsigned long long)b);
+    atomicAdd(count + s, 1);
+}
+
+__global__ void slide_finish_kernel(const long long* acc_pred, const long long* acc_unc,
+                                    const int32_t* count, int n_slides, double* mean_pred,
+                                    double* mean_unc) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slides) return;
+    const double inv = 1.0 / (double)(1ull << BQ_FIXED_SHIFT);
+    const int c = count[s];
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    mean_pred[s] = c > 0 ? ((double)acc_pred[s] * inv) / (double)c : nan;
+    mean_unc[s] = c > 0 ? ((double)acc_unc[s] * inv) / (double)c : nan;
+}
+
+// ---------------------------------------------------------------- debug copies
+template <typename T>
+__global__ void to_f32_nhwc_kernel(const T* __restrict__ x, long long rows, int C, int ld,
+                                   float* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows * C) return;
+    const long long r = gid / C;
+    const int c = (int)(gid - r * C);
+    out[gid] = to_f32<T>(x[r * ld + c]);
+}
+
+template <typename T>
+__global__ void nchw_to_f32_nhwc_kernel(const T* __restrict__ x, int n, int C, int HW,
+                                        float* __restrict__ out) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)n * C * HW) return;
+    const int c = (int)(gid % C);
+    const long long pix = gid / C;
+    const int p = (int)(pix % HW);
+    const long long img = pix / HW;
+    out[gid] = to_f32<T>(x[(img * C + c) * HW + p]);
+}
+
+inline int grid_for(long long total, int block) { return (int)((total + block - 1) / block); }
+
+}  // namespace
+
+#define BQ_DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+    do { if ((dtype) == 1) { CALL_BF16; } else { CALL_F32; } } while (0)
+
+int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, double*, hipStream_t s) {
+    if (n <= 0) return 0;
+    BQ_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(stage_u8_kernel<bf16_t>, dim3(n), dim3(512), 0, s, tiles, px, (bf16_t*)out),
+                  hipLaunchKernelGGL(stage_u8_kernel<float>, dim3(n), dim3(512), 0, s, tiles, px, (float*)out));
+    return (int)hipGetLastError();
+}
+
+int launch_stage_f32(const float* tiles, int n, int px, void* out, int dtype, hipStream_t s) {
+    if (n <= 0) return 0;
+    const long long total = (long long)n * px * px;
+    BQ_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(stage_f32_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     tiles, total, px * px, (bf16_t*)out),
+                  hipLaunchKernelGGL(stage_f32_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     tiles, total, px * px, (float*)out));
+    return (int)hipGetLastError();
+}
+
+int launch_stem1(const void* in, int n, const float* w, const float* scale, const float* bias, void* out,
+                 int dtype, hipStream_t s) {
+    const int px = 299, po = 149;
+    const long long total = (long long)n * po * po;
+    BQ_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(stem1_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const bf16_t*)in, n, px, w, scale, bias, (bf16_t*)out),
+                  hipLaunchKernelGGL(stem1_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const float*)in, n, px, w, scale, bias, (float*)out));
+    return (int)hipGetLastError();
+}
+
+int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, int Wi, int C, int dtype,
+                    hipStream_t s) {
+    const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
+    if (dtype == 1) {
+        const long long total = (long long)n * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL((pool_add_kernel<bf16_t, 8>), dim3(grid_for(total, 256)), dim3(256), 0, s,
+                           (const bf16_t*)y, (const bf16_t*)res, (bf16_t*)out, n, Hi, Wi, Ho, Wo, C);
+    } else {
+        const long long total = (long long)n * Ho * Wo * (C / 4);
+        hipLaunchKernelGGL((pool_add_kernel<float, 4>), dim3(grid_for(total, 256)), dim3(256), 0, s,
+                           (const float*)y, (const float*)res, (float*)out, n, Hi, Wi, Ho, Wo, C);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s) {
+    const long long total = (long long)n * C;
+    BQ_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(gap_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const bf16_t*)x, n, HW, C, ld, feat),
+                  hipLaunchKernelGGL(gap_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const float*)x, n, HW, C, ld, feat));
+    return (int)hipGetLastError();
+}
+
+int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, unsigned seed_lo,
+                      unsigned seed_hi, unsigned thresh, float dscale, const float* w2, const float* b2,
+                      int init, int finalize, float* state, float* mean2, float* std2, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(head_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, h1, n, mc_n, pass0, tile0,
+                       seed_lo, seed_hi, thresh, dscale, w2, b2, init, finalize, state, mean2, std2);
+    return (int)hipGetLastError();
+}
+
+int launch_slide_reduce(const float* mean2, const float* std2, const int32_t* slide_idx, int n,
+                        int n_slides, float tile_uq, long long* acc_pred, long long* acc_unc,
+                        int32_t* count, hipStream_t s) {
+    if (n <= 0) return 0;
+    const int use_uq = (tile_uq == tile_uq) && tile_uq != 0.f;  // NaN / 0 disable the filter
+    hipLaunchKernelGGL(slide_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, mean2, std2, slide_idx,
+                       n, n_slides, tile_uq, use_uq, (unsigned long long*)acc_pred,
+                       (unsigned long long*)acc_unc, count);
+    return (int)hipGetLastError();
+}
+
+int launch_slide_finish(const long long* acc_pred, const long long* acc_unc, const int32_t* count,
+                        int n_slides, double* mean_pred, double* mean_unc, hipStream_t s) {
+    if (n_slides <= 0) return 0;
+    hipLaunchKernelGGL(slide_finish_kernel, dim3(grid_for(n_slides, 256)), dim3(256), 0, s, acc_pred,
+                       acc_unc, count, n_slides, mean_pred, mean_unc);
+    return (int)hipGetLastError();
+}
+
+int launch_to_f32_nhwc(const void* x, long long rows, int C, int ld, float* out, int dtype, hipStream_t s) {
+    const long long total = rows * C;
+    BQ_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(to_f32_nhwc_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const bf16_t*)x, rows, C, ld, out),
+                  hipLaunchKernelGGL(to_f32_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const float*)x, rows, C, ld, out));
+    return (int)hipGetLastError();
+}
+
+int launch_nchw_to_f32_nhwc(const void* x, int n, int C, int HW, float* out, int dtype, hipStream_t s) {
+    const long long total = (long long)n * C * HW;
+    BQ_DISPATCH_T(dtype,
+                  hipLaunchKernelGGL(nchw_to_f32_nhwc_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                     s, (const bf16_t*)x, n, C, HW, out),
+                  hipLaunchKernelGGL(nchw_to_f32_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                     s, (const float*)x, n, C, HW, out));
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,214 @@
+"""Host side of the MI355X MC-dropout inference path.
+
+``Engine`` owns one ``bq_ctx`` (one process per GPU), the uploaded weights and a
+workspace; PyTorch-ROCm tensors are used only as device-memory containers whose
+``data_ptr()`` is handed to the C ABI, and ``torch.cuda.current_stream()`` supplies the
+HIP stream.  All arithmetic happens in ``libbiscuit_hip.so``.
+
+``UncertaintyInterface`` mirrors the callable the reference uses in
+``results.py:234,257-258``: ``interface(batch) -> (mean[B,2], std[B,2])``.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hp import ModelParams, nature2022
+from .weights import pack_blob
+
+TILE_PX = 299
+
+
+class BiscuitHipError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+@dataclass
+class ProfileEntry:
+    name: str
+    launches: int
+    ms: float
+    flops: float
+    bytes: float
+
+
+class Engine:
+    """One MC-dropout inference context on one GPU.
+
+    weights: dict of numpy arrays in Keras layout (``biscuit_amd.weights``).
+    dtype: 'bf16' (matrix-core bf16 backbone, fp32 accumulate/head) or 'f32' (exact
+    fp32 matrix-core path, the parity mode).
+    """
+
+    def __init__(self, weights, hp: ModelParams = None, dtype='bf16', max_batch=256, max_mc=30,
+                 device=None):
+        if not torch.cuda.is_available():
+            raise BiscuitHipError('no HIP device visible: the MI355X path has no CPU fallback')
+        self.hp = hp or nature2022()
+        self.dtype = dtype
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        self.max_batch, self.max_mc = int(max_batch), int(max_mc)
+        self._lib = _lib.lib
+        cfg = _lib.BqConfig(_lib.BQ_DTYPE_BF16 if dtype == 'bf16' else _lib.BQ_DTYPE_F32,
+                            self.hp.tile_px, 2, float(self.hp.dropout), self.max_batch, self.max_mc)
+        self._ctx = self._lib.bq_create(self.device.index, C.byref(cfg))
+        if not self._ctx:
+            raise BiscuitHipError('bq_create: ' + self._lib.bq_last_error(None).decode())
+        blob = pack_blob(weights, dtype)
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        self._check(self._lib.bq_load_weights(self._ctx, C.cast(buf, C.c_void_p), len(blob)))
+        self._ws = None
+        self._elt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+
+    # ------------------------------------------------------------------ utils
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self._lib.bq_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc is not None and rc < 0:
+            raise BiscuitHipError(f'libbiscuit_hip error {rc}: '
+                                  + self._lib.bq_last_error(self._ctx).decode())
+        return rc
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ws_for(self, n, mc_n):
+        """Caller-owned device workspace (a torch uint8 tensor), grown on demand."""
+        need = self._lib.bq_workspace_bytes(self._ctx, int(n), int(mc_n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------ stages
+    def stage(self, tiles_u8):
+        """uint8 NHWC [n,299,299,3] (device) -> standardised planar NCHW tensor."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
+        n = tiles_u8.shape[0]
+        out = torch.empty((n, 3, TILE_PX, TILE_PX), dtype=self._elt, device=self.device)
+        self._check(self._lib.bq_stage(self._ctx, _ptr(tiles_u8), n, _ptr(out), self._stream()))
+        return out
+
+    def stage_f32(self, tiles_f32):
+        assert tiles_f32.dtype == torch.float32 and tiles_f32.is_cuda and tiles_f32.is_contiguous()
+        n = tiles_f32.shape[0]
+        out = torch.empty((n, 3, TILE_PX, TILE_PX), dtype=self._elt, device=self.device)
+        self._check(self._lib.bq_stage_f32(self._ctx, _ptr(tiles_f32), n, _ptr(out), self._stream()))
+        return out
+
+    def backbone(self, staged):
+        n = staged.shape[0]
+        ws = self._ws_for(n, 1)
+        feat = torch.empty((n, 2048), dtype=torch.float32, device=self.device)
+        self._check(self._lib.bq_backbone(self._ctx, _ptr(staged), n, _ptr(feat), _ptr(ws), ws.numel(),
+                                          self._stream()))
+        return feat
+
+    def mc_head(self, feat, mc_n, seed, tile_idx0=0):
+        assert feat.dtype == torch.float32 and feat.is_cuda and feat.is_contiguous()
+        n = feat.shape[0]
+        ws = self._ws_for(n, mc_n)
+        state = torch.empty((n, 5), dtype=torch.float32, device=self.device)
+        mean = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        std = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        self._check(self._lib.bq_mc_head(self._ctx, _ptr(feat), n, int(tile_idx0), int(mc_n), 0,
+                                         int(seed), 1, 1, _ptr(state), _ptr(mean), _ptr(std), _ptr(ws),
+                                         ws.numel(), self._stream()))
+        return mean, std
+
+    def mc_infer(self, tiles_u8, mc_n, seed, tile_idx0=0, mc_mode='head', out=None):
+        """uint8 NHWC tiles (device) -> (mean[n,2], std[n,2]) on device."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
+        n = tiles_u8.shape[0]
+        ws = self._ws_for(n, mc_n)
+        if out is None:
+            mean = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+            std = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        else:
+            mean, std = out
+        mode = _lib.BQ_MC_HEAD if mc_mode == 'head' else _lib.BQ_MC_FULL
+        self._check(self._lib.bq_mc_infer(self._ctx, _ptr(tiles_u8), n, int(tile_idx0), int(mc_n),
+                                          int(seed), mode, _ptr(mean), _ptr(std), _ptr(ws), ws.numel(),
+                                          self._stream()))
+        return mean, std
+
+    def slide_reduce(self, mean2, std2, slide_idx, n_slides, tile_uq=None, acc=None):
+        """Accumulate per-slide fixed-point sums; returns the accumulator triple."""
+        n = mean2.shape[0]
+        if acc is None:
+            acc = (torch.zeros(n_slides, dtype=torch.int64, device=self.device),
+                   torch.zeros(n_slides, dtype=torch.int64, device=self.device),
+                   torch.zeros(n_slides, dtype=torch.int32, device=self.device))
+        uq = float('nan') if not tile_uq else float(tile_uq)   # threshold.py:297 `if tile_uq:`
+        self._check(self._lib.bq_slide_reduce(self._ctx, _ptr(mean2), _ptr(std2), _ptr(slide_idx), n,
+                                              int(n_slides), uq, _ptr(acc[0]), _ptr(acc[1]), _ptr(acc[2]),
+                                              self._stream()))
+        return acc
+
+    def slide_finish(self, acc):
+        n_slides = acc[0].shape[0]
+        mp = torch.empty(n_slides, dtype=torch.float64, device=self.device)
+        mu = torch.empty(n_slides, dtype=torch.float64, device=self.device)
+        self._check(self._lib.bq_slide_finish(self._ctx, _ptr(acc[0]), _ptr(acc[1]), _ptr(acc[2]),
+                                              n_slides, _ptr(mp), _ptr(mu), self._stream()))
+        return mp, mu, acc[2]
+
+    def debug_activation(self, name, staged, shape_hwc):
+        n = staged.shape[0]
+        ws = self._ws_for(n, 1)
+        h, w, c = shape_hwc
+        out = torch.empty((n, h, w, c), dtype=torch.float32, device=self.device)
+        rc = self._lib.bq_debug_activation(self._ctx, name.encode(), _ptr(staged), n, _ptr(ws), ws.numel(),
+                                           _ptr(out), out.numel(), self._stream())
+        self._check(rc)
+        assert rc == out.numel(), (rc, out.numel())
+        return out
+
+    # ------------------------------------------------------------------ profiling
+    def profile_enable(self, on=True):
+        self._check(self._lib.bq_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self):
+        arr = (_lib.BqProfEntry * _lib.BQ_PROF_MAX)()
+        k = self._check(self._lib.bq_profile_read(self._ctx, arr, _lib.BQ_PROF_MAX))
+        return [ProfileEntry(arr[i].name.decode(), arr[i].launches, arr[i].ms, arr[i].flops,
+                             arr[i].bytes) for i in range(k)]
+
+
+class UncertaintyInterface:
+    """Mirror of ``sf.model.tensorflow.UncertaintyInterface`` as the reference uses it
+    (``results.py:234,250-260``): called with a batch of *standardised* float32 NHWC
+    tiles, returns ``(mean, uncertainty)`` each ``[B, 2]``; ``uncertainty[0][0]`` is what
+    ``results.py:258`` compares with the tile-UQ threshold."""
+
+    wsi_normalizer = None   # stain normalisation is the caller's (results.py:252-255)
+
+    def __init__(self, engine: Engine, uq_n=30, seed=0):
+        self.engine, self.uq_n, self.seed = engine, int(uq_n), int(seed)
+        self._calls = 0
+
+    def __call__(self, batch):
+        eng = self.engine
+        x = torch.as_tensor(np.asarray(batch) if not torch.is_tensor(batch) else batch)
+        x = x.to(device=eng.device, dtype=torch.float32).contiguous()
+        if x.ndim != 4 or tuple(x.shape[1:]) != (TILE_PX, TILE_PX, 3):
+            raise ValueError(f'expected [B,{TILE_PX},{TILE_PX},3] standardised tiles, got {tuple(x.shape)}')
+        feat = eng.backbone(eng.stage_f32(x))
+        mean, std = eng.mc_head(feat, self.uq_n, self.seed, tile_idx0=self._calls)
+        self._calls += x.shape[0]
+        return mean.cpu().numpy(), std.cpu().numpy()

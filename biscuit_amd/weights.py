@@ -1,0 +1,222 @@
+"""Weights for the MC-dropout Xception classifier: synthetic generation (seeded),
+BN folding and packing into the device layout ``libbiscuit_hip.so`` consumes.
+
+The reference never stores weights in its repository; a trained model is a
+Slideflow/Keras SavedModel located by ``biscuit/utils.py:233-272`` (``find_model``).
+The canonical in-memory form here is a dict of float32 numpy arrays keyed by Keras
+layer/variable names (``block4_sepconv2/pointwise_kernel`` ...), so a converter from
+a real SavedModel only has to fill the same dict.  Architecture and sizes follow
+``biscuit/hp.py:3-23`` (xception, include_top=False, pooling='avg',
+hidden_layers=2, hidden_layer_width=1024) and keras.applications.Xception.
+
+Device layout ("BQW1" blob, build-owned, parsed by csrc/weights.cpp):
+  * matrix-core layers (pointwise 1x1, residual 1x1/s2, block1_conv2 as im2col,
+    hidden_0/hidden_1): weights pre-swizzled into MFMA operand-fragment order
+        wp[nf][kb][lane][v] = W[k = kb*2V + (lane>>5)*V + v][n = nf*32 + (lane&31)]
+    (V = 8 for bf16 / 32x32x16, V = 4 for fp32 / 4x 32x32x2), so one wave
+    instruction loads one whole 1 KiB fragment, fully coalesced, with no LDS hop;
+  * folded BatchNorm as per-output-channel fp32 ``scale``/``bias`` applied in the
+    kernel epilogue (y = acc*s + b, s = gamma/sqrt(var+eps), b = beta - mean*s);
+  * depthwise 3x3 kernels as fp32 [9][C_padded];
+  * 728-channel tensors are padded to 736 (= 46*16) channels with zero weights.
+"""
+import struct
+
+import numpy as np
+
+BN_EPS = 1e-3
+ENTRY = [(2, 64, [128, 128]), (3, 128, [256, 256]), (4, 256, [728, 728])]
+MAGIC = b'BQW1'
+
+
+def pad_channels(c):
+    """Device channel stride of a c-channel activation (multiple of 16)."""
+    return (c + 15) // 16 * 16
+
+
+def sepconv_plan():
+    """[(name, cin, cout)] of the 34 separable convolutions, in execution order."""
+    plan = []
+    for block, cin, chans in ENTRY:
+        c = cin
+        for i, co in enumerate(chans, 1):
+            plan.append((f'block{block}_sepconv{i}', c, co))
+            c = co
+    for block in range(5, 13):
+        for i in (1, 2, 3):
+            plan.append((f'block{block}_sepconv{i}', 728, 728))
+    plan += [('block13_sepconv1', 728, 728), ('block13_sepconv2', 728, 1024),
+             ('block14_sepconv1', 1024, 1536), ('block14_sepconv2', 1536, 2048)]
+    return plan
+
+
+def residual_plan():
+    return [('block2_res', 64, 128), ('block3_res', 128, 256),
+            ('block4_res', 256, 728), ('block13_res', 728, 1024)]
+
+
+def _bn(rng, w, name, c, gamma=1.0):
+    w[name + '/gamma'] = (gamma * rng.uniform(0.9, 1.1, c)).astype(np.float32)
+    w[name + '/beta'] = rng.normal(0.0, 0.05, c).astype(np.float32)
+    w[name + '/moving_mean'] = rng.normal(0.0, 0.05, c).astype(np.float32)
+    w[name + '/moving_variance'] = rng.uniform(0.9, 1.1, c).astype(np.float32)
+
+
+def synthetic_weights(seed=1, n_classes=2, logit_gain=0.3):
+    """Seeded random-init weights of the hp.nature2022 architecture.
+
+    Variance-preserving init so activations stay O(1) through the 36 conv layers with
+    BatchNorm in inference mode (moving statistics ~ identity): conv / pointwise
+    kernels ~ N(0, g/fan_in) with g = 2 behind a ReLU and 1 otherwise, depthwise
+    kernels ~ N(0, 1/9); the last BN of every residual branch has a damped gamma so
+    the residual stream grows slowly.  There is no network access for a checkpoint.
+    """
+    rng = np.random.default_rng(seed)
+    w = {}
+
+    def conv(name, kh, cin, cout, gain):
+        std = np.sqrt(gain / (kh * kh * cin))
+        w[name + '/kernel'] = rng.normal(0, std, (kh, kh, cin, cout)).astype(np.float32)
+
+    def sep(name, cin, cout, gain):
+        w[name + '/depthwise_kernel'] = rng.normal(0, 1 / 3.0, (3, 3, cin, 1)).astype(np.float32)
+        w[name + '/pointwise_kernel'] = rng.normal(
+            0, np.sqrt(gain / cin), (1, 1, cin, cout)).astype(np.float32)
+
+    conv('block1_conv1', 3, 3, 32, 1.0)
+    _bn(rng, w, 'block1_conv1_bn', 32)
+    conv('block1_conv2', 3, 32, 64, 2.0)
+    _bn(rng, w, 'block1_conv2_bn', 64)
+    for name, cin, cout in residual_plan():
+        conv(name + '_conv', 1, cin, cout, 1.0)
+        _bn(rng, w, name + '_bn', cout, gamma=0.7)
+    for name, cin, cout in sepconv_plan():
+        block = int(name[5:name.index('_')])
+        idx = int(name[-1])
+        last = (idx == 3) or (block in (2, 3, 4, 13) and idx == 2)
+        sep(name, cin, cout, 2.0)
+        gamma = (0.3 if 5 <= block <= 12 else 0.7) if last else 1.0
+        _bn(rng, w, name + '_bn', cout, gamma=gamma)
+    # head: hidden_layers=2, hidden_layer_width=1024 (hp.py:13,21); GAP features are
+    # post-ReLU means (non-negative, strongly correlated), so centre the first layer.
+    k0 = rng.normal(0, np.sqrt(2.0 / 2048), (2048, 1024)).astype(np.float32)
+    w['hidden_0/kernel'] = k0 - k0.mean(axis=0, keepdims=True)
+    w['hidden_0/bias'] = rng.normal(0, 0.1, 1024).astype(np.float32)
+    w['hidden_1/kernel'] = rng.normal(0, np.sqrt(2.0 / 1024), (1024, 1024)).astype(np.float32)
+    w['hidden_1/bias'] = rng.normal(0, 0.1, 1024).astype(np.float32)
+    k2 = rng.normal(0, np.sqrt(1.0 / 1024), (1024, n_classes)).astype(np.float32)
+    w['logits/kernel'] = (k2 - k2.mean(axis=1, keepdims=True)) * np.float32(logit_gain)
+    w['logits/bias'] = np.zeros(n_classes, np.float32)
+    return w
+
+
+def count_backbone_params(w):
+    head = ('hidden_0', 'hidden_1', 'logits')
+    return int(sum(v.size for k, v in w.items() if not k.startswith(head)))
+
+
+# ---------------------------------------------------------------------------
+# device packing
+# ---------------------------------------------------------------------------
+def f32_to_bf16_bits(a):
+    """Round-to-nearest-even float32 -> bfloat16 bit patterns (uint16)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = (u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) >> np.uint64(16)
+    return r.astype(np.uint16)
+
+
+def nfrags_padded(n):
+    nf = (n + 31) // 32
+    return nf if nf <= 8 else (nf + 7) // 8 * 8
+
+
+def pack_fragments(wkn, kpad, vec):
+    """W[K][N] -> fragment order [NFp][KB][64][vec] float32 (zero padded)."""
+    k, n = wkn.shape
+    assert kpad % (2 * vec) == 0 and kpad >= k
+    nfp = nfrags_padded(n)
+    full = np.zeros((kpad, nfp * 32), np.float32)
+    full[:k, :n] = wkn
+    kb = kpad // (2 * vec)
+    # k = kb*2V + h*V + v ; n = nf*32 + r ; lane = h*32 + r
+    t = full.reshape(kb, 2, vec, nfp, 32)          # [kb][h][v][nf][r]
+    t = t.transpose(3, 0, 1, 4, 2)                 # [nf][kb][h][r][v]
+    return np.ascontiguousarray(t).reshape(nfp, kb, 64, vec)
+
+
+def fold_bn(w, name):
+    s = w[name + '/gamma'] / np.sqrt(w[name + '/moving_variance'] + np.float32(BN_EPS))
+    b = w[name + '/beta'] - w[name + '/moving_mean'] * s
+    return s.astype(np.float32), b.astype(np.float32)
+
+
+def _padvec(v, n):
+    out = np.zeros(n, np.float32)
+    out[:v.size] = v
+    return out
+
+
+def pack_blob(w, dtype='bf16'):
+    """Fold BN and serialise every tensor the device needs into one BQW1 blob."""
+    assert dtype in ('bf16', 'f32')
+    vec = 8 if dtype == 'bf16' else 4
+    entries = []
+
+    def add(name, arr):
+        entries.append((name, np.ascontiguousarray(arr)))
+
+    def add_mat(name, wkn, kpad):
+        p = pack_fragments(wkn, kpad, vec)
+        add(name + '/wp', f32_to_bf16_bits(p) if dtype == 'bf16' else p)
+        return p.shape[0] * 32
+
+    def add_affine(name, s, b, npad):
+        add(name + '/scale', _padvec(s, npad))
+        add(name + '/bias', _padvec(b, npad))
+
+    # stem conv1 on the vector ALU: fp32 [27][32], k = (dy*3+dx)*3 + c
+    add('block1_conv1/w', w['block1_conv1/kernel'].reshape(27, 32))
+    s, b = fold_bn(w, 'block1_conv1_bn')
+    add_affine('block1_conv1', s, b, 32)
+    # stem conv2 as im2col GEMM: k = (dy*3+dx)*32 + c
+    npad = add_mat('block1_conv2', w['block1_conv2/kernel'].reshape(288, 64), 288)
+    s, b = fold_bn(w, 'block1_conv2_bn')
+    add_affine('block1_conv2', s, b, npad)
+    for name, cin, cout in residual_plan():
+        npad = add_mat(name, w[name + '_conv/kernel'].reshape(cin, cout), pad_channels(cin))
+        s, b = fold_bn(w, name + '_bn')
+        add_affine(name, s, b, npad)
+    for name, cin, cout in sepconv_plan():
+        cp = pad_channels(cin)
+        dw = np.zeros((9, cp), np.float32)
+        dw[:, :cin] = w[name + '/depthwise_kernel'].reshape(9, cin)
+        add(name + '/dw', dw)
+        npad = add_mat(name, w[name + '/pointwise_kernel'].reshape(cin, cout), cp)
+        s, b = fold_bn(w, name + '_bn')
+        add_affine(name, s, b, npad)
+    # head stays fp32 regardless of the backbone dtype (MC std ~1e-2 must not be
+    # quantisation noise); always V = 4 fragments.
+    for name, kin in (('hidden_0', 2048), ('hidden_1', 1024)):
+        p = pack_fragments(w[name + '/kernel'], kin, 4)
+        add(name + '/wp', p)
+        n = p.shape[0] * 32
+        add_affine(name, np.ones(w[name + '/bias'].size, np.float32), w[name + '/bias'], n)
+    add('logits/w', w['logits/kernel'].astype(np.float32))
+    add('logits/bias', w['logits/bias'].astype(np.float32))
+
+    # header + directory + 256-B aligned payloads
+    hdr_size = 16 + 64 * len(entries)
+    off = (hdr_size + 255) // 256 * 256
+    directory, payload = [], []
+    for name, arr in entries:
+        raw = arr.tobytes()
+        nm = name.encode()
+        assert len(nm) < 48
+        directory.append(struct.pack('<48sQQ', nm, off, len(raw)))
+        pad = (-len(raw)) % 256
+        payload.append(raw + b'\0' * pad)
+        off += len(raw) + pad
+    head = struct.pack('<4sIII', MAGIC, 1, len(entries), 1 if dtype == 'bf16' else 0)
+    blob = head + b''.join(directory)
+    blob += b'\0' * ((-len(blob)) % 256)
+    return blob + b''.join(payload)

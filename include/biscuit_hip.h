@@ -1,0 +1,145 @@
+/* biscuit_hip.h -- C ABI of libbiscuit_hip.so: the MI355X (gfx950) implementation of
+ * BISCUIT's tile-level MC-dropout inference hot path.
+ *
+ * The reference (jamesdolezal/biscuit) has no FFI/plugin interface: the path is entered
+ * through Python calls into Slideflow/TensorFlow and leaves through a tile-prediction
+ * table.  Each entry point below names the reference call site it replaces:
+ *
+ *   bq_stage        tf.image.per_image_standardization(norm_image)      results.py:256
+ *   bq_backbone     keras Xception(include_top=False, pooling='avg')     biscuit/hp.py:4,20,22
+ *   bq_mc_head      the UQ loop behind UncertaintyInterface(model)(batch) -> (mean, std)
+ *                                                                        results.py:234,257-258
+ *                   (dropout 0.1 hard-wired on, 2x Dense(1024)           biscuit/hp.py:11,13,21;
+ *                    hp.uq = True                                        biscuit/experiment.py:849)
+ *   bq_mc_infer     Project.evaluate(model, outcome, ..., save_predictions=True) inner loop
+ *                                                                        biscuit/experiment.py:917-922
+ *   bq_slide_reduce groupby(level).mean() of y_pred / uncertainty after the
+ *                   `uncertainty < tile_uq` filter                       biscuit/threshold.py:191-204,297-298
+ *
+ * Conventions: every device buffer and the stream belong to the caller; the library
+ * allocates only the weights (bq_load_weights) and small per-context scratch at
+ * bq_create.  All work is enqueued on the caller's stream with no hidden
+ * synchronisation (except bq_profile_read).  Return 0 on success, <0 on error; the
+ * message is available from bq_last_error.  One context per device per process; a
+ * context is not re-entrant.  No C++ exception crosses this boundary.
+ */
+#ifndef BISCUIT_HIP_H
+#define BISCUIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bq_ctx bq_ctx;
+typedef void* bq_stream_t; /* hipStream_t */
+
+enum { BQ_DTYPE_F32 = 0, BQ_DTYPE_BF16 = 1 };
+enum { BQ_MC_HEAD = 0, BQ_MC_FULL = 1 };
+
+enum {
+    BQ_OK = 0,
+    BQ_ERR_ARG = -1,      /* bad argument / shape */
+    BQ_ERR_HIP = -2,      /* a HIP runtime call failed */
+    BQ_ERR_WEIGHTS = -3,  /* weight blob malformed or not loaded */
+    BQ_ERR_WORKSPACE = -4 /* workspace too small */
+};
+
+typedef struct bq_config {
+    int32_t dtype;        /* BQ_DTYPE_*: storage/matrix-core type of the backbone activations */
+    int32_t tile_px;      /* 299 (biscuit/hp.py:5) */
+    int32_t n_classes;    /* 2 (LUAD vs LUSC) */
+    float dropout;        /* 0.1 (biscuit/hp.py:11) */
+    int32_t max_batch;    /* largest n any call will pass (sizes the workspace) */
+    int32_t max_mc;       /* largest mc_n any call will pass */
+} bq_config;
+
+/* Lifetime. */
+bq_ctx* bq_create(int device_id, const bq_config* cfg);
+void bq_destroy(bq_ctx* ctx);
+const char* bq_last_error(bq_ctx* ctx); /* ctx may be NULL: last creation error */
+
+/* Bytes of device workspace bq_backbone/bq_mc_head/bq_mc_infer need for `batch` tiles
+ * and `mc_n` passes. */
+size_t bq_workspace_bytes(bq_ctx* ctx, int batch, int mc_n);
+
+/* Upload a "BQW1" weight blob (biscuit_amd/weights.py:pack_blob; folded-BN scale/bias,
+ * matrix-core weights pre-swizzled into MFMA fragment order).  The blob's dtype must
+ * match cfg.dtype. */
+int bq_load_weights(bq_ctx* ctx, const void* host_blob, size_t nbytes);
+
+/* K0: uint8 NHWC tiles [n,px,px,3] -> per-image standardised planar NCHW [n,3,px,px]
+ * of the context dtype.  (x - mean) / max(std, 1/sqrt(N)). */
+int bq_stage(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, void* d_out_nchw,
+             bq_stream_t stream);
+
+/* Variant for callers that already hold standardised float32 NHWC tiles (the
+ * UncertaintyInterface contract, results.py:256-257): converts to planar NCHW. */
+int bq_stage_f32(bq_ctx* ctx, const float* d_tiles_nhwc_f32, int n, void* d_out_nchw,
+                 bq_stream_t stream);
+
+/* K1-K5: staged tiles -> [n,2048] fp32 global-average-pooled features. */
+int bq_backbone(bq_ctx* ctx, const void* d_in_nchw, int n, float* d_feat2048, void* d_ws,
+                size_t ws_bytes, bq_stream_t stream);
+
+/* K6: mc_n stochastic passes of the dropout head over n feature rows, Welford-folded
+ * on the device.  Dropout masks are Philox4x32-10 keyed by `seed` with counter
+ * (unit/4, layer, pass, tile_idx0 + row): independent of batching.
+ * pass0/init/finalize let a caller fold passes over several calls (BQ_MC_FULL):
+ * init=1 zeroes the running state, finalize=1 writes mean/std.  d_state is
+ * [n][5] fp32 (count, mean0, mean1, M2_0, M2_1), caller-owned. */
+int bq_mc_head(bq_ctx* ctx, const float* d_feat, int n, int64_t tile_idx0, int mc_n,
+               int pass0, uint64_t seed, int init, int finalize, float* d_state,
+               float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes,
+               bq_stream_t stream);
+
+/* Fused convenience: uint8 tiles -> (mean[n,2], std[n,2]).  mc_mode BQ_MC_HEAD runs
+ * the backbone once and the head mc_n times; BQ_MC_FULL re-runs the whole network per
+ * pass like the reference loop.  Results are bit-identical between the two. */
+int bq_mc_infer(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, int64_t tile_idx0,
+                int mc_n, uint64_t seed, int mc_mode, float* d_mean2, float* d_std2,
+                void* d_ws, size_t ws_bytes, bq_stream_t stream);
+
+/* K7: per-slide sums of y_pred (= mean of P(class 1)) and uncertainty (= std of
+ * P(class 1)) plus tile counts, restricted to tiles with uncertainty < tile_uq when
+ * tile_uq is a positive finite number (threshold.py:297-298: `if tile_uq:` and strict
+ * `<`).  Accumulates into caller-zeroed 64-bit fixed-point buffers (order-independent,
+ * bit-reproducible); call bq_slide_finish to convert to doubles. */
+int bq_slide_reduce(bq_ctx* ctx, const float* d_mean2, const float* d_std2,
+                    const int32_t* d_slide_idx, int n, int n_slides, float tile_uq,
+                    int64_t* d_acc_pred, int64_t* d_acc_unc, int32_t* d_count,
+                    bq_stream_t stream);
+int bq_slide_finish(bq_ctx* ctx, const int64_t* d_acc_pred, const int64_t* d_acc_unc,
+                    const int32_t* d_count, int n_slides, double* d_mean_pred,
+                    double* d_mean_unc, bq_stream_t stream);
+
+/* Per-kernel timing with HIP events on the launch stream (bench.py roofline leg).
+ * bq_profile_enable(1) brackets every subsequent launch with events;
+ * bq_profile_read synchronises and returns, per kernel class, the number of launches,
+ * total milliseconds, algorithmic FLOPs and algorithmic bytes since the last enable. */
+enum { BQ_PROF_MAX = 64 };
+typedef struct bq_prof_entry {
+    char name[48];
+    int64_t launches;
+    double ms;
+    double flops;
+    double bytes;
+} bq_prof_entry;
+int bq_profile_enable(bq_ctx* ctx, int on);
+int bq_profile_read(bq_ctx* ctx, bq_prof_entry* out, int max_entries);
+
+/* Test hook: run the backbone on staged tiles up to and including the named layer
+ * ("staged", "block1_conv1", "block1_conv2", "block{2,3,4}_{res,sepconv1,sepconv2,out}",
+ * "block{5..13}_out", "block14_sepconv{1,2}") and copy that activation as fp32 NHWC
+ * [n,H,W,C] (true channel count, padding stripped) into d_out.  Returns the number of
+ * elements written, or <0. */
+int64_t bq_debug_activation(bq_ctx* ctx, const char* name, const void* d_in_nchw, int n,
+                            void* d_ws, size_t ws_bytes, float* d_out, size_t out_elems,
+                            bq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BISCUIT_HIP_H */
