@@ -1,0 +1,231 @@
+"""bench.py -- tiles/sec of the MC-dropout tile-inference hot path on MI355X.
+
+Workload (BASELINE.json config 2): synthetic slides of 1000 tiles (299x299x3 uint8,
+resident in HBM before the timed region), Xception bf16 backbone + fp32 MC head, MC = 30,
+batch = 256.  A "step" is one batch of 256 tiles through
+    stage (K0) -> backbone (K1-K5) -> 30 Philox-dropout head passes + Welford (K6)
+    -> slide-level segmented reduce (K7).
+``value`` = tiles processed by all ranks / max-over-ranks wall time of exactly K steps
+(barrier + synchronize on both sides; at N>1 the timed region ends with the single
+all-gather of the per-slide results).
+
+mc_mode 'head' (default, reported as ``value``): backbone once per tile, the 30 stochastic
+passes run in the head -- bit-identical to 30 full passes because every dropout layer sits
+behind the global pool and BN is in inference mode.  ``full_mode_value`` times the
+reference's loop structure (30 complete forward passes) on the same kernels, and
+``cpu_baseline`` times the fp32 CPU oracle in that same full structure on the host cores.
+
+usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--mc 30] [--batch 256]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from biscuit_amd import distributed as D      # noqa: E402
+from biscuit_amd.engine import Engine         # noqa: E402
+from biscuit_amd.weights import synthetic_weights  # noqa: E402
+
+# Algorithmic work per tile (derivation SURVEY.md section 8d)
+FLOP_PER_TILE_HEAD = 16.711e9 + 30 * 6.296e6      # backbone once + 30 head passes
+FLOP_PER_TILE_FULL = 30 * (16.711e9 + 6.296e6)
+BYTES_PER_TILE_BF16 = 90.2e6                      # layer-boundary bf16 bytes, fused dw+pw/BN/ReLU/pool+add
+PEAK_HBM = 8.0e12                                 # B/s   (MI355X_MICROARCH.md: 8 TB/s spec)
+PEAK_BF16 = 2.5e15                                # FLOP/s dense bf16 MFMA
+PEAK_F32 = 157.3e12
+TILES_PER_SLIDE = 1000
+
+
+def cpu_baseline(weights, mc_n, seed, budget_tiles=4):
+    """The CPU oracle in the reference's loop structure (N full forward passes per batch,
+    mean / population std), on this host's cores, on a bounded sample."""
+    from biscuit_amd.synthetic import make_tiles
+    from oracle.xception_ref import XceptionOracle
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    orc = XceptionOracle(weights)
+    tiles = make_tiles(budget_tiles, seed=11)
+    orc.mc_predict(tiles[:1], 1, seed, mode='full')          # warm-up (oneDNN primitive cache)
+    t = time.time()
+    orc.mc_predict(tiles, mc_n, seed, mode='full', batch=budget_tiles)
+    dt_full = time.time() - t
+    t = time.time()
+    orc.mc_predict(tiles, mc_n, seed, mode='head', batch=budget_tiles)
+    dt_head = time.time() - t
+    return {'value': budget_tiles / dt_full, 'unit': 'tiles/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': f'{budget_tiles} synthetic 299x299x3 tiles x MC={mc_n} full forward passes '
+                      f'(fp32 PyTorch-CPU oracle, {dt_full:.1f} s)',
+            'head_mode_value': budget_tiles / dt_head,
+            'cpu': _cpu_name()}
+
+
+def _cpu_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--mc', type=int, default=30)
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--mode', default='head', choices=['head', 'full'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--cpu-tiles', type=int, default=4)
+    args = ap.parse_args()
+
+    rank, world, local = D.init_from_env('cuda')
+    if world != args.gpus and rank == 0:
+        print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using {world}', file=sys.stderr)
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    weights = synthetic_weights(1)
+    eng = Engine(weights, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local)
+    B, K, Wm = args.batch, args.steps, args.warmup
+    seed = 1234
+
+    # synthetic tiles, generated on the device: 4 batches resident, cycled
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    pool = [torch.randint(0, 256, (B, 299, 299, 3), dtype=torch.uint8, device=dev, generator=g)
+            for _ in range(4)]
+    n_slides_local = (K * B + TILES_PER_SLIDE - 1) // TILES_PER_SLIDE + 1
+    slide_of = [torch.div(torch.arange(s * B, (s + 1) * B, device=dev), TILES_PER_SLIDE,
+                          rounding_mode='floor').to(torch.int32) for s in range(max(K, Wm))]
+    mean = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    std = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    tile_base = rank * K * B                      # global tile index of this rank's shard
+
+    def zero_acc():
+        return (torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
+                torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
+                torch.zeros(n_slides_local, dtype=torch.int32, device=dev))
+
+    def step(i, acc, mode):
+        eng.mc_infer(pool[i % 4], args.mc, seed, tile_idx0=tile_base + i * B, mc_mode=mode, out=(mean, std))
+        eng.slide_reduce(mean, std, slide_of[i], n_slides_local, acc=acc)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(mode, steps):
+        acc = zero_acc()
+        for i in range(Wm):
+            step(i, acc, mode)
+        acc = zero_acc()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, acc, mode)
+        mp, mu, cnt = eng.slide_finish(acc)
+        if world > 1:                              # the path's one collective (RCCL over xGMI)
+            ids = np.arange(rank * n_slides_local, (rank + 1) * n_slides_local)
+            D.gather_slide_results(ids, mp.cpu().numpy(), mu.cpu().numpy(), cnt.cpu().numpy(),
+                                   world * n_slides_local, n_slides_local, device=dev)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert int(cnt.sum()) == steps * B and bool(torch.isfinite(mp[cnt > 0]).all())
+        return dt
+
+    dt = timed(args.mode, K)
+    value = world * K * B / dt
+
+    out = {
+        'metric': 'tiles/sec at MC-dropout=30, 299x299x3 (Xception, slide-level pred/sigma reduce)',
+        'value': value, 'unit': 'tiles/s', 'n_gpus': world, 'steps': K, 'warmup': Wm,
+        'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': f'BASELINE.json config 2: {TILES_PER_SLIDE} synthetic 299x299x3 tiles/slide, '
+                               f'Xception {args.dtype} + fp32 MC head, MC={args.mc}, batch={B}, '
+                               f'{K * B} tiles/GPU resident in HBM',
+                   'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B,
+                   'parallelism': f'slide-sharded dp{world}, one all-gather of slide (pred, sigma, n)'},
+    }
+
+    if rank == 0:
+        flop_tile = FLOP_PER_TILE_HEAD if args.mode == 'head' else FLOP_PER_TILE_FULL
+        per_gpu = value / world
+        out['path_roofline'] = {
+            'hbm_frac': per_gpu * BYTES_PER_TILE_BF16 / PEAK_HBM if args.dtype == 'bf16' else None,
+            'mfma_frac': per_gpu * flop_tile / (PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32),
+            'bytes_per_tile': BYTES_PER_TILE_BF16, 'flop_per_tile': flop_tile}
+
+    # the other MC structure on the same kernels (N=1 only; a few steps)
+    if world == 1 and rank == 0:
+        other = 'full' if args.mode == 'head' else 'head'
+        k2 = 2 if other == 'full' else K
+        dt2 = timed(other, k2)
+        out[f'{other}_mode_value'] = k2 * B / dt2
+
+    # per-kernel roofline: HIP events on the launch stream around every launch
+    if not args.no_profile and rank == 0:
+        acc = zero_acc()
+        eng.profile_enable(True)
+        psteps = 4
+        for i in range(psteps):
+            step(i, acc, args.mode)
+        ents = eng.profile_read()
+        eng.profile_enable(False)
+        tot = sum(e.ms for e in ents)
+        ents.sort(key=lambda e: -e.ms)
+        dom = ents[0]
+        avg_s = dom.ms / dom.launches * 1e-3
+        es = 2 if args.dtype == 'bf16' else 4
+        ridge = (PEAK_BF16 if es == 2 else PEAK_F32) / PEAK_HBM
+        bound = 'mfma' if dom.flops / max(dom.bytes, 1) >= ridge * 0.5 else 'hbm'
+        if bound == 'mfma':
+            peak = (PEAK_BF16 if es == 2 else PEAK_F32) / 1e12
+            ach = dom.flops / avg_s / 1e12
+            unit = 'TFLOP/s'
+        else:
+            peak = PEAK_HBM / 1e9
+            ach = dom.bytes / avg_s / 1e9
+            unit = 'GB/s'
+        out['roofline'] = {'kernel': dom.name, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
+                           'frac': ach / peak, 'traffic': None,
+                           'launches_per_step': dom.launches / psteps, 'avg_launch_ms': dom.ms / dom.launches,
+                           'share_of_step': dom.ms / tot,
+                           'algorithmic_flops_per_launch': dom.flops, 'algorithmic_bytes_per_launch': dom.bytes}
+        out['kernels'] = [{'name': e.name, 'launches_per_step': e.launches / psteps,
+                           'ms_per_launch': e.ms / e.launches, 'share': e.ms / tot,
+                           'tflops': e.flops / (e.ms / e.launches * 1e-3) / 1e12,
+                           'gbps': e.bytes / (e.ms / e.launches * 1e-3) / 1e9} for e in ents[:12]]
+
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(weights, args.mc, seed, args.cpu_tiles)
+        out['speedup_vs_cpu_full'] = (out.get('full_mode_value') or value) / out['cpu_baseline']['value']
+        out['speedup_headline_vs_cpu_full'] = value / out['cpu_baseline']['value']
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -4,6 +4,7 @@
 #include "bq_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -126,11 +127,11 @@ struct ProfScope {
         cls = prof_class(c, name, flops, bytes);
         a = c->ev_pool[c->ev_used++];
         b = c->ev_pool[c->ev_used++];
-        hipEventRecord(a, s);
+        (void)hipEventRecord(a, s);
     }
     ~ProfScope() {
         if (cls < 0) return;
-        hipEventRecord(b, s);
+        (void)hipEventRecord(b, s);
         c->prof_recs.push_back({cls, a, b});
     }
 };
@@ -200,6 +201,15 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
              a.prod == PROD_S2 ? "res1x1s2" : (a.prod == PROD_IM2COL ? "conv3x3" : "sepconv"), L.cin,
              L.cout, a.H, a.W);
     ProfScope ps(c, s, cls, flops, bytes);
+    static const bool no_pipe = getenv("BQ_NO_PIPE") != nullptr;
+    if (!no_pipe && nsplit == 1 && pipe_supported(dtype, a.prod, L.nfp, a.W, L.kpad)) {
+        p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
+        p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
+        const int e = launch_sepconv_pipe(a.prod, p, s);
+        if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(pipe) ") + a.layer + ": " +
+                                                   hipGetErrorString((hipError_t)e));
+        return BQ_OK;
+    }
     for (int sp = 0; sp < nsplit; ++sp) {
         const bool last = sp == nsplit - 1;
         p.K = L.kpad / nsplit;
@@ -436,8 +446,8 @@ bq_ctx* bq_create(int device_id, const bq_config* cfg) {
 
 void bq_destroy(bq_ctx* c) {
     if (!c) return;
-    if (c->d_blob) hipFree(c->d_blob);
-    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    if (c->d_blob) (void)hipFree(c->d_blob);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -459,11 +469,11 @@ int bq_load_weights(bq_ctx* c, const void* host_blob, size_t nbytes) {
     int prev = 0;
     HIPCHK(c, hipGetDevice(&prev));
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->d_blob) { hipFree(c->d_blob); c->d_blob = nullptr; }
+    if (c->d_blob) { (void)hipFree(c->d_blob); c->d_blob = nullptr; }
     c->entries.clear(); c->layers.clear(); c->loaded = false;
     HIPCHK(c, hipMalloc((void**)&c->d_blob, nbytes));
     HIPCHK(c, hipMemcpy(c->d_blob, hb, nbytes, hipMemcpyHostToDevice));
-    hipSetDevice(prev);
+    (void)hipSetDevice(prev);
     c->blob_bytes = nbytes;
     for (uint32_t i = 0; i < cnt; ++i) {
         const unsigned char* e = hb + 16 + (size_t)i * 64;

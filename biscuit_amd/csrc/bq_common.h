@@ -60,6 +60,8 @@ size_t gemm_lds_bytes(int dtype, int shape, int K);
 // Returns hipError_t as int.
 int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t s);
 int gemm_tile_rows(int shape);
+bool pipe_supported(int dtype, int prod, int nfp, int W, int K);
+int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s);
 
 // ---- small kernels (kernels_misc.hip) ----------------------------------------------
 int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, double* stats_scratch,

@@ -19,90 +19,10 @@
 //  * bf16 uses v_mfma_f32_32x32x16_bf16; fp32 (parity mode and the MC head) uses four
 //    exact-fp32 v_mfma_f32_32x32x2_f32 per 16-byte fragment with the k order permuted
 //    identically on both operands.
-#include "bq_common.h"
+#include "gemm_common.h"
 
 namespace {
-
-template <typename T> struct TT;
-template <> struct TT<bf16_t> { static constexpr int VEC = 8; };
-template <> struct TT<float> { static constexpr int VEC = 4; };
-
-template <typename T> __device__ __forceinline__ void unpack(const uint4& v, float* f);
-template <> __device__ __forceinline__ void unpack<bf16_t>(const uint4& v, float* f) {
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-}
-template <> __device__ __forceinline__ void unpack<float>(const uint4& v, float* f) {
-    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
-    f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
-}
-
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    const unsigned short a = __builtin_bit_cast(unsigned short, (bf16_t)lo);
-    const unsigned short b = __builtin_bit_cast(unsigned short, (bf16_t)hi);
-    return (unsigned)a | ((unsigned)b << 16);
-}
-
-template <typename T> __device__ __forceinline__ uint4 pack(const float* f);
-template <> __device__ __forceinline__ uint4 pack<bf16_t>(const float* f) {
-    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
-                      pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
-}
-template <> __device__ __forceinline__ uint4 pack<float>(const float* f) {
-    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
-                      __float_as_uint(f[3]));
-}
-
-// 4 consecutive output channels of one pixel
-template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
-template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* v) {
-    const uint2 u = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-}
-template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
-    const float4 u = *reinterpret_cast<const float4*>(p);
-    v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
-}
-template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-}
-template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-
-template <typename T>
-__device__ __forceinline__ void mma(f32x16& acc, const uint4& w, const uint4& a);
-template <> __device__ __forceinline__ void mma<bf16_t>(f32x16& acc, const uint4& w, const uint4& a) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w),
-                                                   __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
-}
-template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const uint4& w, const uint4& a) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
-}
-
-// Row iterator over flattened (image, y, x) pixel indices of an H x W map.
-struct PixIt {
-    int img, y, x;
-    __device__ __forceinline__ void init(int p, int H, int W) {
-        const int hw = H * W;
-        img = p / hw;
-        const int rem = p - img * hw;
-        y = rem / W;
-        x = rem - y * W;
-    }
-    __device__ __forceinline__ void advance(int step, int H, int W) {
-        x += step;
-        while (x >= W) { x -= W; ++y; }
-        while (y >= H) { y -= H; ++img; }
-    }
-};
+using namespace bqk;
 
 // ------------------------------------------------------------------ producers
 template <typename T, int PROD, int MT, int NT>
@@ -230,11 +150,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_fused_kernel(const GemmPara
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
-    // XCD-aware block -> tile map (bijective): blocks b, b+8, ... share an XCD/L2, give
-    // them neighbouring pixel tiles so depthwise halos are L2 hits.
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
-    const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = tile * MT;
     const int CH = p.K / VEC;
     const int stride = (CH | 1) * 16;
@@ -248,9 +164,6 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_fused_kernel(const GemmPara
     const int KB = p.K / (2 * VEC);
     const unsigned char* a_base = smem + (size_t)(wm * RM * 32 + r32) * stride + h * 16;
     const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(p.wp);
-    T* __restrict__ out = reinterpret_cast<T*>(p.out);
-    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-
     for (int nfb = wn * RN; nfb < p.NFp; nfb += WN * RN) {
         f32x16 acc[RM][RN];
 #pragma unroll
@@ -305,46 +218,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_fused_kernel(const GemmPara
             }
         }
 
-        // epilogue: folded BN, residual, ReLU, NHWC store (4 channels per lane per quad)
-#pragma unroll
-        for (int j = 0; j < RN; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n0 = (nfb + j) * 32 + g * 8 + h * 4;
-                if (n0 < p.Nstore) {
-                    float sc[4] = {1.f, 1.f, 1.f, 1.f}, bi[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (p.scale) {
-                        const float4 t = *reinterpret_cast<const float4*>(p.scale + n0);
-                        sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w;
-                    }
-                    if (p.bias) {
-                        const float4 t = *reinterpret_cast<const float4*>(p.bias + n0);
-                        bi[0] = t.x; bi[1] = t.y; bi[2] = t.z; bi[3] = t.w;
-                    }
-#pragma unroll
-                    for (int i = 0; i < RM; ++i) {
-                        const int m = m0 + (wm * RM + i) * 32 + r32;
-                        if (m < p.M) {
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[i][j][g * 4 + e], sc[e], bi[e]);
-                            const size_t o = (size_t)m * p.ldo + n0;
-                            if (res) {
-                                float rv[4];
-                                load4<T>(res + o, rv);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += rv[e];
-                            }
-                            if (p.relu) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                            }
-                            store4<T>(out + o, v);
-                        }
-                    }
-                }
-            }
-        }
+        epilogue<T, RM, RN>(p, acc, nfb, m0 + wm * RM * 32, r32, h);
     }
 }
 

@@ -1,0 +1,152 @@
+"""The per-slide MC-dropout inference loop -- what ``Project.evaluate(model, outcome,
+filters, save_predictions=True)`` (``biscuit/experiment.py:917-922``) and the validation
+step of ``Project.train(..., save_predictions=True)`` (``experiment.py:1042-1051``) do for
+BISCUIT: stream every slide's 299x299 tiles, run the classifier with dropout active for
+``uq_n`` passes, keep per-tile mean/std, and reduce to slide-level prediction/uncertainty.
+
+Slides are sharded over ranks (one process per GPU); tiles stream in batches of
+``batch`` that may span slide boundaries (a per-tile slide index drives the device-side
+segmented reduce); each tile's Philox counter is its GLOBAL index in dataset order, so
+results do not depend on batch size, sharding or rank count.
+"""
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import distributed as D
+from .predictions import save_tile_predictions, tile_frame, EVAL_NAME
+
+
+@dataclass
+class Slide:
+    """One slide = one TFRecord's worth of tiles.  ``tiles`` is either a uint8 array
+    [T,299,299,3] (host or device) or a zero-argument callable returning one."""
+    name: str
+    tiles: object
+    n_tiles: int
+    y_true: int = 0
+    patient: Optional[str] = None
+    loc: Optional[np.ndarray] = None
+
+    def load(self):
+        t = self.tiles() if callable(self.tiles) else self.tiles
+        return t
+
+
+@dataclass
+class EvalResult:
+    tile_df: Optional[pd.DataFrame]          # this rank's tile rows (Slideflow headers)
+    slide_names: List[str]
+    slide_pred: np.ndarray                   # float64 [S], all slides (after the gather)
+    slide_unc: np.ndarray
+    slide_count: np.ndarray
+    slide_y_true: np.ndarray
+    local_slides: List[int] = field(default_factory=list)
+
+    def slide_frame(self, pred_thresh=0.5, level='slide'):
+        """Group table in ``process_group_predictions`` form from the device-reduced means."""
+        from .threshold import group_frame
+        keep = self.slide_count > 0
+        names = [n for n, k in zip(self.slide_names, keep) if k]
+        return group_frame(names, self.slide_pred[keep], self.slide_y_true[keep].astype(np.uint8),
+                           self.slide_unc[keep], pred_thresh, level)
+
+
+def _to_device(t, device):
+    if torch.is_tensor(t):
+        return t.to(device=device, dtype=torch.uint8, non_blocking=True).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(t)).to(device, non_blocking=True)
+
+
+def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=None, batch=256,
+             mc_mode='head', tile_uq=None, save_dir=None, keep_tiles=True, rank=0, world=1):
+    """Run MC-dropout inference over ``slides`` and return tile- and slide-level results.
+
+    Every rank passes the SAME slide list; rank r processes ``partition_slides(...)[r]``.
+    The slide-level arrays are all-gathered (one collective); tile rows stay rank-local and
+    are written as ``{save_dir}/tile_predictions_eval[.rankR].csv`` when requested."""
+    hp = engine.hp
+    mc_n = int(mc_n or hp.uq_n)
+    seed = int(hp.seed if seed is None else seed)
+    counts = [s.n_tiles for s in slides]
+    parts = D.partition_slides(counts, world)
+    mine = parts[rank]
+    offsets = D.global_tile_offsets(counts)
+    dev = engine.device
+    n_local = len(mine)
+    acc = None
+    rows_mean, rows_std, rows_slide, rows_true, rows_loc = [], [], [], [], []
+
+    # stream tiles of this rank's slides in batches that may span slides
+    pend_tiles, pend_sidx, pend_gidx = [], [], []
+    pend_n = 0
+
+    def flush(final=False):
+        nonlocal pend_tiles, pend_sidx, pend_gidx, pend_n, acc
+        while pend_n >= batch or (final and pend_n > 0):
+            tiles = torch.cat(pend_tiles) if len(pend_tiles) > 1 else pend_tiles[0]
+            sidx = torch.cat(pend_sidx) if len(pend_sidx) > 1 else pend_sidx[0]
+            gidx = np.concatenate(pend_gidx)
+            take = min(batch, pend_n)
+            cur, rest = tiles[:take].contiguous(), tiles[take:]
+            cs, rs = sidx[:take].contiguous(), sidx[take:]
+            cg, rg = gidx[:take], gidx[take:]
+            # global tile indices inside a batch are contiguous per slide but not across
+            # slides: run one bq_mc_infer per contiguous run so the Philox counter is exact
+            mean = torch.empty((take, 2), dtype=torch.float32, device=dev)
+            std = torch.empty((take, 2), dtype=torch.float32, device=dev)
+            brk = np.flatnonzero(np.diff(cg) != 1) + 1
+            starts = np.concatenate([[0], brk]); ends = np.concatenate([brk, [take]])
+            if len(starts) == 1:
+                engine.mc_infer(cur, mc_n, seed, tile_idx0=int(cg[0]), mc_mode=mc_mode, out=(mean, std))
+            else:
+                for a, b in zip(starts, ends):
+                    engine.mc_infer(cur[a:b], mc_n, seed, tile_idx0=int(cg[a]), mc_mode=mc_mode,
+                                    out=(mean[a:b], std[a:b]))
+            acc = engine.slide_reduce(mean, std, cs, max(n_local, 1), tile_uq=tile_uq, acc=acc)
+            if keep_tiles:
+                rows_mean.append(mean.cpu()); rows_std.append(std.cpu())
+            pend_tiles, pend_sidx, pend_gidx = ([rest] if rest.shape[0] else []), \
+                ([rs] if rs.shape[0] else []), ([rg] if rg.shape[0] else [])
+            pend_n = rest.shape[0]
+
+    for li, si in enumerate(mine):
+        s = slides[si]
+        t = _to_device(s.load(), dev)
+        assert t.shape[0] == s.n_tiles, (s.name, t.shape, s.n_tiles)
+        if s.n_tiles == 0:
+            continue
+        pend_tiles.append(t)
+        pend_sidx.append(torch.full((s.n_tiles,), li, dtype=torch.int32, device=dev))
+        pend_gidx.append(offsets[si] + np.arange(s.n_tiles, dtype=np.int64))
+        pend_n += s.n_tiles
+        if keep_tiles:
+            rows_slide += [s.name] * s.n_tiles
+            rows_true += [s.y_true] * s.n_tiles
+            if s.loc is not None:
+                rows_loc.append(np.asarray(s.loc))
+        flush()
+    flush(final=True)
+
+    if acc is not None:
+        mp, mu, cnt = engine.slide_finish(acc)
+        mp, mu, cnt = mp.cpu().numpy(), mu.cpu().numpy(), cnt.cpu().numpy()
+    else:
+        mp = mu = np.zeros(0); cnt = np.zeros(0, dtype=np.int64)
+    cap = max(len(p) for p in parts) if parts else 0
+    g_pred, g_unc, g_cnt = D.gather_slide_results(mine, mp[:n_local], mu[:n_local], cnt[:n_local],
+                                                  len(slides), cap)
+    tile_df = None
+    if keep_tiles:
+        mean = torch.cat(rows_mean).numpy() if rows_mean else np.zeros((0, 2), np.float32)
+        std = torch.cat(rows_std).numpy() if rows_std else np.zeros((0, 2), np.float32)
+        loc = np.concatenate(rows_loc) if rows_loc and sum(len(x) for x in rows_loc) == len(rows_slide) else None
+        tile_df = tile_frame(outcome, rows_slide, rows_true, mean, std, loc)
+        if save_dir is not None:
+            name = EVAL_NAME if world == 1 else EVAL_NAME.replace('.csv', f'.rank{rank}.csv')
+            save_tile_predictions(tile_df, save_dir, name)
+    return EvalResult(tile_df, [s.name for s in slides], g_pred, g_unc, g_cnt,
+                      np.array([s.y_true for s in slides]), list(mine))

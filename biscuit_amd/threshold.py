@@ -1,0 +1,254 @@
+"""Consumer of the tile-prediction table: same function names, arguments, return values
+and exceptions as ``biscuit/threshold.py`` so callers (``Experiment.results``,
+``thresholds_from_nested_cv``; ``experiment.py:705-720,967-1001``) can switch imports.
+
+Re-implemented, not copied: group statistics are vectorised (one ``groupby`` instead of
+the reference's per-level ``.loc`` scans, ``threshold.py:193-204``, which are O(S^2)),
+Youden's J uses ``argmax`` (first maximum, same tie-break as ``list.index`` at
+``threshold.py:151-152``).  Results are checked value-for-value against fixtures captured
+from the reference itself (``tests/golden/consumer_*.json.gz``).
+
+Known reference quirks kept on purpose: slide order = first
+appearance; ``y_true`` group mean truncated to uint8; strict ``<`` UQ filters; a falsy
+threshold disables a filter; ``>=`` in group binarisation vs ``>`` in ``apply``; with
+``slide_uq`` not 'detect', ``detect`` reports 0.5.  One deliberate difference: a frame
+missing required columns raises ``ValueError`` (the reference intends that but trips an
+``UnboundLocalError`` first, ``threshold.py:184-186``).  Plotting is out of scope.
+"""
+import logging
+import warnings
+
+import numpy as np
+import pandas as pd
+from sklearn import metrics
+from sklearn.exceptions import UndefinedMetricWarning
+
+from . import errors
+
+log = logging.getLogger('biscuit_amd')
+
+_FLOATS = (float, np.float16, np.float32, np.float64)
+
+
+def _roc(y_true, y_score):
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=UndefinedMetricWarning)
+        return metrics.roc_curve(y_true, y_score)
+
+
+def _youden(fpr, tpr, thresh):
+    """Threshold at the first maximum of tpr - fpr."""
+    j = np.asarray(tpr) - np.asarray(fpr)
+    if len(thresh) == 0 or np.isnan(j).any():
+        # one class only: the reference's max()/list.index() pair fails on the NaN rates
+        # with ValueError (threshold.py:151-152,423-424); callers rely on that.
+        raise ValueError('ROC undefined: only one class present')
+    return thresh[int(np.argmax(j))]
+
+
+def auc(y_true, y_pred):
+    """AUROC, NaN when undefined (``biscuit/utils.py:489-504``)."""
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', category=UndefinedMetricWarning)
+        try:
+            fpr, tpr, _ = metrics.roc_curve(y_true, y_pred)
+            return metrics.auc(fpr, tpr)
+        except ValueError:
+            log.warning('Unable to calculate ROC')
+            return np.nan
+
+
+def process_tile_predictions(df, pred_thresh=0.5, patients=None):
+    """Tile-level correctness flags (``threshold.py:125-177``).  Mutates ``df`` like the
+    reference: adds ``patient`` (if a mapping is given), ``error``, ``correct``,
+    ``incorrect``, ``y_pred_bin``.  Returns ``(df, pred_thresh)``."""
+    yp = df['y_pred'].to_numpy()
+    if np.isnan(yp).sum():
+        raise errors.PredsContainNaNError
+    fpr, tpr, thresh = _roc(df['y_true'].to_numpy(), yp)
+    try:
+        opt_pred = _youden(fpr, tpr, thresh)
+    except ValueError:
+        opt_pred = 0.5
+    if isinstance(pred_thresh, str) and pred_thresh == 'detect':
+        pred_thresh = opt_pred
+    if patients is not None:
+        df['patient'] = df['slide'].map(patients)
+    y_true = df['y_true']
+    y_pred = df['y_pred']
+    df['error'] = abs(y_true - y_pred)
+    df['correct'] = (((y_pred < pred_thresh) & (y_true == 0))
+                     | ((y_pred >= pred_thresh) & (y_true == 1)))
+    df['incorrect'] = (~df['correct']).astype(int)
+    df['y_pred_bin'] = (y_pred >= pred_thresh).astype(int)
+    return df, pred_thresh
+
+
+def group_means(df, level):
+    """Per-group means of y_pred / y_true / uncertainty in order of first appearance
+    (``threshold.py:189-204``).  Returns (levels, y_pred, y_true_uint8, uncertainty)."""
+    keys = df[level]
+    keep = keys.notna().to_numpy()
+    sub = df.loc[keep, [level, 'y_pred', 'y_true', 'uncertainty']]
+    g = sub.groupby(level, sort=False).mean()      # sort=False: first-appearance order
+    levels = list(g.index)
+    yp = g['y_pred'].to_numpy(dtype=np.float64)
+    yt = g['y_true'].to_numpy(dtype=np.float64).astype(np.uint8)   # truncation, threshold.py:197-200
+    un = g['uncertainty'].to_numpy(dtype=np.float64)
+    return levels, yp, yt, un
+
+
+def group_frame(levels, yp, yt, un, pred_thresh, level):
+    """Group table from already-reduced arrays -- the entry point for slide means that
+    were reduced on the GPU (``bq_slide_reduce``)."""
+    if not len(yt):
+        raise errors.ROCFailedError('Unable to generate ROC; preds are empty.')
+    fpr, tpr, thresh = _roc(yt, yp)
+    if isinstance(pred_thresh, str) and pred_thresh == 'detect':
+        try:
+            pred_thresh = _youden(fpr, tpr, thresh)
+        except ValueError:
+            raise errors.ROCFailedError(f'Unable to generate {level}-level ROC')
+    correct = ((yp < pred_thresh) & (yt == 0)) | ((yp >= pred_thresh) & (yt == 1))
+    incorrect = (((yp < pred_thresh) & (yt == 1)) | ((yp >= pred_thresh) & (yt == 0))).astype(int)
+    out = pd.DataFrame({
+        level: pd.Series(levels),
+        'error': pd.Series(abs(yt - yp)),
+        'uncertainty': pd.Series(un),
+        'correct': correct,
+        'incorrect': incorrect,
+        'y_true': pd.Series(yt),
+        'y_pred': pd.Series(yp),
+        'y_pred_bin': pd.Series(yp >= pred_thresh).astype(int),
+    })
+    return out, pred_thresh
+
+
+def process_group_predictions(df, pred_thresh, level):
+    """Slide-/patient-level predictions and uncertainty from tile rows
+    (``threshold.py:180-245``)."""
+    if any(c not in df.columns for c in ('y_true', 'y_pred', 'uncertainty')):
+        raise ValueError('Missing columns. Expected y_true, y_pred, uncertainty. '
+                         f'Got: {list(df.columns)}')
+    levels, yp, yt, un = group_means(df, level)
+    return group_frame(levels, yp, yt, un, pred_thresh, level)
+
+
+def _metrics(s_df, num_pre_filter, slide_pred):
+    a = auc(s_df['y_true'].to_numpy(), s_df['y_pred'].to_numpy())
+    percent_incl = len(s_df) / num_pre_filter
+    y_true = s_df['y_true'].to_numpy().astype(bool)
+    y_pred = s_df['y_pred'].to_numpy() > slide_pred       # '>' here, '>=' above (threshold.py:340)
+    tp = np.logical_and(y_true, y_pred).sum()
+    fp = np.logical_and(~y_true, y_pred).sum()
+    tn = np.logical_and(~y_true, ~y_pred).sum()
+    fn = np.logical_and(y_true, ~y_pred).sum()
+    with np.errstate(divide='ignore', invalid='ignore'):
+        acc = (tp + tn) / (tp + tn + fp + fn)
+        sens = tp / (tp + fn)
+        spec = tn / (tn + fp)
+    return {'auc': a, 'percent_incl': percent_incl, 'acc': acc, 'sensitivity': sens,
+            'specificity': spec}
+
+
+def apply(df, tile_uq, slide_uq, tile_pred=0.5, slide_pred=0.5, plot=False,
+          keep='high_confidence', title=None, patients=None, level='slide'):
+    """Apply pre-computed tile- and group-level uncertainty thresholds
+    (``threshold.py:248-361``).  Returns (metrics dict, thresholded group frame)."""
+    assert keep in ('high_confidence', 'low_confidence')
+    assert not (level == 'patient' and patients is None)
+    if plot:
+        raise NotImplementedError('plotting is outside the hot path (threshold.py:15-122)')
+    if patients:
+        df['patient'] = df['slide'].map(patients)
+    df, _ = process_tile_predictions(df, pred_thresh=tile_pred, patients=patients)
+    num_pre_filter = pd.unique(df[level]).shape[0]
+    if tile_uq:
+        df = df[df['uncertainty'] < tile_uq]
+    try:
+        s_df, _ = process_group_predictions(df, pred_thresh=slide_pred, level=level)
+    except errors.ROCFailedError:
+        log.error('Unable to process slide predictions')
+        return {k: None for k in ('auc', 'percent_incl', 'acc', 'sensitivity', 'specificity')}, None
+    if slide_uq:
+        if keep == 'high_confidence':
+            s_df = s_df.loc[s_df['uncertainty'] < slide_uq]
+        else:
+            s_df = s_df.loc[s_df['uncertainty'] >= slide_uq]
+    return _metrics(s_df, num_pre_filter, slide_pred), s_df
+
+
+def detect(df, tile_uq='detect', slide_uq='detect', tile_pred='detect', slide_pred='detect',
+           plot=False, patients=None):
+    """Detect optimal tile- and slide-level uncertainty thresholds
+    (``threshold.py:364-475``).  Returns (thresholds dict, slide-level AUROC)."""
+    empty = {k: None for k in ('tile_uq', 'slide_uq', 'tile_pred', 'slide_pred')}
+    if plot:
+        raise NotImplementedError('plotting is outside the hot path')
+    try:
+        df, detected_tile_pred = process_tile_predictions(df, pred_thresh=tile_pred, patients=patients)
+    except errors.PredsContainNaNError:
+        log.error('Tile-level predictions contain NaNs; unable to process.')
+        return empty, None
+    if isinstance(tile_pred, str) and tile_pred == 'detect':
+        tile_pred = detected_tile_pred
+
+    if isinstance(tile_uq, _FLOATS):
+        df = df[df['uncertainty'] < tile_uq]
+    elif not (isinstance(tile_uq, str) and tile_uq == 'detect'):
+        tile_uq = None
+    else:
+        fpr, tpr, thresh = _roc(df['incorrect'].to_numpy(), df['uncertainty'].to_numpy())
+        tile_uq = _youden(fpr, tpr, thresh)
+        df = df[df['uncertainty'] < tile_uq]
+
+    try:
+        s_df, slide_pred = process_group_predictions(df, pred_thresh=slide_pred, level='slide')
+    except errors.ROCFailedError:
+        log.error('Unable to process slide predictions')
+        return empty, None
+
+    if isinstance(slide_uq, str) and slide_uq == 'detect':
+        if not s_df['incorrect'].to_numpy().sum():
+            slide_uq = None
+        else:
+            fpr, tpr, thresh = _roc(s_df['incorrect'], s_df['uncertainty'].to_numpy())
+            slide_uq = _youden(fpr, tpr, thresh)
+            s_df = s_df[s_df['uncertainty'] < slide_uq]
+    else:
+        slide_uq = 0.5
+    a = auc(s_df['y_true'].to_numpy(), s_df['y_pred'].to_numpy())
+    return {'tile_uq': tile_uq, 'slide_uq': slide_uq, 'tile_pred': tile_pred,
+            'slide_pred': slide_pred}, a
+
+
+def from_cv(dfs, **kwargs):
+    """Optimal thresholds from a set of (nested) cross-validation folds
+    (``threshold.py:478-557``): tile_uq = min, slide_uq = max, prediction thresholds =
+    mean over the folds in which both UQ thresholds could be detected."""
+    required = ('y_true', 'y_pred', 'uncertainty', 'slide', 'patient')
+    k_tile, k_slide, k_tile_pred, k_slide_pred = [], [], [], []
+    skip_tile = 'tile_uq_thresh' in kwargs and kwargs['tile_uq_thresh'] is None
+    skip_slide = 'slide_uq_thresh' in kwargs and kwargs['slide_uq_thresh'] is None
+    for idx, df in enumerate(dfs):
+        if not all(col in df.columns for col in required):
+            raise ValueError(f'DataFrame missing columns, expected {required}, got: '
+                             f"{', '.join(df.columns.tolist())}")
+        thresholds, _ = detect(df, **kwargs)
+        if thresholds['tile_uq'] is None or thresholds['slide_uq'] is None:
+            log.debug(f'Skipping CV #{idx}, unable to detect threshold')
+            continue
+        k_tile_pred.append(thresholds['tile_pred'])
+        k_slide_pred.append(thresholds['slide_pred'])
+        if not skip_tile:
+            k_tile.append(thresholds['tile_uq'])
+        if not skip_slide:
+            k_slide.append(thresholds['slide_uq'])
+    if not skip_tile and not len(k_tile):
+        raise errors.ThresholdError('Unable to detect tile UQ threshold.')
+    if not skip_slide and not len(k_slide):
+        raise errors.ThresholdError('Unable to detect slide UQ threshold.')
+    return {'tile_uq': np.min(k_tile) if not skip_tile else k_tile,
+            'slide_uq': np.max(k_slide) if not skip_slide else k_slide,
+            'tile_pred': np.mean(k_tile_pred),
+            'slide_pred': np.mean(k_slide_pred)}

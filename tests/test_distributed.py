@@ -1,0 +1,136 @@
+"""N>1 path on CPU: world_size-2 gloo processes run the real sharding / streaming /
+gather code of biscuit_amd.inference with a stand-in for the device engine (the engine is
+the only GPU-bound piece; its stand-in computes a deterministic function of tile content
+and GLOBAL tile index so mis-sharding or mis-indexing changes the answer)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from biscuit_amd import distributed as D
+from biscuit_amd.hp import nature2022
+from biscuit_amd.inference import Slide, evaluate
+
+
+class StandInEngine:
+    def __init__(self):
+        self.hp = nature2022()
+        self.device = torch.device('cpu')
+        self.calls = []
+
+    def mc_infer(self, tiles, mc_n, seed, tile_idx0=0, mc_mode='head', out=None):
+        n = tiles.shape[0]
+        g = torch.arange(tile_idx0, tile_idx0 + n, dtype=torch.float64)
+        p1 = tiles.reshape(n, -1).double().mean(1) / 255.0
+        unc = ((g * 0.6180339887) % 1.0) * 0.05 + 0.001 * mc_n
+        mean, std = out
+        mean[:, 1] = p1.float(); mean[:, 0] = 1 - p1.float()
+        std[:, 0] = unc.float(); std[:, 1] = unc.float()
+        self.calls.append((int(tile_idx0), n))
+        return mean, std
+
+    def slide_reduce(self, mean2, std2, slide_idx, n_slides, tile_uq=None, acc=None):
+        if acc is None:
+            acc = (torch.zeros(n_slides, dtype=torch.float64), torch.zeros(n_slides, dtype=torch.float64),
+                   torch.zeros(n_slides, dtype=torch.int32))
+        keep = torch.ones(mean2.shape[0], dtype=torch.bool) if not tile_uq else (std2[:, 1] < tile_uq)
+        idx = slide_idx.long()[keep]
+        acc[0].index_add_(0, idx, mean2[keep, 1].double())
+        acc[1].index_add_(0, idx, std2[keep, 1].double())
+        acc[2].index_add_(0, idx, torch.ones(idx.shape[0], dtype=torch.int32))
+        return acc
+
+    def slide_finish(self, acc):
+        c = acc[2].double()
+        return acc[0] / c, acc[1] / c, acc[2]
+
+
+def make_slides():
+    rng = np.random.default_rng(0)
+    counts = [7, 0, 13, 5, 21, 1, 9, 4]
+    return [Slide(f's{i}', rng.integers(0, 256, (c, 4, 4, 3), dtype=np.uint8), c, y_true=i % 2)
+            for i, c in enumerate(counts)]
+
+
+def reference_result(slides, tile_uq=None):
+    pred, unc, cnt = [], [], []
+    off = 0
+    for s in slides:
+        g = np.arange(off, off + s.n_tiles, dtype=np.float64)
+        off += s.n_tiles
+        p = s.tiles.reshape(s.n_tiles, -1).astype(np.float64).mean(1) / 255.0 if s.n_tiles else np.zeros(0)
+        u = (((g * 0.6180339887) % 1.0) * 0.05 + 0.001 * 30).astype(np.float32).astype(np.float64)
+        p = p.astype(np.float32).astype(np.float64)
+        keep = np.ones(len(p), bool) if not tile_uq else u < tile_uq
+        pred.append(p[keep].mean() if keep.any() else np.nan)
+        unc.append(u[keep].mean() if keep.any() else np.nan)
+        cnt.append(int(keep.sum()))
+    return np.array(pred), np.array(unc), np.array(cnt)
+
+
+@pytest.mark.parametrize('batch', [4, 16, 256])
+def test_streaming_single_process(batch):
+    slides = make_slides()
+    eng = StandInEngine()
+    res = evaluate(eng, slides, outcome='cohort', mc_n=30, seed=1, batch=batch)
+    pred, unc, cnt = reference_result(slides)
+    np.testing.assert_allclose(res.slide_pred, pred, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(res.slide_unc, unc, atol=1e-12, equal_nan=True)
+    assert list(res.slide_count) == list(cnt)
+    assert len(res.tile_df) == sum(cnt)
+    assert list(res.tile_df.columns)[:2] == ['slide', 'cohort-y_true0']
+    # every mc_infer call covered a run of consecutive global indices, all tiles exactly once
+    seen = sorted(sum([list(range(a, a + n)) for a, n in eng.calls], []))
+    assert seen == list(range(sum(cnt)))
+    # slide table in first-appearance order, empty slide dropped
+    sf, _ = res.slide_frame()
+    assert list(sf['slide']) == [s.name for s in slides if s.n_tiles]
+
+
+def test_tile_uq_filter_on_reduce():
+    slides = make_slides()
+    res = evaluate(StandInEngine(), slides, mc_n=30, seed=1, batch=8, tile_uq=0.05)
+    pred, unc, cnt = reference_result(slides, tile_uq=0.05)
+    assert list(res.slide_count) == list(cnt)
+    ok = cnt > 0
+    np.testing.assert_allclose(res.slide_pred[ok], pred[ok], atol=1e-12)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = D.init_from_env(device_type='cpu')
+    slides = make_slides()
+    res = evaluate(StandInEngine(), slides, mc_n=30, seed=1, batch=8, rank=r, world=w)
+    q.put((rank, res.slide_pred, res.slide_unc, res.slide_count, res.local_slides, len(res.tile_df)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    slides = make_slides()
+    pred, unc, cnt = reference_result(slides)
+    locals_ = []
+    for rank, gp, gu, gc, loc, ntile in out:
+        np.testing.assert_allclose(gp, pred, atol=1e-12, equal_nan=True)      # every rank holds all slides
+        np.testing.assert_allclose(gu, unc, atol=1e-12, equal_nan=True)
+        assert list(gc) == list(cnt)
+        assert ntile == sum(cnt[i] for i in loc)                              # tile rows stay rank-local
+        locals_ += loc
+    assert sorted(locals_) == list(range(len(slides)))                        # disjoint cover

@@ -1,0 +1,281 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, against committed golden fixtures, and -- at BASELINE.json's full sizes --
+through size-independent properties.  Run on the MI355X box with ``-m gpu``.
+
+Tolerances (BASELINE.json north_star: tile- and slide-level mean/std within 1e-3 in fp32):
+  * fp32 path vs fp32 oracle ........ 1e-4 on probabilities (measured ~1e-7), 2e-4 on layers
+  * bf16 path vs bf16-emulating oracle (same rounding points) 1e-3
+  * bf16 path vs fp32 oracle ........ 1e-3 at tile and slide level (measured in the report)
+  * integer / index work (masks, counts, slide order) ........ bit-exact
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from biscuit_amd.synthetic import make_slides, make_tiles
+from biscuit_amd.weights import synthetic_weights
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+TAPS = [('staged', (299, 299, 3)), ('block1_conv1', (149, 149, 32)), ('block1_conv2', (147, 147, 64)),
+        ('block2_res', (74, 74, 128)), ('block2_sepconv1', (147, 147, 128)), ('block2_sepconv2', (147, 147, 128)),
+        ('block2_out', (74, 74, 128)), ('block3_res', (37, 37, 256)), ('block3_sepconv1', (74, 74, 256)),
+        ('block3_sepconv2', (74, 74, 256)), ('block3_out', (37, 37, 256)), ('block4_res', (19, 19, 728)),
+        ('block4_sepconv1', (37, 37, 728)), ('block4_sepconv2', (37, 37, 728)), ('block4_out', (19, 19, 728))] + \
+       [(f'block{b}_out', (19, 19, 728)) for b in range(5, 13)] + \
+       [('block13_out', (10, 10, 1024)), ('block14_sepconv1', (10, 10, 1536)), ('block14_sepconv2', (10, 10, 2048))]
+
+
+@pytest.fixture(scope='module')
+def weights():
+    return synthetic_weights(1)
+
+
+@pytest.fixture(scope='module')
+def engines(weights):
+    from biscuit_amd.engine import Engine
+    return {'f32': Engine(weights, dtype='f32', max_batch=256, max_mc=50),
+            'bf16': Engine(weights, dtype='bf16', max_batch=256, max_mc=50)}
+
+
+@pytest.fixture(scope='module')
+def oracles(weights):
+    from oracle.xception_ref import XceptionOracle
+    return {'f32': XceptionOracle(weights), 'bf16': XceptionOracle(weights, emulate_bf16=True)}
+
+
+@pytest.fixture(scope='module')
+def tiles():
+    t, _, _ = make_slides(3, 2, seed=0)
+    return t
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def test_native_library_is_loaded():
+    from biscuit_amd import _lib
+    maps = open('/proc/self/maps').read()
+    assert 'libbiscuit_hip.so' in maps and os.path.exists(_lib.LIB_PATH)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_stage_exact(engines, tiles, dtype):
+    from oracle.xception_ref import standardize
+    ref = standardize(tiles)
+    if dtype == 'bf16':
+        ref = ref.to(torch.bfloat16).float()
+    got = engines[dtype].stage(dev(tiles)).float().cpu()
+    assert torch.equal(got, ref)            # integer statistics -> bit-exact
+    const = np.full((1, 299, 299, 3), 9, np.uint8)         # std = 0 edge case (floor 1/sqrt(N))
+    assert torch.all(engines[dtype].stage(dev(const)).float() == 0)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_every_layer_against_oracle(engines, oracles, tiles, dtype):
+    from oracle.xception_ref import standardize
+    taps = {}
+    t2 = tiles[:2]
+    feat_ref = oracles[dtype].backbone(standardize(t2), taps)
+    eng = engines[dtype]
+    staged = eng.stage(dev(t2))
+    for name, shp in TAPS:
+        got = eng.debug_activation(name, staged, shp).cpu().numpy()
+        ref = taps[name].permute(0, 2, 3, 1).numpy()
+        d = np.abs(got - ref)
+        if dtype == 'f32':
+            assert d.max() < 2e-4, (name, d.max())
+        else:
+            # identical rounding points; only fp32 accumulation order differs, which flips an
+            # occasional bf16 rounding (1 ulp = 2^-8 relative) and propagates
+            rms = np.sqrt((d ** 2).mean()) / np.sqrt((ref ** 2).mean())
+            assert rms < 2e-2 and not np.isnan(got).any(), (name, rms)
+    feat = eng.backbone(staged).cpu().numpy()
+    tol = 1e-4 if dtype == 'f32' else 3e-2
+    assert np.abs(feat - feat_ref.numpy()).max() < tol
+
+
+def test_mc_head_against_oracle(engines, oracles):
+    feat = np.abs(np.random.default_rng(3).normal(0.8, 0.5, (37, 2048))).astype(np.float32)
+    for mc in (1, 5, 30):
+        m, s = engines['f32'].mc_head(dev(feat), mc, 1234, tile_idx0=11)
+        rm, rs = oracles['f32'].mc_from_features(feat, mc, 1234, tile_index0=11)
+        assert np.abs(m.cpu().numpy() - rm).max() < 1e-6
+        assert np.abs(s.cpu().numpy() - rs).max() < 1e-6
+    m1, s1 = engines['f32'].mc_head(dev(feat), 1, 7)
+    assert torch.all(s1 == 0)                                    # one pass -> zero std
+    # the bf16 engine's head is the same fp32 code
+    mb, sb = engines['bf16'].mc_head(dev(feat), 5, 1234, tile_idx0=11)
+    mf, sf = engines['f32'].mc_head(dev(feat), 5, 1234, tile_idx0=11)
+    assert torch.equal(mb, mf) and torch.equal(sb, sf)
+
+
+def test_end_to_end_fp32(engines, oracles, tiles):
+    m, s = engines['f32'].mc_infer(dev(tiles), 5, 1234)
+    rm, rs = oracles['f32'].mc_predict(tiles, 5, 1234, mode='head')
+    assert np.abs(m.cpu().numpy() - rm).max() < 1e-4            # north-star tolerance is 1e-3
+    assert np.abs(s.cpu().numpy() - rs).max() < 1e-4
+    m = m.cpu().numpy(); s = s.cpu().numpy()
+    np.testing.assert_allclose(m.sum(1), 1.0, atol=1e-6)
+    np.testing.assert_allclose(s[:, 0], s[:, 1], atol=1e-6)
+
+
+def test_end_to_end_bf16(engines, oracles, tiles):
+    m, s = engines['bf16'].mc_infer(dev(tiles), 5, 1234)
+    m, s = m.cpu().numpy(), s.cpu().numpy()
+    rm, rs = oracles['bf16'].mc_predict(tiles, 5, 1234, mode='head')
+    assert np.abs(m - rm).max() < 1e-3 and np.abs(s - rs).max() < 1e-3
+    fm, fs = oracles['f32'].mc_predict(tiles, 5, 1234, mode='head')
+    print('bf16 HIP vs fp32 oracle: max|dmean|=%.3e max|dstd|=%.3e' % (np.abs(m - fm).max(), np.abs(s - fs).max()))
+    assert np.abs(m - fm).max() < 1e-3 and np.abs(s - fs).max() < 1e-3
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_full_mode_batching_and_determinism_bit_exact(engines, tiles, dtype):
+    eng = engines[dtype]
+    d = dev(tiles)
+    m_h, s_h = eng.mc_infer(d, 4, 99, tile_idx0=100, mc_mode='head')
+    m_f, s_f = eng.mc_infer(d, 4, 99, tile_idx0=100, mc_mode='full')
+    assert torch.equal(m_h, m_f) and torch.equal(s_h, s_f)       # N full passes == fused Welford
+    m_a, s_a = eng.mc_infer(d[:2].contiguous(), 4, 99, tile_idx0=100)
+    m_b, s_b = eng.mc_infer(d[2:].contiguous(), 4, 99, tile_idx0=102)
+    assert torch.equal(torch.cat([m_a, m_b]), m_h) and torch.equal(torch.cat([s_a, s_b]), s_h)
+    m_r, s_r = eng.mc_infer(d, 4, 99, tile_idx0=100)
+    assert torch.equal(m_r, m_h) and torch.equal(s_r, s_h)
+    m_o, _ = eng.mc_infer(d, 4, 100, tile_idx0=100)
+    assert not torch.equal(m_o, m_h)                             # the seed matters
+
+
+def test_golden_config1(engines):
+    """BASELINE.json config 1: 16 slides x 64 tiles, MC=5, against the committed fixture."""
+    g = np.load(os.path.join(GOLDEN, 'producer_cfg1.npz'))
+    tiles, sidx, y_true = make_slides(16, 64, seed=0)
+    assert np.uint64(tiles.astype(np.uint64).sum()) == g['tile_checksum']      # same inputs as the fixture
+    assert np.array_equal(sidx, g['slide_idx'])
+    d_sidx = dev(sidx)
+    for dtype, key, tol_tile, tol_slide in (('f32', 'f32', 1e-4, 1e-5), ('bf16', 'bf16emu', 1e-3, 3e-4)):
+        eng = engines[dtype]
+        means, stds = [], []
+        for a in range(0, 1024, 256):
+            m, s = eng.mc_infer(dev(tiles[a:a + 256]), 5, 1234, tile_idx0=a)
+            means.append(m); stds.append(s)
+        m, s = torch.cat(means), torch.cat(stds)
+        assert np.abs(m.cpu().numpy() - g[f'mean_{key}']).max() < tol_tile
+        assert np.abs(s.cpu().numpy() - g[f'std_{key}']).max() < tol_tile
+        mp, mu, cnt = eng.slide_finish(eng.slide_reduce(m, s, d_sidx, 16))
+        assert list(cnt.cpu().numpy()) == [64] * 16
+        assert np.abs(mp.cpu().numpy() - g[f'slide_pred_{key}']).max() < tol_slide
+        assert np.abs(mu.cpu().numpy() - g[f'slide_unc_{key}']).max() < tol_slide
+        if dtype == 'bf16':      # and the headline claim: bf16 kernels vs the fp32 oracle, slide level
+            d_pred = np.abs(mp.cpu().numpy() - g['slide_pred_f32']).max()
+            d_unc = np.abs(mu.cpu().numpy() - g['slide_unc_f32']).max()
+            d_tile = np.abs(m.cpu().numpy() - g['mean_f32']).max()
+            print('bf16 HIP vs fp32 golden: tile max|d|=%.3e slide pred %.3e unc %.3e' % (d_tile, d_pred, d_unc))
+            assert d_pred < 1e-3 and d_unc < 1e-3 and d_tile < 1e-3
+
+
+def test_slide_reduce_against_reference_consumer(engines, consumer_cases):
+    """Device segmented reduce vs the group means the reference's own
+    process_group_predictions produced (golden), incl. the strict '<' tile-UQ filter."""
+    eng = engines['bf16']
+    for case in consumer_cases['cases']:
+        inp = case['input']
+        yp = np.array(inp['y_pred'], np.float32); un = np.array(inp['uncertainty'], np.float32)
+        names = list(dict.fromkeys(inp['slide']))                 # first-appearance order
+        idx = np.array([names.index(s) for s in inp['slide']], np.int32)
+        mean2 = np.stack([1 - yp, yp], 1); std2 = np.stack([un, un], 1)
+        for key, uq in (('group_slide_0.5', None), ('group_slide_filtered', case['group_slide_filtered']['tile_uq'])):
+            want = case[key]
+            acc = eng.slide_reduce(dev(mean2), dev(std2), dev(idx), len(names), tile_uq=uq)
+            mp, mu, cnt = [x.cpu().numpy() for x in eng.slide_finish(acc)]
+            order = [names.index(s) for s in want['levels']]
+            if uq is not None:    # float32 copy of uncertainty vs the float64 threshold: same side of '<'?
+                keep64 = np.array(inp['uncertainty']) < uq
+                if not np.array_equal(keep64, un < np.float32(uq)):
+                    continue
+            np.testing.assert_allclose(mp[order], want['cols']['y_pred'], atol=1e-7)
+            np.testing.assert_allclose(mu[order], want['cols']['uncertainty'], atol=1e-7)
+        # equality goes to low-confidence: threshold exactly at a tile's uncertainty drops it
+        acc = eng.slide_reduce(dev(mean2), dev(std2), dev(idx), len(names), tile_uq=float(un[0]))
+        cnt_eq = eng.slide_finish(acc)[2].cpu().numpy()
+        assert cnt_eq.sum() == int((un < un[0]).sum())
+        # 0 / None disable the filter (threshold.py:297 `if tile_uq:`)
+        for off in (0.0, None):
+            c = eng.slide_finish(eng.slide_reduce(dev(mean2), dev(std2), dev(idx), len(names), tile_uq=off))[2]
+            assert int(c.sum()) == len(yp)
+    # bit-reproducible whatever the order of arrival
+    perm = np.random.default_rng(0).permutation(len(yp))
+    a1 = eng.slide_reduce(dev(mean2), dev(std2), dev(idx), len(names))
+    a2 = eng.slide_reduce(dev(mean2[perm]), dev(std2[perm]), dev(idx[perm]), len(names))
+    assert all(torch.equal(x, y) for x, y in zip(a1, a2))
+
+
+def test_uncertainty_interface_mirror(engines, oracles, tiles):
+    """results.py:250-258: standardise on the host, call interface(batch[1,299,299,3])."""
+    from biscuit_amd.engine import UncertaintyInterface
+    from oracle.xception_ref import standardize
+    x = standardize(tiles[:1]).permute(0, 2, 3, 1).contiguous().numpy()
+    itf = UncertaintyInterface(engines['f32'], uq_n=30, seed=5)
+    mean, unc = itf(x)
+    assert mean.shape == (1, 2) and unc.shape == (1, 2)
+    feat = oracles['f32'].backbone(torch.from_numpy(x).permute(0, 3, 1, 2))
+    rm, rs = oracles['f32'].mc_from_features(feat, 30, 5)
+    assert abs(mean[0][1] - rm[0][1]) < 1e-4 and abs(unc[0][0] - rs[0][0]) < 1e-4
+    with pytest.raises(ValueError):
+        itf(np.zeros((1, 64, 64, 3), np.float32))
+
+
+def test_full_size_properties(engines):
+    """BASELINE.json config 2 sizes (1000 tiles/slide, batch 256, MC=30, bf16): properties
+    that do not need the oracle at that size."""
+    eng = engines['bf16']
+    g = torch.Generator(device='cuda').manual_seed(0)
+    base = torch.randint(0, 256, (250, 299, 299, 3), dtype=torch.uint8, device='cuda', generator=g)
+    tiles = torch.cat([base, base[:6]])                 # 256: six duplicates at other batch positions
+    feat = eng.backbone(eng.stage(tiles))
+    assert torch.equal(feat[250:], feat[:6])            # a tile's features do not depend on its position
+    feat17 = eng.backbone(eng.stage(tiles[:17].contiguous()))
+    assert torch.equal(feat17, feat[:17])               # nor on the batch size
+    assert torch.isfinite(feat).all() and (feat >= 0).all()
+    means, stds, sidx = [], [], []
+    for b in range(4):                                  # 1000 tiles of one slide in batches of 256
+        n = 256 if b < 3 else 232
+        m, s = eng.mc_infer(tiles[:n].contiguous(), 30, 1234, tile_idx0=b * 256)
+        means.append(m); stds.append(s)
+    m, s = torch.cat(means), torch.cat(stds)
+    assert m.shape == (1000, 2)
+    assert torch.allclose(m.sum(1), torch.ones(1000, device='cuda'), atol=1e-6)
+    assert torch.allclose(s[:, 0], s[:, 1], atol=1e-6) and (s > 0).all() and (s < 0.5).all()
+    assert not torch.equal(m[:256], m[256:512])         # same tiles, other global index -> other masks
+    idx = torch.zeros(1000, dtype=torch.int32, device='cuda')
+    mp, mu, cnt = eng.slide_finish(eng.slide_reduce(m, s, idx, 1))
+    assert int(cnt[0]) == 1000
+    assert abs(float(mp[0]) - float(m[:, 1].double().mean())) < 1e-9
+    assert abs(float(mu[0]) - float(s[:, 1].double().mean())) < 1e-9
+
+
+def test_evaluate_driver_matches_direct_calls(engines):
+    """biscuit_amd.inference.evaluate (ragged slides, batches spanning slides) == direct calls."""
+    from biscuit_amd.inference import Slide, evaluate
+    eng = engines['bf16']
+    counts = [5, 0, 9, 3]
+    rng = np.random.default_rng(1)
+    slides = [Slide(f's{i}', make_tiles(c, seed=40 + i) if c else np.zeros((0, 299, 299, 3), np.uint8), c,
+                    y_true=i % 2) for i, c in enumerate(counts)]
+    res = evaluate(eng, slides, outcome='cohort', mc_n=5, seed=7, batch=4)
+    allt = np.concatenate([s.tiles for s in slides])
+    m, s = eng.mc_infer(dev(allt), 5, 7, tile_idx0=0)
+    df = res.tile_df
+    assert np.array_equal(df['cohort-y_pred1'].to_numpy(), m[:, 1].double().cpu().numpy())
+    assert np.array_equal(df['cohort-uncertainty1'].to_numpy(), s[:, 1].double().cpu().numpy())
+    assert list(res.slide_count) == counts
+    off = 0
+    for i, c in enumerate(counts):
+        if c:
+            assert abs(res.slide_pred[i] - float(m[off:off + c, 1].double().mean())) < 1e-9
+        off += c

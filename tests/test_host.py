@@ -1,0 +1,143 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the
+header declares (no compute without a GPU), weight packing matches its definition, the
+table contract, partitioning."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from biscuit_amd import predictions as P
+from biscuit_amd import weights as W
+from biscuit_amd.distributed import global_tile_offsets, partition_slides
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_symbols_exported():
+    from biscuit_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'biscuit_hip.h')).read()
+    declared = set(re.findall(r'\b(bq_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'bq_ctx', 'bq_config', 'bq_stream_t', 'bq_prof_entry'}
+    assert declared == set(_lib.ABI), declared ^ set(_lib.ABI)
+    for name in declared:
+        assert hasattr(_lib.lib, name), name
+    # fails loudly, with a message, when there is no device (never falls back to CPU)
+    cfg = _lib.BqConfig(1, 299, 2, 0.1, 8, 30)
+    import torch
+    if not torch.cuda.is_available():
+        assert not _lib.lib.bq_create(0, ctypes.byref(cfg))
+        assert b'HIP device' in _lib.lib.bq_last_error(None)
+        from biscuit_amd.engine import BiscuitHipError, Engine
+        with pytest.raises(BiscuitHipError):
+            Engine({}, dtype='bf16')
+
+
+def test_missing_library_is_an_error(tmp_path):
+    from biscuit_amd import _lib
+    with pytest.raises(ImportError):
+        _lib.load(str(tmp_path / 'nope.so'))
+
+
+def test_pack_fragments_definition():
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(40, 70)).astype(np.float32)
+    for vec in (8, 4):
+        kpad = 48
+        p = W.pack_fragments(w, kpad, vec)
+        nfp = p.shape[0]
+        assert p.shape == (3, kpad // (2 * vec), 64, vec) and nfp * 32 >= 70
+        for nf, kb, lane, v in [(0, 0, 0, 0), (1, 1, 37, 3), (2, kpad // (2 * vec) - 1, 63, vec - 1), (0, 2, 5, 1)]:
+            k = kb * 2 * vec + (lane >> 5) * vec + v
+            n = nf * 32 + (lane & 31)
+            want = w[k, n] if (k < 40 and n < 70) else 0.0
+            assert p[nf, kb, lane, v] == want
+    assert W.nfrags_padded(728) == 24 and W.nfrags_padded(128) == 4 and W.nfrags_padded(64) == 2
+    assert W.pad_channels(728) == 736
+
+
+def test_bf16_rounding_bits():
+    import torch
+    x = np.random.default_rng(1).normal(size=1000).astype(np.float32)
+    want = torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().astype(np.uint16)
+    assert (W.f32_to_bf16_bits(x) == want).all()
+
+
+def test_blob_directory_roundtrip():
+    w = W.synthetic_weights(3)
+    blob = W.pack_blob(w, 'bf16')
+    magic, ver, n, dt = struct.unpack_from('<4sIII', blob, 0)
+    assert (magic, ver, dt) == (b'BQW1', 1, 1)
+    names = {}
+    for i in range(n):
+        nm, off, ln = struct.unpack_from('<48sQQ', blob, 16 + 64 * i)
+        names[nm.rstrip(b'\0').decode()] = (off, ln)
+        assert off % 256 == 0 and off + ln <= len(blob)
+    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2     # stem, conv2, res, sepconvs, hidden, logits
+    off, ln = names['block5_sepconv2/scale']
+    s, b = W.fold_bn(w, 'block5_sepconv2_bn')
+    got = np.frombuffer(blob, np.float32, ln // 4, off)
+    assert ln == 768 * 4 and np.array_equal(got[:728], s) and not got[728:].any()
+    off, ln = names['block5_sepconv2/wp']
+    assert ln == 24 * 46 * 64 * 8 * 2
+    f32 = W.pack_blob(w, 'f32')
+    assert struct.unpack_from('<4sIII', f32, 0)[3] == 0
+
+
+def test_fold_bn_equals_batchnorm():
+    w = W.synthetic_weights(2)
+    x = np.random.default_rng(0).normal(size=(5, 128)).astype(np.float32)
+    s, b = W.fold_bn(w, 'block2_sepconv1_bn')
+    ref = (x - w['block2_sepconv1_bn/moving_mean']) / np.sqrt(w['block2_sepconv1_bn/moving_variance'] + 1e-3) \
+        * w['block2_sepconv1_bn/gamma'] + w['block2_sepconv1_bn/beta']
+    np.testing.assert_allclose(x * s + b, ref, atol=1e-5)
+
+
+def test_table_contract(tmp_path):
+    mean = np.array([[0.3, 0.7], [0.6, 0.4]], np.float32)
+    std = np.array([[0.02, 0.02], [0.05, 0.05]], np.float32)
+    df = P.tile_frame('cohort', ['a', 'b'], [1, 0], mean, std)
+    assert list(df.columns) == ['slide', 'cohort-y_true0', 'cohort-y_pred0', 'cohort-y_pred1',
+                                'cohort-uncertainty0', 'cohort-uncertainty1']
+    path = P.save_tile_predictions(df, str(tmp_path))
+    assert path.endswith('tile_predictions_eval.csv')
+    back = P.load_tile_predictions(path, 'cohort')
+    assert {'y_true', 'y_pred', 'uncertainty', 'slide'} <= set(back.columns)
+    np.testing.assert_allclose(back['y_pred'], mean[:, 1].astype(np.float64))     # class-1 column
+    np.testing.assert_allclose(back['uncertainty'], std[:, 1].astype(np.float64))
+    # underscore headers and the '-y_true' fallback (utils.py:31-53)
+    d2 = pd.DataFrame({'slide': ['1'], 'o_y_true0': [1], 'o_y_pred1': [0.9], 'o_uncertainty1': [0.1]})
+    P.rename_cols(d2, 'o')
+    assert {'y_true', 'y_pred', 'uncertainty'} <= set(d2.columns)
+    d3 = pd.DataFrame({'slide': ['1'], 'o-y_true': [1], 'o-y_pred1': [0.9], 'o-uncertainty1': [0.1]})
+    P.rename_cols(d3, 'o')
+    assert 'y_true' in d3.columns
+    from biscuit_amd.errors import PredsContainNaNError
+    with pytest.raises(PredsContainNaNError):
+        P.tile_frame('c', ['a'], [0], np.array([[np.nan, 0.5]], np.float32), std[:1])
+
+
+def test_partition_and_offsets():
+    parts = partition_slides([1000] * 16, 8)
+    assert sorted(sum(parts, [])) == list(range(16)) and all(len(p) == 2 for p in parts)
+    ragged = [5, 900, 20, 300, 300, 1, 0, 64]
+    parts = partition_slides(ragged, 3)
+    assert sorted(sum(parts, [])) == list(range(8))
+    loads = [sum(ragged[i] for i in p) for p in parts]
+    assert max(loads) == 900                     # LPT: the big slide alone
+    assert partition_slides(ragged, 3) == parts  # deterministic
+    assert partition_slides([], 2) == [[], []]
+    assert list(global_tile_offsets([5, 3, 8])) == [0, 5, 8]
+
+
+def test_hp_mirror():
+    from biscuit_amd.hp import nature2022
+    hp = nature2022().validate()
+    assert (hp.model, hp.tile_px, hp.dropout, hp.hidden_layers, hp.hidden_layer_width, hp.batch_size) == \
+        ('xception', 299, 0.1, 2, 1024, 128)
+    hp.hidden_layers = 3
+    with pytest.raises(ValueError):
+        hp.validate()
