@@ -202,6 +202,8 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
              L.cout, a.H, a.W);
     ProfScope ps(c, s, cls, flops, bytes);
     static const bool no_pipe = getenv("BQ_NO_PIPE") != nullptr;
+    static const int dbg = getenv("BQ_DBG") ? atoi(getenv("BQ_DBG")) : 0;
+    p.dbg = dbg;
     if (!no_pipe && nsplit == 1 && pipe_supported(dtype, a.prod, L.nfp, a.W, L.kpad)) {
         p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;

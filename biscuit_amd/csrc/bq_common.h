@@ -54,6 +54,7 @@ struct GemmParams {
     float dscale;
     int layer, mc_n, pass0, in_row_is_tile;
     long long tile0;
+    int dbg;               // ablation flags for timing experiments (0 in production)
 };
 
 size_t gemm_lds_bytes(int dtype, int shape, int K);

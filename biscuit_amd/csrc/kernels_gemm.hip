@@ -218,7 +218,15 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_fused_kernel(const GemmPara
             }
         }
 
-        epilogue<T, RM, RN>(p, acc, nfb, m0 + wm * RM * 32, r32, h);
+        if (p.NFp == WN * RN) {
+            // single pass over N: the A tile is dead, reuse LDS to coalesce the stores
+            __syncthreads();
+            epilogue_to_lds<T, RM, RN>(p, acc, nfb, wm * RM * 32, m0, r32, h, smem);
+            __syncthreads();
+            lds_rows_to_global<T, NT, MT>(p, m0, tid, smem);
+        } else {
+            epilogue<T, RM, RN>(p, acc, nfb, m0 + wm * RM * 32, r32, h);
+        }
     }
 }
 
@@ -232,7 +240,11 @@ int launch_inst(const GemmParams& p, hipStream_t s) {
     constexpr int PF = 4;
     auto kern = gemm_fused_kernel<T, PROD, d.MF, d.WM, d.WN, d.RN, PF>;
     const int vec = TT<T>::VEC;
-    const size_t lds = (size_t)(((p.K / vec) | 1) * 16) * (32 * d.MF);
+    size_t lds = (size_t)(((p.K / vec) | 1) * 16) * (32 * d.MF);
+    if (p.NFp == d.WN * d.RN) {   // staged epilogue needs MT rows of the output tile
+        const size_t stage = (size_t)(32 * d.MF) * (p.Nstore * sizeof(T) + 16);
+        if (stage > lds) lds = stage;
+    }
     static size_t lds_set = 0;
     if (lds > lds_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

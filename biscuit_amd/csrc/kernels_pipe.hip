@@ -24,11 +24,90 @@ constexpr int CPR = KC / 8;        // 16-byte pieces per raw pixel row (8)
 constexpr int RAW_ROW = KC * 2;    // 128 B of one pixel's chunk
 constexpr int A_STR = KC * 2 + 16; // 144 B: odd number of 16-byte slots -> conflict-free ds_read_b128
 
+// All LDS addresses are formed as `smem + integer offset` so the compiler keeps them in the
+// LDS address space (ds_* instructions); pointer arrays / lambdas capturing pointers decay
+// to flat addressing and scratch.
+// Raw staging registers as three named values (an array here ends up in scratch).
+struct Raw3 { uint4 a, b, c; };
+
+template <int NT>
+__device__ __forceinline__ uint4 raw_load1(const bf16_t* __restrict__ in, int ldi, int coff, int row, int p_lo, int M) {
+    int prow = p_lo + row;
+    prow = prow < 0 ? 0 : (prow >= M ? M - 1 : prow);
+    return *reinterpret_cast<const uint4*>(in + (size_t)prow * ldi + coff);
+}
+
+template <int NT>
+__device__ __forceinline__ Raw3 raw_load(const bf16_t* __restrict__ in, int ldi, int c, int K, int jch, int tid,
+                                         int p_lo, int M) {
+    // Branch-free (clamped) so the loads stay in flight: rows outside the tensor and pieces
+    // past K load valid-but-unused data.
+    int coff = c * KC + jch * 8;
+    coff = coff < K - 8 ? coff : K - 8;
+    Raw3 r;
+    r.a = raw_load1<NT>(in, ldi, coff, tid >> 3, p_lo, M);
+    r.b = raw_load1<NT>(in, ldi, coff, (tid + NT) >> 3, p_lo, M);
+    r.c = raw_load1<NT>(in, ldi, coff, (tid + 2 * NT) >> 3, p_lo, M);
+    return r;
+}
+
+template <int NT>
+__device__ __forceinline__ void raw_store1(const uint4& v, unsigned char* smem, int raw_off, int jch, int row,
+                                           int p_lo, int HP, int M) {
+    const int prow = p_lo + row;
+    if (row < HP && prow >= 0 && prow < M)
+        *reinterpret_cast<uint4*>(smem + raw_off + row * RAW_ROW + jch * 16) = v;
+}
+
+template <int NT>
+__device__ __forceinline__ void raw_store(const Raw3& r, unsigned char* smem, int raw_off, int jch, int tid,
+                                          int p_lo, int HP, int M) {
+    raw_store1<NT>(r.a, smem, raw_off, jch, tid >> 3, p_lo, HP, M);
+    raw_store1<NT>(r.b, smem, raw_off, jch, (tid + NT) >> 3, p_lo, HP, M);
+    raw_store1<NT>(r.c, smem, raw_off, jch, (tid + 2 * NT) >> 3, p_lo, HP, M);
+}
+
+// D stage: depthwise 3x3 of chunk c, raw rows at smem+raw_off -> A chunk at smem+a_off
+template <bool RELU, int NT, int MT, int NITEM>
+__device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, int wl_off, int c, int K,
+                                          int W, int jch, int tid, const unsigned (&item_mask)[NITEM]) {
+    if (c * KC + jch * 8 >= K) return;             // padded tail of the last chunk: A never read there
+    const int wbase = wl_off + (c * KC + jch * 8) * 4;
+#pragma unroll
+    for (int q = 0; q < NITEM; ++q) {
+        const int r = (tid + q * NT) >> 3;
+        if (r < MT) {                              // wave-uniform (NT and MT*8 are multiples of 64)
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            const int base = raw_off + (r + W + 1) * RAW_ROW + jch * 16;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int off = ((t / 3 - 1) * W + (t % 3 - 1)) * RAW_ROW;
+                uint4 v = *reinterpret_cast<const uint4*>(smem + base + off);
+                if (!((item_mask[q] >> t) & 1u)) v = make_uint4(0, 0, 0, 0);
+                const float4 w0 = *reinterpret_cast<const float4*>(smem + wbase + t * K * 4);
+                const float4 w1 = *reinterpret_cast<const float4*>(smem + wbase + t * K * 4 + 16);
+                float f[8];
+                unpack<bf16_t>(v, f);
+                if (RELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+                }
+                acc[0] = fmaf(w0.x, f[0], acc[0]); acc[1] = fmaf(w0.y, f[1], acc[1]);
+                acc[2] = fmaf(w0.z, f[2], acc[2]); acc[3] = fmaf(w0.w, f[3], acc[3]);
+                acc[4] = fmaf(w1.x, f[4], acc[4]); acc[5] = fmaf(w1.y, f[5], acc[5]);
+                acc[6] = fmaf(w1.z, f[6], acc[6]); acc[7] = fmaf(w1.w, f[7], acc[7]);
+            }
+            *reinterpret_cast<uint4*>(smem + a_off + r * A_STR + jch * 16) = pack<bf16_t>(acc);
+        }
+    }
+}
+
 template <bool RELU, int MF, int WN, int RN>
 __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams p) {
     constexpr int NT = 64 * WN;
     constexpr int MT = 32 * MF;
-    constexpr int NRAW = 3;                        // raw 16-byte loads per thread per chunk (max)
     constexpr int NITEM = (MT * CPR + NT - 1) / NT;
     constexpr int KBC = KC / 16;                   // k-blocks per chunk (4)
     constexpr int PF = 2;                          // B register ring depth (k-blocks ahead)
@@ -38,9 +117,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     const int tid = threadIdx.x;
     const int W = p.W, H = p.H;
     const int HP = MT + 2 * (W + 1);               // halo rows of the flattened pixel range
-    unsigned char* raw[2] = {smem, smem + (size_t)HP * RAW_ROW};
-    unsigned char* abuf[2] = {raw[1] + (size_t)HP * RAW_ROW, raw[1] + (size_t)HP * RAW_ROW + MT * A_STR};
-    float* wl = reinterpret_cast<float*>(abuf[1] + MT * A_STR);     // [9][K] depthwise taps
+    const int raw_bytes = HP * RAW_ROW;            // LDS map: raw[0] | raw[1] | A[0] | A[1] | taps
+    const int a_off0 = 2 * raw_bytes;
+    const int wl_off = a_off0 + 2 * MT * A_STR;
 
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = tile * MT;
@@ -51,20 +130,19 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in);
     const int ldi = p.ldi;
 
-    // depthwise taps -> LDS
+    // depthwise taps -> LDS as fp32 [9][K]
     for (int i = tid * 4; i < 9 * K; i += NT * 4) {
         const int t = i / K, k = i - t * K;
-        *reinterpret_cast<float4*>(wl + i) = *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + k);
+        *reinterpret_cast<float4*>(smem + wl_off + i * 4) =
+            *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + k);
     }
 
-    // ---- per-thread constants of the depthwise stage (independent of the chunk)
+    // per-thread constants of the depthwise stage (independent of the chunk)
     const int jch = tid & (CPR - 1);               // this thread's 16-byte piece (8 channels)
-    int item_row[NITEM];
     unsigned item_mask[NITEM];                     // 9 validity bits ('same' zero padding)
 #pragma unroll
     for (int q = 0; q < NITEM; ++q) {
         const int r = (tid + q * NT) >> 3;
-        item_row[q] = r;
         unsigned bits = 0;
         if (r < MT && m0 + r < p.M) {
             PixIt it;
@@ -79,74 +157,15 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
         }
         item_mask[q] = bits;
     }
-    // ---- raw staging map: piece idx = tid + q*NT -> halo row idx>>3, 16-byte piece idx&7 == jch
-    uint4 rreg[NRAW];
-    auto raw_load = [&](int c) {
-        // pieces past K (last chunk of a K that is not a multiple of 64) are neither loaded
-        // nor used
-        if (c * KC + jch * 8 < K) {
-#pragma unroll
-            for (int q = 0; q < NRAW; ++q) {
-                const int row = (tid + q * NT) >> 3;
-                const int prow = p_lo + row;
-                if (row < HP && prow >= 0 && prow < p.M)
-                    rreg[q] = *reinterpret_cast<const uint4*>(in + (size_t)prow * ldi + c * KC + jch * 8);
-            }
-        }
-    };
-    auto raw_store = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < NRAW; ++q) {
-            const int row = (tid + q * NT) >> 3;
-            const int prow = p_lo + row;
-            if (row < HP && prow >= 0 && prow < p.M)
-                *reinterpret_cast<uint4*>(raw[buf] + row * RAW_ROW + jch * 16) = rreg[q];
-        }
-    };
-    // D stage: depthwise of chunk c from raw[buf] into abuf[buf2]
-    auto depthwise = [&](int c, const unsigned char* rb, unsigned char* ab) {
-        const int kvalid = K - c * KC;             // channels of this chunk that exist
-        if (jch * 8 >= kvalid) return;             // padded tail of the last chunk: A never read there
-        const float* wc = wl + c * KC + jch * 8;
-#pragma unroll
-        for (int q = 0; q < NITEM; ++q) {
-            const int r = item_row[q];
-            if (r < MT) {                          // wave-uniform (NT and MT*8 are multiples of 64)
-                float acc[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-                const unsigned char* base = rb + (r + W + 1) * RAW_ROW + jch * 16;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int off = ((t / 3 - 1) * W + (t % 3 - 1)) * RAW_ROW;
-                    uint4 v = *reinterpret_cast<const uint4*>(base + off);
-                    if (!((item_mask[q] >> t) & 1u)) v = make_uint4(0, 0, 0, 0);
-                    const float4 w0 = *reinterpret_cast<const float4*>(wc + t * K);
-                    const float4 w1 = *reinterpret_cast<const float4*>(wc + t * K + 4);
-                    float f[8];
-                    unpack<bf16_t>(v, f);
-                    if (RELU) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
-                    }
-                    acc[0] = fmaf(w0.x, f[0], acc[0]); acc[1] = fmaf(w0.y, f[1], acc[1]);
-                    acc[2] = fmaf(w0.z, f[2], acc[2]); acc[3] = fmaf(w0.w, f[3], acc[3]);
-                    acc[4] = fmaf(w1.x, f[4], acc[4]); acc[5] = fmaf(w1.y, f[5], acc[5]);
-                    acc[6] = fmaf(w1.z, f[6], acc[6]); acc[7] = fmaf(w1.w, f[7], acc[7]);
-                }
-                *reinterpret_cast<uint4*>(ab + r * A_STR + jch * 16) = pack<bf16_t>(acc);
-            }
-        }
-    };
 
     // ---- prologue: raw(0) -> LDS, D(0), raw(1) -> LDS, raw(2) in flight
-    raw_load(0);
-    raw_store(0);
-    raw_load(1);
+    Raw3 rreg = raw_load<NT>(in, ldi, 0, K, jch, tid, p_lo, p.M);
+    raw_store<NT>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
+    rreg = raw_load<NT>(in, ldi, 1, K, jch, tid, p_lo, p.M);
     __syncthreads();                               // raw[0] and the taps are visible
-    depthwise(0, raw[0], abuf[0]);
-    raw_store(1);
-    raw_load(2);
+    depthwise<RELU, NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
+    raw_store<NT>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
+    rreg = raw_load<NT>(in, ldi, 2, K, jch, tid, p_lo, p.M);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
@@ -170,35 +189,48 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     __syncthreads();                               // A(0) and raw[1] visible
 
     for (int c = 0; c < NC; ++c) {
-        // L: raw chunk c+2 (loaded during the previous iteration) -> raw[c&1], whose last
+        const int cur = c & 1, nxt = cur ^ 1;
+        // L: raw chunk c+2 (loaded during the previous iteration) -> raw[cur], whose last
         // reader D(c) finished before the previous barrier; then start loading chunk c+3
-        if (c + 2 < NC) raw_store(c & 1);
-        raw_load(c + 3);
-        // D: depthwise of chunk c+1
-        if (c + 1 < NC) depthwise(c + 1, raw[(c + 1) & 1], abuf[(c + 1) & 1]);
-        // G: matrix cores on chunk c
-        const unsigned char* a_base = abuf[c & 1] + (size_t)r32 * A_STR + h * 16;
+        if (!(p.dbg & 16)) {
+        if (c + 2 < NC) raw_store<NT>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
+        rreg = raw_load<NT>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+        }
+        // D: depthwise of chunk c+1 (raw[nxt] -> A[nxt])
+        if (c + 1 < NC && !(p.dbg & 1))
+            depthwise<RELU, NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W,
+                                           jch, tid, item_mask);
+        // G: matrix cores on chunk c (A[cur])
+        const int a_base = a_off0 + cur * MT * A_STR + r32 * A_STR + h * 16;
 #pragma unroll
         for (int d = 0; d < KBC; ++d) {
             const int kb = c * KBC + d;
-            if (kb < KB) {
+            if (kb < KB && !(p.dbg & 2)) {
                 uint4 a[MF];
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
-                    a[i] = *reinterpret_cast<const uint4*>(a_base + (size_t)i * 32 * A_STR + d * 32);
+                    a[i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR + d * 32);
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
                     for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
                 const int nx = kb + PF;
                 const int idx = nx < KB ? nx : KB - 1;
+                if (!(p.dbg & 8)) {
 #pragma unroll
-                for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * p.KBtot + idx) * 64];
+                    for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * p.KBtot + idx) * 64];
+                }
             }
         }
         __syncthreads();
     }
-    epilogue<bf16_t, MF, RN>(p, acc, nfb, m0, r32, h);
+    // every wave is past its last LDS read (the loop's closing barrier): reuse LDS as the
+    // output staging tile
+    if (!(p.dbg & 4)) {
+        epilogue_to_lds<bf16_t, MF, RN>(p, acc, nfb, 0, m0, r32, h, smem);
+        __syncthreads();
+        lds_rows_to_global<bf16_t, NT, MT>(p, m0, tid, smem);
+    }
 }
 
 template <bool RELU>
@@ -207,7 +239,9 @@ int launch_pipe(const GemmParams& p, hipStream_t s) {
     auto kern = sepconv_pipe_kernel<RELU, MF, WN, RN>;
     const int MT = 32 * MF;
     const int HP = MT + 2 * (p.W + 1);
-    const size_t lds = (size_t)2 * HP * RAW_ROW + 2 * MT * A_STR + (size_t)9 * p.K * 4;
+    size_t lds = (size_t)2 * HP * RAW_ROW + 2 * MT * A_STR + (size_t)9 * p.K * 4;
+    const size_t stage = (size_t)MT * (p.Nstore * 2 + 16);
+    if (stage > lds) lds = stage;
     if (p.NFp != WN * RN || p.K % 16 != 0 || HP * CPR > 3 * 64 * WN || lds > 160 * 1024 || p.k_off != 0)
         return (int)hipErrorInvalidValue;
     static size_t lds_set = 0;
@@ -229,7 +263,7 @@ bool pipe_supported(int dtype, int prod, int nfp, int W, int K) {
     if (dtype != 1 || (prod != PROD_DW && prod != PROD_DW_RELU) || nfp != 24 || K % 16 != 0) return false;
     const int HP = 96 + 2 * (W + 1);
     const size_t lds = (size_t)2 * HP * RAW_ROW + 2 * 96 * A_STR + (size_t)9 * K * 4;
-    return HP * CPR <= 3 * 512 && lds <= 160 * 1024;
+    return HP * CPR <= 3 * 512 && lds <= 160 * 1024 && (size_t)96 * (768 * 2 + 16) <= 160 * 1024;
 }
 
 int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s) {
