@@ -50,32 +50,46 @@ __device__ __forceinline__ void produce(const GemmParams& p, unsigned char* smem
                     const float4 wv = *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + ch0 + j);
                     w[t][j] = wv.x; w[t][j + 1] = wv.y; w[t][j + 2] = wv.z; w[t][j + 3] = wv.w;
                 }
+            // Two items per trip: all 18 tap loads of both pixels are issued before either is
+            // consumed, doubling the bytes each wave keeps in flight (these layers are bound by
+            // L2/HBM latency, not by the ALUs).
+            constexpr int U = 2;
             PixIt it;
             it.init(m0 + tr, H, W);
-            for (int r = tr; r < MT; r += RF) {
-                if (m0 + r < p.M) {
-                    float acc[VEC];
+            for (int r = tr; r < MT; r += U * RF) {
+                uint4 v[U][9];
+                bool ok[U][9];
+                bool live[U];
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-                    uint4 v[9];
-                    bool ok[9];
+                for (int u = 0; u < U; ++u) {
+                    const int ru = r + u * RF;
+                    live[u] = ru < MT && m0 + ru < p.M;
+                    // rows past the tensor clamp to a valid pixel (loaded, never stored)
+                    const int img = live[u] ? it.img : 0, y = live[u] ? it.y : 0, x = live[u] ? it.x : 0;
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
-                        const int yy = it.y + dy - 1;
+                        const int yy = y + dy - 1;
                         const bool vy = (unsigned)yy < (unsigned)H;
                         const int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx) {
-                            const int xx = it.x + dx - 1;
-                            ok[dy * 3 + dx] = vy && ((unsigned)xx < (unsigned)W);
+                            const int xx = x + dx - 1;
+                            ok[u][dy * 3 + dx] = vy && ((unsigned)xx < (unsigned)W);
                             const int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
-                            const size_t off = ((size_t)(it.img * H + yc) * W + xc) * ldi + ch0;
-                            v[dy * 3 + dx] = *reinterpret_cast<const uint4*>(in + off);
+                            const size_t off = ((size_t)(img * H + yc) * W + xc) * ldi + ch0;
+                            v[u][dy * 3 + dx] = *reinterpret_cast<const uint4*>(in + off);
                         }
                     }
+                    it.advance(RF, H, W);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float acc[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const uint4 vv = ok[t] ? v[t] : zero4;
+                        const uint4 vv = ok[u][t] ? v[u][t] : zero4;
                         float f[VEC];
                         unpack<T>(vv, f);
 #pragma unroll
@@ -84,9 +98,9 @@ __device__ __forceinline__ void produce(const GemmParams& p, unsigned char* smem
                             acc[j] = fmaf(w[t][j], f[j], acc[j]);
                         }
                     }
-                    *reinterpret_cast<uint4*>(smem + (size_t)r * stride + c * 16) = pack<T>(acc);
+                    if (live[u])
+                        *reinterpret_cast<uint4*>(smem + (size_t)(r + u * RF) * stride + c * 16) = pack<T>(acc);
                 }
-                it.advance(RF, H, W);
             }
         } else if constexpr (PROD == PROD_S2) {
             const int H = p.H, W = p.W;  // output map

@@ -51,24 +51,39 @@ __device__ __forceinline__ Raw3 raw_load(const bf16_t* __restrict__ in, int ldi,
     return r;
 }
 
-template <int NT>
-__device__ __forceinline__ void raw_store1(const uint4& v, unsigned char* smem, int raw_off, int jch, int row,
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// ReLU on two packed bf16: as signed 16-bit integers negative floats (and -0) are negative,
+// so max(x, 0) per half is exactly ReLU -- one v_pk_max_i16 per dword.
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned x) {
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), z));
+}
+
+template <int NT, bool RELU>
+__device__ __forceinline__ void raw_store1(uint4 v, unsigned char* smem, int raw_off, int jch, int row,
                                            int p_lo, int HP, int M) {
     const int prow = p_lo + row;
+    if (RELU) { v.x = relu_bf16x2(v.x); v.y = relu_bf16x2(v.y); v.z = relu_bf16x2(v.z); v.w = relu_bf16x2(v.w); }
     if (row < HP && prow >= 0 && prow < M)
         *reinterpret_cast<uint4*>(smem + raw_off + row * RAW_ROW + jch * 16) = v;
 }
 
-template <int NT>
+template <int NT, bool RELU>
 __device__ __forceinline__ void raw_store(const Raw3& r, unsigned char* smem, int raw_off, int jch, int tid,
                                           int p_lo, int HP, int M) {
-    raw_store1<NT>(r.a, smem, raw_off, jch, tid >> 3, p_lo, HP, M);
-    raw_store1<NT>(r.b, smem, raw_off, jch, (tid + NT) >> 3, p_lo, HP, M);
-    raw_store1<NT>(r.c, smem, raw_off, jch, (tid + 2 * NT) >> 3, p_lo, HP, M);
+    raw_store1<NT, RELU>(r.a, smem, raw_off, jch, tid >> 3, p_lo, HP, M);
+    raw_store1<NT, RELU>(r.b, smem, raw_off, jch, (tid + NT) >> 3, p_lo, HP, M);
+    raw_store1<NT, RELU>(r.c, smem, raw_off, jch, (tid + 2 * NT) >> 3, p_lo, HP, M);
 }
 
-// D stage: depthwise 3x3 of chunk c, raw rows at smem+raw_off -> A chunk at smem+a_off
-template <bool RELU, int NT, int MT, int NITEM>
+// D stage: depthwise 3x3 of chunk c, raw rows at smem+raw_off -> A chunk at smem+a_off.
+// Per tap and 16-byte piece: 8 v_perm_b32 (bf16 -> f32 bits and the 'same'-padding mask in
+// one byte-permute: an out-of-image tap selects constant-zero bytes) + 4 v_pk_fma_f32 against
+// taps pre-permuted to (w0,w2,w1,w3 | w4,w6,w5,w7).  ReLU, when the layer has one in front,
+// was already applied to the raw rows as they were staged.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NT, int MT, int NITEM>
 __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, int wl_off, int c, int K,
                                           int W, int jch, int tid, const unsigned (&item_mask)[NITEM]) {
     if (c * KC + jch * 8 >= K) return;             // padded tail of the last chunk: A never read there
@@ -77,29 +92,66 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
     for (int q = 0; q < NITEM; ++q) {
         const int r = (tid + q * NT) >> 3;
         if (r < MT) {                              // wave-uniform (NT and MT*8 are multiples of 64)
-            float acc[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            f32x2 aA = {0.f, 0.f}, aB = {0.f, 0.f}, aC = {0.f, 0.f}, aD = {0.f, 0.f};
             const int base = raw_off + (r + W + 1) * RAW_ROW + jch * 16;
+            // one tap row at a time (outer loop not unrolled): keeps the live set small, the
+            // accumulators of the matrix-core stage leave few spare registers
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy) {
+                const int rowoff = base + (dy - 1) * W * RAW_ROW;
+                const int woff = wbase + dy * 3 * K * 4;
+                const unsigned mrow = item_mask[q] >> (dy * 3);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int off = ((t / 3 - 1) * W + (t % 3 - 1)) * RAW_ROW;
-                uint4 v = *reinterpret_cast<const uint4*>(smem + base + off);
-                if (!((item_mask[q] >> t) & 1u)) v = make_uint4(0, 0, 0, 0);
-                const float4 w0 = *reinterpret_cast<const float4*>(smem + wbase + t * K * 4);
-                const float4 w1 = *reinterpret_cast<const float4*>(smem + wbase + t * K * 4 + 16);
-                float f[8];
-                unpack<bf16_t>(v, f);
-                if (RELU) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+                for (int dx = 0; dx < 3; ++dx) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(smem + rowoff + (dx - 1) * RAW_ROW);
+                    const bool ok = (mrow >> dx) & 1u;
+                    const unsigned sl = ok ? 0x01000c0cu : 0x0c0c0c0cu;   // low bf16  -> f32 bits (<< 16)
+                    const unsigned sh = ok ? 0x03020c0cu : 0x0c0c0c0cu;   // high bf16 -> f32 bits (& 0xffff0000)
+                    const float4 w0 = *reinterpret_cast<const float4*>(smem + woff + dx * K * 4);
+                    const float4 w1 = *reinterpret_cast<const float4*>(smem + woff + dx * K * 4 + 16);
+                    const f32x2 lo01 = {__uint_as_float(__builtin_amdgcn_perm(0u, v.x, sl)),
+                                        __uint_as_float(__builtin_amdgcn_perm(0u, v.y, sl))};   // ch 0, 2
+                    const f32x2 hi01 = {__uint_as_float(__builtin_amdgcn_perm(0u, v.x, sh)),
+                                        __uint_as_float(__builtin_amdgcn_perm(0u, v.y, sh))};   // ch 1, 3
+                    const f32x2 lo23 = {__uint_as_float(__builtin_amdgcn_perm(0u, v.z, sl)),
+                                        __uint_as_float(__builtin_amdgcn_perm(0u, v.w, sl))};   // ch 4, 6
+                    const f32x2 hi23 = {__uint_as_float(__builtin_amdgcn_perm(0u, v.z, sh)),
+                                        __uint_as_float(__builtin_amdgcn_perm(0u, v.w, sh))};   // ch 5, 7
+                    aA = __builtin_elementwise_fma((f32x2){w0.x, w0.y}, lo01, aA);
+                    aB = __builtin_elementwise_fma((f32x2){w0.z, w0.w}, hi01, aB);
+                    aC = __builtin_elementwise_fma((f32x2){w1.x, w1.y}, lo23, aC);
+                    aD = __builtin_elementwise_fma((f32x2){w1.z, w1.w}, hi23, aD);
                 }
-                acc[0] = fmaf(w0.x, f[0], acc[0]); acc[1] = fmaf(w0.y, f[1], acc[1]);
-                acc[2] = fmaf(w0.z, f[2], acc[2]); acc[3] = fmaf(w0.w, f[3], acc[3]);
-                acc[4] = fmaf(w1.x, f[4], acc[4]); acc[5] = fmaf(w1.y, f[5], acc[5]);
-                acc[6] = fmaf(w1.z, f[6], acc[6]); acc[7] = fmaf(w1.w, f[7], acc[7]);
             }
+            const float acc[8] = {aA.x, aB.x, aA.y, aB.y, aC.x, aD.x, aC.y, aD.y};
             *reinterpret_cast<uint4*>(smem + a_off + r * A_STR + jch * 16) = pack<bf16_t>(acc);
+        }
+    }
+}
+
+// G stage: the matrix cores on one 64-channel chunk of A (KBC k-blocks), B through the ring
+template <int MF, int RN, int PF, int KBC>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
+                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot,
+                                          int dbg) {
+#pragma unroll
+    for (int d = 0; d < KBC; ++d) {
+        const int kb = c * KBC + d;
+        if (kb < KB && !(dbg & 2)) {
+            uint4 a[MF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+                a[i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR + d * 32);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
+            const int nx = kb + PF;
+            const int idx = nx < KB ? nx : KB - 1;
+            if (!(dbg & 8)) {
+#pragma unroll
+                for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * KBtot + idx) * 64];
+            }
         }
     }
 }
@@ -133,8 +185,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     // depthwise taps -> LDS as fp32 [9][K]
     for (int i = tid * 4; i < 9 * K; i += NT * 4) {
         const int t = i / K, k = i - t * K;
-        *reinterpret_cast<float4*>(smem + wl_off + i * 4) =
-            *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + k);
+        // stored as (w0,w2,w1,w3): the order the packed-FMA depthwise consumes them in
+        const float4 wv = *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + k);
+        *reinterpret_cast<float4*>(smem + wl_off + i * 4) = make_float4(wv.x, wv.z, wv.y, wv.w);
     }
 
     // per-thread constants of the depthwise stage (independent of the chunk)
@@ -160,16 +213,17 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
 
     // ---- prologue: raw(0) -> LDS, D(0), raw(1) -> LDS, raw(2) in flight
     Raw3 rreg = raw_load<NT>(in, ldi, 0, K, jch, tid, p_lo, p.M);
-    raw_store<NT>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
+    raw_store<NT, RELU>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
     rreg = raw_load<NT>(in, ldi, 1, K, jch, tid, p_lo, p.M);
     __syncthreads();                               // raw[0] and the taps are visible
-    depthwise<RELU, NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
-    raw_store<NT>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
+    depthwise<NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
+    raw_store<NT, RELU>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
     rreg = raw_load<NT>(in, ldi, 2, K, jch, tid, p_lo, p.M);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
     const int nfb = wave * RN;                     // single pass over N: NFp == WN*RN
+    const bool first_half = __builtin_amdgcn_readfirstlane(wave) < WN / 2;
     const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(p.wp);
     const uint4* bp0 = wp + ((size_t)nfb * p.KBtot + p.kb0) * 64 + lane;
     uint4 bq[PF][RN];
@@ -193,35 +247,21 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
         // L: raw chunk c+2 (loaded during the previous iteration) -> raw[cur], whose last
         // reader D(c) finished before the previous barrier; then start loading chunk c+3
         if (!(p.dbg & 16)) {
-        if (c + 2 < NC) raw_store<NT>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
+        if (c + 2 < NC) raw_store<NT, RELU>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
         rreg = raw_load<NT>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
         }
-        // D: depthwise of chunk c+1 (raw[nxt] -> A[nxt])
-        if (c + 1 < NC && !(p.dbg & 1))
-            depthwise<RELU, NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W,
-                                           jch, tid, item_mask);
-        // G: matrix cores on chunk c (A[cur])
+        // D (depthwise of chunk c+1, vector ALU) and G (matrix cores on chunk c) are independent.
+        // Each SIMD hosts one wave of each half of the workgroup: run them in opposite order so
+        // one wave's vector-ALU stage overlaps its partner's matrix-core stage.
         const int a_base = a_off0 + cur * MT * A_STR + r32 * A_STR + h * 16;
-#pragma unroll
-        for (int d = 0; d < KBC; ++d) {
-            const int kb = c * KBC + d;
-            if (kb < KB && !(p.dbg & 2)) {
-                uint4 a[MF];
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-                    a[i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR + d * 32);
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-#pragma unroll
-                    for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
-                const int nx = kb + PF;
-                const int idx = nx < KB ? nx : KB - 1;
-                if (!(p.dbg & 8)) {
-#pragma unroll
-                    for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * p.KBtot + idx) * 64];
-                }
-            }
-        }
+        const bool do_d = (c + 1 < NC) && !(p.dbg & 1);
+        if (do_d && first_half)
+            depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch, tid,
+                                     item_mask);
+        mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
+        if (do_d && !first_half)
+            depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch, tid,
+                                     item_mask);
         __syncthreads();
     }
     // every wave is past its last LDS read (the loop's closing barrier): reuse LDS as the
