@@ -44,28 +44,55 @@ PEAK_F32 = 157.3e12
 TILES_PER_SLIDE = 1000
 
 
-def cpu_baseline(weights, mc_n, seed, budget_tiles=4):
-    """The CPU oracle in the reference's loop structure (N full forward passes per batch,
-    mean / population std), on this host's cores, on a bounded sample."""
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:    # cgroup v2
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:    # cgroup v1
+            quota = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                n = max(1, min(n, int(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(weights, mc_n, seed, batch=8, budget_s=20.0):
+    """The CPU oracle in the reference's loop structure -- N complete forward passes per
+    batch, then mean / population std -- on this host's cores.  Bounded sample: whole
+    forward passes over one batch are timed until the budget is spent; tiles/s at MC=N is
+    batch * passes / (N * seconds)."""
     from biscuit_amd.synthetic import make_tiles
-    from oracle.xception_ref import XceptionOracle
-    threads = os.cpu_count() or 1
+    from oracle.xception_ref import XceptionOracle, standardize
+    threads = usable_cores()
     torch.set_num_threads(threads)
     orc = XceptionOracle(weights)
-    tiles = make_tiles(budget_tiles, seed=11)
-    orc.mc_predict(tiles[:1], 1, seed, mode='full')          # warm-up (oneDNN primitive cache)
-    t = time.time()
-    orc.mc_predict(tiles, mc_n, seed, mode='full', batch=budget_tiles)
-    dt_full = time.time() - t
-    t = time.time()
-    orc.mc_predict(tiles, mc_n, seed, mode='head', batch=budget_tiles)
-    dt_head = time.time() - t
-    return {'value': budget_tiles / dt_full, 'unit': 'tiles/s', 'cores': torch.get_num_threads(),
-            'kind': 'port',
-            'sample': f'{budget_tiles} synthetic 299x299x3 tiles x MC={mc_n} full forward passes '
-                      f'(fp32 PyTorch-CPU oracle, {dt_full:.1f} s)',
-            'head_mode_value': budget_tiles / dt_head,
-            'cpu': _cpu_name()}
+    tiles = make_tiles(batch, seed=11)
+    idx = np.arange(batch)
+    x = standardize(tiles)
+    orc.head_pass(orc.backbone(x), idx, 0, seed)              # warm-up (oneDNN primitive cache)
+    passes, t0 = 0, time.time()
+    while True:
+        orc.head_pass(orc.backbone(x), idx, passes, seed)     # one full stochastic forward pass
+        passes += 1
+        dt_full = time.time() - t0
+        if dt_full >= budget_s or passes >= mc_n:
+            break
+    full = batch * passes / (mc_n * dt_full)
+    t0 = time.time()
+    feat = orc.backbone(x)
+    for p in range(mc_n):
+        orc.head_pass(feat, idx, p, seed)
+    dt_head = time.time() - t0
+    return {'value': full, 'unit': 'tiles/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{passes} complete fp32 forward passes (PyTorch-CPU oracle, dropout on) over a batch of '
+                      f'{batch} synthetic 299x299x3 tiles in {dt_full:.1f} s, scaled to MC={mc_n} passes per tile',
+            'head_mode_value': batch / dt_head, 'cpu': _cpu_name(), 'os_cpu_count': os.cpu_count()}
 
 
 def _cpu_name():
@@ -89,7 +116,7 @@ def main():
     ap.add_argument('--mode', default='head', choices=['head', 'full'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--cpu-tiles', type=int, default=4)
+    ap.add_argument('--cpu-tiles', type=int, default=8)
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env('cuda')

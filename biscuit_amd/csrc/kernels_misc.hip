@@ -256,7 +256,11 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict
         const float zm = fmaxf(z0, z1);
         const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
         const float inv = 1.f / (e0 + e1);
-        const float p0 = e0 * inv, p1 = e1 * inv;
+        float p0 = e0 * inv, p1 = e1 * inv;
+        // Pin the rounded probabilities: if the compiler contracts e*inv into the Welford
+        // differences below (fma(e, inv, -mean)), p - mean keeps the product's rounding error
+        // instead of an exact 0 and a single pass reports std ~1e-4 instead of 0.
+        asm volatile("" : "+v"(p0), "+v"(p1));
         cnt += 1.f;
         const float d0 = p0 - mu0, d1 = p1 - mu1;
         mu0 += d0 / cnt;

@@ -1,10 +1,16 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, A/B timing, bench, rocprof.  Logs -> gpurun_out/
+# One GPU-box session: parity tests, smoke, bench, optional rocprof.  Logs -> gpurun_out/
 mkdir -p gpurun_out
-( timeout 1200 python -m pytest tests -m gpu -x -q -s 2>&1 | tail -40 ) > gpurun_out/pytest_gpu.log
-( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > gpurun_out/smoke.log
-( BQ_NO_PIPE=1 timeout 300 python tools/gpu_probe.py time --dtype bf16 --n 256 2>&1 | grep -v amdgpu.ids | head -14 ) > gpurun_out/time_nopipe.log
-( timeout 300 python tools/gpu_probe.py time --dtype bf16 --n 256 2>&1 | grep -v amdgpu.ids | head -14 ) > gpurun_out/time_pipe.log
-( timeout 900 python bench.py 2>gpurun_out/bench.err | tail -1 ) > gpurun_out/bench.json
+python - > gpurun_out/cpuinfo.log 2>&1 <<'PY'
+import os
+print('cpu_count', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))
+for f in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us', '/sys/fs/cgroup/cpu/cpu.cfs_period_us'):
+    try: print(f, open(f).read().strip())
+    except OSError as e: print(f, 'n/a')
+PY
+( timeout 1200 python -m pytest tests -m gpu -x -q -s 2>&1 | grep -v amdgpu.ids | tail -30 ) > gpurun_out/pytest_gpu.log
+grep -q "passed" gpurun_out/pytest_gpu.log && ! grep -q "failed" gpurun_out/pytest_gpu.log || { cat gpurun_out/pytest_gpu.log | cut -c1-300; echo "PYTEST FAILED - stopping"; exit 1; }
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 ) > gpurun_out/smoke.log
+( timeout 600 python bench.py 2>gpurun_out/bench.err | tail -1 ) > gpurun_out/bench.json
 if [ "$1" == "prof" ]; then bash tools/profile.sh ${2:-r01} > gpurun_out/profile.log 2>&1; fi
-tail -5 gpurun_out/pytest_gpu.log; cat gpurun_out/smoke.log; head -4 gpurun_out/time_nopipe.log; head -4 gpurun_out/time_pipe.log; cut -c1-600 gpurun_out/bench.json
+cat gpurun_out/cpuinfo.log; tail -5 gpurun_out/pytest_gpu.log; cat gpurun_out/smoke.log; cut -c1-1200 gpurun_out/bench.json; tail -2 gpurun_out/bench.err | cut -c1-300

@@ -1,0 +1,69 @@
+"""Condense rocprofv3 CSV output (tools/profile.sh) into a small markdown summary that is
+committed under profiles/.  usage: python tools/summarize_prof.py gpurun_out/prof_r01 profiles/r01_rocprof.md"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+)I(.*)EEv10GemmParams', name)
+    if m:
+        args = m.group(2).replace('DF16b', 'bf16,').replace('Li', '').replace('E', ',').replace('Lb', 'b')
+        return f'{m.group(1)}<{args.strip(",")}>'
+    return name[:90]
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    lines = [f'# rocprofv3 summary ({os.path.basename(src)})', '',
+             'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 8 '
+             '--warmup 2 --no-cpu-baseline --no-profile` (plus two separate `--pmc` passes, FETCH_SIZE and '
+             'WRITE_SIZE, which do not fit one pass on gfx950).', '']
+    stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        tot = sum(float(r['TotalDurationNs']) for r in rows)
+        lines += ['## Kernel time (--kernel-trace --stats)', '',
+                  '| kernel | calls | total ms | avg us | % |', '|---|---:|---:|---:|---:|']
+        for r in rows[:18]:
+            lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | "
+                         f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
+        lines += ['', f'Total GPU kernel time in trace: {tot/1e6:.1f} ms', '']
+    pmc = {}
+    for key in ('pmc_fetch', 'pmc_write'):
+        files = glob.glob(os.path.join(src, key, '*', '*_counter_collection.csv'))
+        if not files:
+            continue
+        acc = defaultdict(lambda: [0.0, 0, 0.0])
+        for r in csv.DictReader(open(files[0])):
+            a = acc[(r['Kernel_Name'], r['Counter_Name'])]
+            a[0] += float(r['Counter_Value'])
+            a[1] += 1
+            a[2] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+        pmc[key] = acc
+    if pmc:
+        names = defaultdict(dict)
+        for key, acc in pmc.items():
+            for (kn, cn), (v, n, dur) in acc.items():
+                names[kn][cn] = (v / n, n, dur / n)
+        lines += ['## HBM traffic per launch (--pmc FETCH_SIZE / WRITE_SIZE, separate passes)', '',
+                  'Counter units are KiB.  Corrected bytes follow MI355X_MICROARCH.md (HBM section): on gfx950 '
+                  'FETCH_SIZE tallies 128-B requests at 64 B, so wide coalesced reads are doubled; WRITE_SIZE is exact.',
+                  '', '| kernel | launches | FETCH_SIZE avg (KiB) | WRITE_SIZE avg (KiB) | corrected MB/launch | avg us (pmc pass) |',
+                  '|---|---:|---:|---:|---:|---:|']
+        order = sorted(names.items(), key=lambda kv: -sum(x[0] * x[1] for x in kv[1].values()))
+        for kn, d in order[:14]:
+            f = d.get('FETCH_SIZE', (0, 0, 0)); w = d.get('WRITE_SIZE', (0, 0, 0))
+            mb = (2 * f[0] + w[0]) * 1024 / 1e6
+            lines.append(f'| `{short(kn)}` | {f[1] or w[1]} | {f[0]:.0f} | {w[0]:.0f} | {mb:.1f} | {(f[2] or w[2])/1e3:.1f} |')
+        lines.append('')
+    open(out, 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:40]))
+
+
+if __name__ == '__main__':
+    main()
