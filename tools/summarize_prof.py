@@ -23,7 +23,11 @@ def main():
              'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 8 '
              '--warmup 2 --no-cpu-baseline --no-profile` (plus two separate `--pmc` passes, FETCH_SIZE and '
              'WRITE_SIZE, which do not fit one pass on gfx950).', '']
-    stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
+    def newest(pattern):
+        f = sorted(glob.glob(pattern), key=os.path.getmtime)
+        return f[-1:] if f else []
+
+    stats = newest(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         tot = sum(float(r['TotalDurationNs']) for r in rows)
@@ -33,9 +37,23 @@ def main():
             lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | "
                          f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
         lines += ['', f'Total GPU kernel time in trace: {tot/1e6:.1f} ms', '']
+    trace = newest(os.path.join(src, 'trace', '*', '*_kernel_trace.csv'))
+    if trace:
+        # the same kernel symbol serves several layers: split by grid size so a layer's average
+        # launch duration can be compared with bench.py's event-timed figure
+        acc = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(trace[0])):
+            k = (short(r['Kernel_Name']), int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1))
+            acc[k][0] += 1
+            acc[k][1] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+        lines += ['## Per (kernel, workgroups) average launch duration (from the kernel trace)', '',
+                  '| kernel | workgroups | launches | avg us | total ms |', '|---|---:|---:|---:|---:|']
+        for (kn, wg), (n, dur) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:16]:
+            lines.append(f'| `{kn}` | {wg} | {n} | {dur/n/1e3:.1f} | {dur/1e6:.2f} |')
+        lines.append('')
     pmc = {}
     for key in ('pmc_fetch', 'pmc_write'):
-        files = glob.glob(os.path.join(src, key, '*', '*_counter_collection.csv'))
+        files = newest(os.path.join(src, key, '*', '*_counter_collection.csv'))
         if not files:
             continue
         acc = defaultdict(lambda: [0.0, 0, 0.0])
