@@ -43,6 +43,7 @@ struct bq_ctx {
     const float* stem_w = nullptr; const float* stem_s = nullptr; const float* stem_b = nullptr;
     const float* logits_w = nullptr; const float* logits_b = nullptr;
     bool loaded = false;
+    int num_cus = 256;
     // profiling
     bool prof = false;
     std::vector<std::string> prof_names;
@@ -201,6 +202,22 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
              a.prod == PROD_S2 ? "res1x1s2" : (a.prod == PROD_IM2COL ? "conv3x3" : "sepconv"), L.cin,
              L.cout, a.H, a.W);
     ProfScope ps(c, s, cls, flops, bytes);
+    static const bool no_tile = getenv("BQ_NO_TILE") != nullptr;
+    static const int tile_mask = getenv("BQ_TILE_MASK") ? atoi(getenv("BQ_TILE_MASK")) : 7;   // kinds enabled (bit k)
+    if (!no_tile && dtype == BQ_DTYPE_BF16 && !a.residual) {
+        int kind = -1;
+        if (a.prod == PROD_IM2COL && L.cin == 32 && L.cout == 64) kind = 0;
+        else if (a.prod == PROD_DW && L.cin == 64 && L.cout == 128) kind = 1;
+        else if (a.prod == PROD_DW && L.cin == 128 && L.cout == 128) kind = 2;
+        else if (a.prod == PROD_DW_RELU && L.cin == 128 && L.cout == 256) kind = 3;
+        if (kind >= 0 && ((tile_mask >> kind) & 1)) {
+            const int e = launch_tile_conv(kind, a.in, L.wp, L.dw, L.scale, L.bias, a.out, a.n, a.H, a.W, a.Hi, a.Wi,
+                                           a.relu, c->num_cus, s);
+            if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(tile) ") + a.layer + ": " +
+                                                       hipGetErrorString((hipError_t)e));
+            return BQ_OK;
+        }
+    }
     static const bool no_pipe = getenv("BQ_NO_PIPE") != nullptr;
     static const int dbg = getenv("BQ_DBG") ? atoi(getenv("BQ_DBG")) : 0;
     p.dbg = dbg;
@@ -443,6 +460,7 @@ bq_ctx* bq_create(int device_id, const bq_config* cfg) {
     if (!c) { g_create_error = "out of host memory"; return nullptr; }
     c->cfg = *cfg;
     c->device = device_id;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return c;
 }
 

@@ -63,6 +63,9 @@ int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t
 int gemm_tile_rows(int shape);
 bool pipe_supported(int dtype, int prod, int nfp, int W, int K);
 int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s);
+int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, const float* scale,
+                     const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
+                     hipStream_t s);
 
 // ---- small kernels (kernels_misc.hip) ----------------------------------------------
 int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, double* stats_scratch,

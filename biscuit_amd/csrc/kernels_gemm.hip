@@ -102,31 +102,41 @@ __device__ __forceinline__ void produce(const GemmParams& p, unsigned char* smem
                         *reinterpret_cast<uint4*>(smem + (size_t)(r + u * RF) * stride + c * 16) = pack<T>(acc);
                 }
             }
-        } else if constexpr (PROD == PROD_S2) {
+        } else if constexpr (PROD == PROD_S2 || PROD == PROD_IM2COL) {
+            // Pure gathers (1x1/s2 sampling, 3x3 valid im2col): issue UC independent 16-byte
+            // loads per trip before the first LDS store so the wave keeps them all in flight.
+            constexpr int UC = 6;
             const int H = p.H, W = p.W;  // output map
-            PixIt it;
-            it.init(m0 + tr, H, W);
-            for (int r = tr; r < MT; r += RF) {
-                if (m0 + r < p.M) {
-                    const size_t off = ((size_t)(it.img * p.Hi + 2 * it.y) * p.Wi + 2 * it.x) * ldi + ch0;
-                    *reinterpret_cast<uint4*>(smem + (size_t)r * stride + c * 16) =
-                        *reinterpret_cast<const uint4*>(in + off);
-                }
-                it.advance(RF, H, W);
+            int dy = 0, dx = 0, cc = ch0;
+            if constexpr (PROD == PROD_IM2COL) {
+                const int tap = ch0 / ldi;
+                cc = ch0 - tap * ldi;
+                dy = tap / 3;
+                dx = tap - dy * 3;
             }
-        } else if constexpr (PROD == PROD_IM2COL) {
-            const int H = p.H, W = p.W;  // output map (valid conv: Hi = H + 2)
-            const int tap = ch0 / ldi, cc = ch0 - tap * ldi;
-            const int dy = tap / 3, dx = tap - dy * 3;
             PixIt it;
             it.init(m0 + tr, H, W);
-            for (int r = tr; r < MT; r += RF) {
-                if (m0 + r < p.M) {
-                    const size_t off = ((size_t)(it.img * p.Hi + it.y + dy) * p.Wi + it.x + dx) * ldi + cc;
-                    *reinterpret_cast<uint4*>(smem + (size_t)r * stride + c * 16) =
-                        *reinterpret_cast<const uint4*>(in + off);
+            for (int r = tr; r < MT; r += UC * RF) {
+                uint4 v[UC];
+#pragma unroll
+                for (int u = 0; u < UC; ++u) {
+                    const int ru = r + u * RF;
+                    const bool live = ru < MT && m0 + ru < p.M;
+                    const int img = live ? it.img : 0, y = live ? it.y : 0, x = live ? it.x : 0;
+                    size_t off;
+                    if constexpr (PROD == PROD_S2)
+                        off = ((size_t)(img * p.Hi + 2 * y) * p.Wi + 2 * x) * ldi + cc;
+                    else
+                        off = ((size_t)(img * p.Hi + y + dy) * p.Wi + x + dx) * ldi + cc;
+                    v[u] = *reinterpret_cast<const uint4*>(in + off);
+                    it.advance(RF, H, W);
                 }
-                it.advance(RF, H, W);
+#pragma unroll
+                for (int u = 0; u < UC; ++u) {
+                    const int ru = r + u * RF;
+                    if (ru < MT && m0 + ru < p.M)
+                        *reinterpret_cast<uint4*>(smem + (size_t)ru * stride + c * 16) = v[u];
+                }
             }
         } else {  // PROD_DROPOUT (T = float): Philox4x32-10 inverted dropout
             for (int r = tr; r < MT; r += RF) {

@@ -1,0 +1,269 @@
+// Persistent 2-D tile kernel for the big, HBM-bound entry-flow layers (block1_conv2 at 147x147,
+// the block2/block3 separable convolutions at 147x147 / 74x74), bf16.
+//
+// These layers move 1-3 GB per batch through tiny GEMMs (K, N <= 256): what matters is that
+// every input byte is fetched once, in coalesced 16-byte pieces, with enough loads in flight,
+// and that nothing but the final activations is written.  Design:
+//  * Persistent workgroups (4 waves) walk 8x16-pixel output tiles of the image grid.
+//  * The layer's weights are copied ONCE per workgroup into LDS in MFMA fragment order
+//    (16-64 KB) and stay there: no per-tile weight stream from L2.
+//  * Per tile the (8+2)x(16+2) input halo is loaded with all of a thread's 16-byte loads in
+//    flight at once, zero-filled outside the image ('same' padding for free), and the loads of
+//    tile t+1 are issued before tile t is computed (register prefetch across the tile loop).
+//  * No A tile: the MFMA operand layout D[cout][pixel] = W[cout][k] * Act[k][pixel] wants, per
+//    lane, 8 consecutive k of ONE pixel -- exactly one depthwise result (8 channels of a
+//    pixel) or, for the 3x3 stem conv, 16 bytes of a shifted halo pixel.  Each wave owns two
+//    tile rows (32 pixels = one 32x32 fragment) and feeds its depthwise results straight into
+//    its MFMAs: no LDS round trip, no barrier between the vector-ALU and matrix stages.
+//  * Epilogue: folded BN + ReLU in registers, tile parked in LDS (aliasing the dead halo),
+//    streamed out as 16 x Cout x 2 B contiguous row segments.
+#include "gemm_common.h"
+
+#include <stdlib.h>
+
+namespace {
+using namespace bqk;
+
+constexpr int TH = 8, TW = 16, RH = TH + 2, RW = TW + 2, RPIX = RH * RW;   // 180 halo pixels
+enum { MODE_CONV3 = 0, MODE_SEP = 1 };
+
+typedef float f32x2t __attribute__((ext_vector_type(2)));
+typedef short s16x2t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned relu2(unsigned x) {   // ReLU on two packed bf16 (v_pk_max_i16)
+    const s16x2t z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2t, x), z));
+}
+
+struct TileParams {
+    const bf16_t* in;      // NHWC [n][Hi][Wi][CIN]
+    const uint4* wp;       // fragment-packed weights [NF][KB][64] x 16 B
+    const float* dw;       // [9][CIN] fp32 (MODE_SEP)
+    const float* scale;    // [NF*32]
+    const float* bias;
+    bf16_t* out;           // NHWC [n][H][W][NF*32]
+    int n, H, W, Hi, Wi;   // output / input maps
+    int tyn, txn;          // tiles per image
+    int relu;
+};
+
+template <int MODE, int CIN, int NF, bool RELU_IN>
+__global__ void __launch_bounds__(256) tile_conv_kernel(const TileParams p) {
+    constexpr int NT = 256;
+    constexpr int CC = CIN < 64 ? CIN : 64;            // channels staged per pass (<= 64)
+    constexpr int NPASS = CIN / CC;
+    constexpr int PPP = CC / 8;                        // 16-byte pieces per halo pixel and pass
+    constexpr int PS = CC * 2 + 16;                    // halo pixel stride in LDS (odd # of 16-B slots)
+    constexpr int KB = (MODE == MODE_CONV3 ? 9 * CIN : CIN) / 16;
+    constexpr int KBP = KB / NPASS;                    // k-blocks per pass
+    constexpr int NLOAD = (RPIX * PPP + NT - 1) / NT;  // raw 16-byte loads per thread and pass
+    constexpr int N = NF * 32;
+    constexpr int SST = N * 2 + 16;                    // staging row stride
+    constexpr int W_BYTES = NF * KB * 1024;
+    constexpr int TAP_BYTES = MODE == MODE_SEP ? 9 * CIN * 4 : 0;
+    constexpr int BUF_OFF = W_BYTES + TAP_BYTES;       // raw halo / output staging share this region
+    static_assert(MODE == MODE_SEP || NPASS == 1, "the 3x3 conv stages all its channels at once");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, h = lane >> 5;
+
+    // ---- one-time: weights (fragment order) and depthwise taps -> LDS
+    for (int i = tid; i < W_BYTES / 16; i += NT)
+        *reinterpret_cast<uint4*>(smem + i * 16) = p.wp[i];
+    if (MODE == MODE_SEP) {
+        for (int i = tid * 4; i < 9 * CIN; i += NT * 4) {
+            const float4 wv = *reinterpret_cast<const float4*>(p.dw + i);
+            // (w0,w2,w1,w3): the order the packed-FMA depthwise consumes them in
+            *reinterpret_cast<float4*>(smem + W_BYTES + i * 4) = make_float4(wv.x, wv.z, wv.y, wv.w);
+        }
+    }
+
+    const int tiles_per_img = p.tyn * p.txn;
+    const int ntiles = p.n * tiles_per_img;
+    const int org = MODE == MODE_SEP ? -1 : 0;         // halo origin relative to the tile origin
+
+    // tile-independent part of this thread's halo pieces: (ry, rx) and the element offset
+    int rel[NLOAD], ryx[NLOAD];
+#pragma unroll
+    for (int q = 0; q < NLOAD; ++q) {
+        const int idx = tid + q * NT;
+        const int pix = idx / PPP, j = idx - pix * PPP;
+        const int ry = pix / RW, rx = pix - ry * RW;
+        rel[q] = (ry * p.Wi + rx) * CIN + j * 8;
+        ryx[q] = pix < RPIX ? ((ry << 8) | rx) : -1;
+    }
+    uint4 rreg[NLOAD];
+    // issue the halo loads of (tile, pass) into registers; zeros outside the image
+    auto load_pass = [&](int tile, int pass) {
+        const int img = tile / tiles_per_img;
+        const int trem = tile - img * tiles_per_img;
+        const int ty = trem / p.txn, tx = trem - ty * p.txn;
+        const int gy0 = ty * TH + org, gx0 = tx * TW + org;
+        const long long base = ((long long)(img * p.Hi + gy0) * p.Wi + gx0) * CIN + pass * CC;
+#pragma unroll
+        for (int q = 0; q < NLOAD; ++q) {
+            const int gy = gy0 + (ryx[q] >> 8), gx = gx0 + (ryx[q] & 255);
+            const bool ok = ryx[q] >= 0 && (unsigned)gy < (unsigned)p.Hi && (unsigned)gx < (unsigned)p.Wi;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) v = *reinterpret_cast<const uint4*>(p.in + base + rel[q]);
+            if (RELU_IN) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }
+            rreg[q] = v;
+        }
+    };
+    auto store_pass = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLOAD; ++q) {
+            const int idx = tid + q * NT;
+            const int pix = idx / PPP, j = idx - pix * PPP;
+            if (ryx[q] >= 0) *reinterpret_cast<uint4*>(smem + BUF_OFF + pix * PS + j * 16) = rreg[q];
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_pass(tile, 0);
+    // this wave's pixels: tile rows 2*wave and 2*wave+1, lane&31 -> (row, column)
+    const int py = 2 * wave + (r32 >> 4), px = r32 & 15;
+    const int raw_lane = BUF_OFF + (py * RW + px) * PS;        // halo pixel of tap (0,0)
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        f32x16 acc[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+            __syncthreads();             // previous readers of the halo / staging region are done
+            store_pass();
+            __syncthreads();             // halo (and, first time, weights/taps) visible
+            // next halo in flight while this one is computed
+            if (pass + 1 < NPASS) load_pass(tile, pass + 1);
+            else if (tile + (int)gridDim.x < ntiles) load_pass(tile + gridDim.x, 0);
+
+#pragma unroll 2
+            for (int kl = 0; kl < KBP; ++kl) {
+                const int kb = pass * KBP + kl;
+                uint4 opnd;
+                if constexpr (MODE == MODE_CONV3) {
+                    // k = tap*CIN + channel: this k-block is 16 channels of one tap
+                    const int tap = (kb * 16) / CIN, c0 = (kb * 16) % CIN;
+                    const int dy = tap / 3, dx = tap - dy * 3;
+                    opnd = *reinterpret_cast<const uint4*>(smem + raw_lane + (dy * RW + dx) * PS + (c0 + h * 8) * 2);
+                } else {
+                    // depthwise 3x3 of 8 channels (piece 2*kl + h of this pass) of this lane's pixel
+                    const int wbase = W_BYTES + (2 * kb + h) * 32;
+                    const int rbase = raw_lane + (2 * kl + h) * 16;
+                    f32x2t aA = {0.f, 0.f}, aB = {0.f, 0.f}, aC = {0.f, 0.f}, aD = {0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(smem + rbase + ((t / 3) * RW + (t % 3)) * PS);
+                        const float4 w0 = *reinterpret_cast<const float4*>(smem + wbase + t * CIN * 4);
+                        const float4 w1 = *reinterpret_cast<const float4*>(smem + wbase + t * CIN * 4 + 16);
+                        const f32x2t lo01 = {__uint_as_float(v.x << 16), __uint_as_float(v.y << 16)};
+                        const f32x2t hi01 = {__uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y & 0xffff0000u)};
+                        const f32x2t lo23 = {__uint_as_float(v.z << 16), __uint_as_float(v.w << 16)};
+                        const f32x2t hi23 = {__uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w & 0xffff0000u)};
+                        aA = __builtin_elementwise_fma((f32x2t){w0.x, w0.y}, lo01, aA);
+                        aB = __builtin_elementwise_fma((f32x2t){w0.z, w0.w}, hi01, aB);
+                        aC = __builtin_elementwise_fma((f32x2t){w1.x, w1.y}, lo23, aC);
+                        aD = __builtin_elementwise_fma((f32x2t){w1.z, w1.w}, hi23, aD);
+                    }
+                    const float a8[8] = {aA.x, aB.x, aA.y, aB.y, aC.x, aD.x, aC.y, aD.y};
+                    opnd = pack<bf16_t>(a8);
+                }
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((j * KB + kb) * 64 + lane) * 16);
+                    mma<bf16_t>(acc[j], wf, opnd);
+                }
+            }
+        }
+
+        // ---- epilogue: BN + ReLU in registers -> LDS staging (aliases the halo) -> row segments
+        __syncthreads();                 // every wave is done reading the halo
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n0 = j * 32 + g * 8 + h * 4;
+                const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+                const float4 bi = *reinterpret_cast<const float4*>(p.bias + n0);
+                float v[4] = {fmaf(acc[j][g * 4 + 0], sc.x, bi.x), fmaf(acc[j][g * 4 + 1], sc.y, bi.y),
+                              fmaf(acc[j][g * 4 + 2], sc.z, bi.z), fmaf(acc[j][g * 4 + 3], sc.w, bi.w)};
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                store4<bf16_t>(reinterpret_cast<bf16_t*>(smem + BUF_OFF + (wave * 32 + r32) * SST) + n0, v);
+            }
+        __syncthreads();
+        {
+            const int img = tile / tiles_per_img;
+            const int trem = tile - img * tiles_per_img;
+            const int ty = trem / p.txn, tx = trem - ty * p.txn;
+            constexpr int PPR = N * 2 / 16;            // 16-byte pieces per output pixel
+            for (int idx = tid; idx < TH * TW * PPR; idx += NT) {
+                const int pix = idx / PPR, pc = idx - pix * PPR;
+                const int oy = ty * TH + (pix >> 4), ox = tx * TW + (pix & 15);
+                if (oy < p.H && ox < p.W)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) +
+                                              (((size_t)(img * p.H + oy) * p.W + ox) * N) * 2 + pc * 16) =
+                        *reinterpret_cast<const uint4*>(smem + BUF_OFF + pix * SST + pc * 16);
+            }
+        }
+    }
+}
+
+template <int MODE, int CIN, int NF, bool RELU_IN>
+int launch_tile(const TileParams& p, int num_cus, hipStream_t s) {
+    constexpr int KB = (MODE == MODE_CONV3 ? 9 * CIN : CIN) / 16;
+    constexpr size_t W_BYTES = (size_t)NF * KB * 1024;
+    constexpr size_t TAP_BYTES = MODE == MODE_SEP ? 9 * CIN * 4 : 0;
+    constexpr size_t RAW_BYTES = (size_t)RPIX * ((CIN < 64 ? CIN : 64) * 2 + 16);
+    constexpr size_t STAGE_BYTES = (size_t)TH * TW * (NF * 64 + 16);
+    constexpr size_t lds = W_BYTES + TAP_BYTES + (RAW_BYTES > STAGE_BYTES ? RAW_BYTES : STAGE_BYTES);
+    static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
+    auto kern = tile_conv_kernel<MODE, CIN, NF, RELU_IN>;
+    static bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        set = true;
+    }
+    const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+    static const int env_wgs = getenv("BQ_TILE_WGS") ? atoi(getenv("BQ_TILE_WGS")) : 0;
+    int wgs = per_cu > 2 ? 2 : per_cu;         // measured: 2 persistent workgroups per CU beat 1 and 3
+    if (env_wgs > 0 && env_wgs < wgs) wgs = env_wgs;
+    const int ntiles = p.n * p.tyn * p.txn;
+    int grid = num_cus * wgs;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// kind: 0 = 3x3 valid conv 32->64 (block1_conv2); 1 = sepconv 64->128; 2 = sepconv 128->128;
+// 3 = sepconv 128->256 with ReLU on the input.  Returns <0 if the combination is not built.
+int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, const float* scale,
+                     const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
+                     hipStream_t s) {
+    TileParams p;
+    p.in = reinterpret_cast<const bf16_t*>(in);
+    p.wp = reinterpret_cast<const uint4*>(wp);
+    p.dw = dw; p.scale = scale; p.bias = bias;
+    p.out = reinterpret_cast<bf16_t*>(out);
+    p.n = n; p.H = H; p.W = W; p.Hi = Hi; p.Wi = Wi;
+    p.tyn = (H + TH - 1) / TH; p.txn = (W + TW - 1) / TW;
+    p.relu = relu;
+    switch (kind) {
+        case 0: return launch_tile<MODE_CONV3, 32, 2, false>(p, num_cus, s);
+        case 1: return launch_tile<MODE_SEP, 64, 4, false>(p, num_cus, s);
+        case 2: return launch_tile<MODE_SEP, 128, 4, false>(p, num_cus, s);
+        case 3: return launch_tile<MODE_SEP, 128, 8, true>(p, num_cus, s);
+    }
+    return -1;
+}
