@@ -164,6 +164,7 @@ struct ConvArgs {
     int n, H, W, Hi, Wi;   // output / input spatial dims
     int ldi, ldo;          // row strides (elements)
     int relu;
+    void* dwtmp = nullptr; // scratch for the two-kernel (depthwise + GEMM) form, >= n*H*W*ldi elements
 };
 
 int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
@@ -201,7 +202,9 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     snprintf(cls, sizeof cls, "%s_k%d_n%d_%dx%d",
              a.prod == PROD_S2 ? "res1x1s2" : (a.prod == PROD_IM2COL ? "conv3x3" : "sepconv"), L.cin,
              L.cout, a.H, a.W);
-    ProfScope ps(c, s, cls, flops, bytes);
+    static const bool split_env = getenv("BQ_SPLIT") != nullptr;
+    const bool will_split = split_env && dtype == BQ_DTYPE_BF16 && dwp && L.nfp % 4 == 0 && a.dwtmp && nsplit == 1;
+    ProfScope ps(c, s, will_split ? std::string("split_") + cls : std::string(cls), will_split ? 0.0 : flops, will_split ? 0.0 : bytes);
     static const bool no_tile = getenv("BQ_NO_TILE") != nullptr;
     static const int tile_mask = getenv("BQ_TILE_MASK") ? atoi(getenv("BQ_TILE_MASK")) : 7;   // kinds enabled (bit k)
     if (!no_tile && dtype == BQ_DTYPE_BF16 && !a.residual) {
@@ -217,6 +220,22 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
                                                        hipGetErrorString((hipError_t)e));
             return BQ_OK;
         }
+    }
+    static const bool split = getenv("BQ_SPLIT") != nullptr;
+    if (split && dtype == BQ_DTYPE_BF16 && dwp && L.nfp % 4 == 0 && a.dwtmp && nsplit == 1) {
+        {
+            ProfScope pd(c, s, std::string("dw3x3_") + cls, 18.0 * M * L.cin, 2.0 * es * M * L.cin);
+            const int e = launch_dw3x3(a.in, L.dw, a.dwtmp, a.n, a.H, a.W, a.ldi, a.prod == PROD_DW_RELU, s);
+            if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(dw3x3) ") + a.layer);
+        }
+        ProfScope pg(c, s, std::string("gemm_") + cls, 2.0 * M * L.cin * L.cout,
+                     es * (M * L.cin + M * L.cout * (a.residual ? 2.0 : 1.0)));
+        p.in = a.dwtmp; p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
+        p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
+        const int e = launch_gemm_tile(p, s);
+        if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(gemm_tile) ") + a.layer + ": " +
+                                                   hipGetErrorString((hipError_t)e));
+        return BQ_OK;
     }
     static const bool no_pipe = getenv("BQ_NO_PIPE") != nullptr;
     static const int dbg = getenv("BQ_DBG") ? atoi(getenv("BQ_DBG")) : 0;
@@ -324,11 +343,11 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     for (int block = 5; block <= 12; ++block) {
         char nm[64];
         snprintf(nm, sizeof nm, "block%d_sepconv1", block);
-        RUN(run_conv(c, {nm, PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1}, s));
+        RUN(run_conv(c, {nm, PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1, R}, s));
         snprintf(nm, sizeof nm, "block%d_sepconv2", block);
-        RUN(run_conv(c, {nm, PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1}, s));
+        RUN(run_conv(c, {nm, PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1, R}, s));
         snprintf(nm, sizeof nm, "block%d_sepconv3", block);
-        RUN(run_conv(c, {nm, PROD_DW, C, Y, X, nullptr, n, 19, 19, 19, 19, 736, 736, 0}, s));
+        RUN(run_conv(c, {nm, PROD_DW, C, Y, X, nullptr, n, 19, 19, 19, 19, 736, 736, 0, R}, s));
         void* t = X; X = Y; Y = t;
         snprintf(nm, sizeof nm, "block%d_out", block);
         TAP(nm, X, 19, 19, 728, 736);
