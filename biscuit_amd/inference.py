@@ -36,6 +36,21 @@ class Slide:
         return t
 
 
+def slides_from_tfrecords(paths, labels, patients=None, tile_px=299):
+    """One ``Slide`` per ``*.tfrecords`` file (Slideflow writes one file per slide).  Tiles are
+    decoded lazily when the slide's turn comes; only the record headers are scanned up front.
+    labels: {slide name (file stem): 0/1}."""
+    import os
+    from . import tfrecord
+    out = []
+    for path in paths:
+        name = os.path.splitext(os.path.basename(path))[0]
+        loader = (lambda pth=path: tfrecord.read_slide(pth, tile_px)[1])
+        out.append(Slide(name, loader, tfrecord.count_records(path), y_true=int(labels.get(name, 0)),
+                         patient=(patients or {}).get(name)))
+    return out
+
+
 @dataclass
 class EvalResult:
     tile_df: Optional[pd.DataFrame]          # this rank's tile rows (Slideflow headers)

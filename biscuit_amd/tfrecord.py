@@ -141,6 +141,20 @@ def read_records(path, verify='length'):
             yield data
 
 
+def count_records(path):
+    """Number of records (tiles) in a TFRecord file, reading only the 12-byte headers."""
+    n = 0
+    with open(path, 'rb') as f:
+        while True:
+            head = f.read(12)
+            if not head:
+                return n
+            if len(head) < 12:
+                raise IOError(f'{path}: truncated record header')
+            f.seek(struct.unpack('<Q', head[:8])[0] + 4, 1)
+            n += 1
+
+
 def decode_image(raw, tile_px=299):
     from PIL import Image
     img = np.asarray(Image.open(io.BytesIO(raw)).convert('RGB'))

@@ -64,3 +64,20 @@ def test_corruption_is_detected(tmp_path):
     T.write_slide(wrong, 'w', np.zeros((1, 64, 64, 3), np.uint8))
     with pytest.raises(ValueError):
         T.read_slide(wrong)
+
+
+def test_evaluate_from_tfrecords(tmp_path):
+    """The inference driver over TFRecord slides (device engine replaced by the CPU stand-in)."""
+    from biscuit_amd.inference import evaluate, slides_from_tfrecords
+    from tests.test_distributed import StandInEngine
+    paths = []
+    for i, n in enumerate((3, 0, 2)):
+        p = str(tmp_path / f'slide{i}.tfrecords')
+        T.write_slide(p, f'slide{i}', make_tiles(n, seed=20 + i)) if n else open(p, 'wb').close()
+        paths.append(p)
+    assert [T.count_records(p) for p in paths] == [3, 0, 2]
+    slides = slides_from_tfrecords(paths, {'slide0': 1, 'slide2': 0})
+    res = evaluate(StandInEngine(), slides, outcome='cohort', mc_n=30, seed=1, batch=4)
+    assert list(res.slide_count) == [3, 0, 2] and len(res.tile_df) == 5
+    assert list(res.tile_df['slide']) == ['slide0'] * 3 + ['slide2'] * 2
+    assert list(res.tile_df['cohort-y_true0']) == [1, 1, 1, 0, 0]
