@@ -28,7 +28,7 @@ constexpr int A_STR = KC * 2 + 16; // 144 B: odd number of 16-byte slots -> conf
 // LDS address space (ds_* instructions); pointer arrays / lambdas capturing pointers decay
 // to flat addressing and scratch.
 // Raw staging registers as three named values (an array here ends up in scratch).
-struct Raw3 { uint4 a, b, c; };
+struct Raw3 { uint4 a, b, c, d, e; };   // up to 5 staging slots (NRAW of them used)
 
 template <int NT>
 __device__ __forceinline__ uint4 raw_load1(const bf16_t* __restrict__ in, int ldi, int coff, int row, int p_lo, int M) {
@@ -37,7 +37,7 @@ __device__ __forceinline__ uint4 raw_load1(const bf16_t* __restrict__ in, int ld
     return *reinterpret_cast<const uint4*>(in + (size_t)prow * ldi + coff);
 }
 
-template <int NT>
+template <int NT, int NRAW>
 __device__ __forceinline__ Raw3 raw_load(const bf16_t* __restrict__ in, int ldi, int c, int K, int jch, int tid,
                                          int p_lo, int M) {
     // Branch-free (clamped) so the loads stay in flight: rows outside the tensor and pieces
@@ -48,6 +48,8 @@ __device__ __forceinline__ Raw3 raw_load(const bf16_t* __restrict__ in, int ldi,
     r.a = raw_load1<NT>(in, ldi, coff, tid >> 3, p_lo, M);
     r.b = raw_load1<NT>(in, ldi, coff, (tid + NT) >> 3, p_lo, M);
     r.c = raw_load1<NT>(in, ldi, coff, (tid + 2 * NT) >> 3, p_lo, M);
+    if constexpr (NRAW > 3) r.d = raw_load1<NT>(in, ldi, coff, (tid + 3 * NT) >> 3, p_lo, M);
+    if constexpr (NRAW > 4) r.e = raw_load1<NT>(in, ldi, coff, (tid + 4 * NT) >> 3, p_lo, M);
     return r;
 }
 
@@ -68,12 +70,14 @@ __device__ __forceinline__ void raw_store1(uint4 v, unsigned char* smem, int raw
         *reinterpret_cast<uint4*>(smem + raw_off + row * RAW_ROW + jch * 16) = v;
 }
 
-template <int NT, bool RELU>
+template <int NT, bool RELU, int NRAW>
 __device__ __forceinline__ void raw_store(const Raw3& r, unsigned char* smem, int raw_off, int jch, int tid,
                                           int p_lo, int HP, int M) {
     raw_store1<NT, RELU>(r.a, smem, raw_off, jch, tid >> 3, p_lo, HP, M);
     raw_store1<NT, RELU>(r.b, smem, raw_off, jch, (tid + NT) >> 3, p_lo, HP, M);
     raw_store1<NT, RELU>(r.c, smem, raw_off, jch, (tid + 2 * NT) >> 3, p_lo, HP, M);
+    if constexpr (NRAW > 3) raw_store1<NT, RELU>(r.d, smem, raw_off, jch, (tid + 3 * NT) >> 3, p_lo, HP, M);
+    if constexpr (NRAW > 4) raw_store1<NT, RELU>(r.e, smem, raw_off, jch, (tid + 4 * NT) >> 3, p_lo, HP, M);
 }
 
 // D stage: depthwise 3x3 of chunk c, raw rows at smem+raw_off -> A chunk at smem+a_off.
@@ -156,7 +160,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF]
     }
 }
 
-template <bool RELU, int MF, int WN, int RN>
+template <bool RELU, int MF, int WN, int RN, int NRAW>
 __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams p) {
     constexpr int NT = 64 * WN;
     constexpr int MT = 32 * MF;
@@ -212,13 +216,13 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     }
 
     // ---- prologue: raw(0) -> LDS, D(0), raw(1) -> LDS, raw(2) in flight
-    Raw3 rreg = raw_load<NT>(in, ldi, 0, K, jch, tid, p_lo, p.M);
-    raw_store<NT, RELU>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
-    rreg = raw_load<NT>(in, ldi, 1, K, jch, tid, p_lo, p.M);
+    Raw3 rreg = raw_load<NT, NRAW>(in, ldi, 0, K, jch, tid, p_lo, p.M);
+    raw_store<NT, RELU, NRAW>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
+    rreg = raw_load<NT, NRAW>(in, ldi, 1, K, jch, tid, p_lo, p.M);
     __syncthreads();                               // raw[0] and the taps are visible
     depthwise<NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
-    raw_store<NT, RELU>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
-    rreg = raw_load<NT>(in, ldi, 2, K, jch, tid, p_lo, p.M);
+    raw_store<NT, RELU, NRAW>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
+    rreg = raw_load<NT, NRAW>(in, ldi, 2, K, jch, tid, p_lo, p.M);
 
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
@@ -247,8 +251,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
         // L: raw chunk c+2 (loaded during the previous iteration) -> raw[cur], whose last
         // reader D(c) finished before the previous barrier; then start loading chunk c+3
         if (!(p.dbg & 16)) {
-        if (c + 2 < NC) raw_store<NT, RELU>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
-        rreg = raw_load<NT>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+        if (c + 2 < NC) raw_store<NT, RELU, NRAW>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
+        rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
         }
         // D (depthwise of chunk c+1, vector ALU) and G (matrix cores on chunk c) are independent.
         // Each SIMD hosts one wave of each half of the workgroup: run them in opposite order so
@@ -273,16 +277,16 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     }
 }
 
-template <bool RELU>
+template <bool RELU, int RN, int NRAW>
 int launch_pipe(const GemmParams& p, hipStream_t s) {
-    constexpr int MF = 3, WN = 8, RN = 3;
-    auto kern = sepconv_pipe_kernel<RELU, MF, WN, RN>;
+    constexpr int MF = 3, WN = 8;
+    auto kern = sepconv_pipe_kernel<RELU, MF, WN, RN, NRAW>;
     const int MT = 32 * MF;
     const int HP = MT + 2 * (p.W + 1);
     size_t lds = (size_t)2 * HP * RAW_ROW + 2 * MT * A_STR + (size_t)9 * p.K * 4;
     const size_t stage = (size_t)MT * (p.Nstore * 2 + 16);
     if (stage > lds) lds = stage;
-    if (p.NFp != WN * RN || p.K % 16 != 0 || HP * CPR > 3 * 64 * WN || lds > 160 * 1024 || p.k_off != 0)
+    if (p.NFp != WN * RN || p.K % 16 != 0 || HP * CPR > NRAW * 64 * WN || lds > 160 * 1024 || p.k_off != 0)
         return (int)hipErrorInvalidValue;
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -298,14 +302,25 @@ int launch_pipe(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-// bf16 SeparableConv2D with NFp == 24 (728-wide outputs) on maps up to 37x37.
+// bf16 SeparableConv2D whose (padded) output width is 768 (three fragments per wave, maps up to
+// 37x37) or 256 (one fragment per wave, maps up to 74x74).
+static int pipe_variant(int nfp, int W) {
+    const int HP = 96 + 2 * (W + 1);
+    if (nfp == 24 && HP * CPR <= 3 * 512) return 0;
+    if (nfp == 8 && HP * CPR <= 4 * 512) return 1;
+    return -1;
+}
+
 bool pipe_supported(int dtype, int prod, int nfp, int W, int K) {
-    if (dtype != 1 || (prod != PROD_DW && prod != PROD_DW_RELU) || nfp != 24 || K % 16 != 0) return false;
+    if (dtype != 1 || (prod != PROD_DW && prod != PROD_DW_RELU) || K % 16 != 0) return false;
+    if (pipe_variant(nfp, W) < 0) return false;
     const int HP = 96 + 2 * (W + 1);
     const size_t lds = (size_t)2 * HP * RAW_ROW + 2 * 96 * A_STR + (size_t)9 * K * 4;
-    return HP * CPR <= 3 * 512 && lds <= 160 * 1024 && (size_t)96 * (768 * 2 + 16) <= 160 * 1024;
+    return lds <= 160 * 1024 && (size_t)96 * (nfp * 64 + 16) <= 160 * 1024;
 }
 
 int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s) {
-    return prod == PROD_DW_RELU ? launch_pipe<true>(p, s) : launch_pipe<false>(p, s);
+    const bool relu = prod == PROD_DW_RELU;
+    if (pipe_variant(p.NFp, p.W) == 0) return relu ? launch_pipe<true, 3, 3>(p, s) : launch_pipe<false, 3, 3>(p, s);
+    return relu ? launch_pipe<true, 1, 4>(p, s) : launch_pipe<false, 1, 4>(p, s);
 }

@@ -151,6 +151,16 @@ def test_full_mode_batching_and_determinism_bit_exact(engines, tiles, dtype):
     assert not torch.equal(m_o, m_h)                             # the seed matters
 
 
+@pytest.mark.parametrize('n', [1, 5])
+def test_ragged_batch_sizes(engines, oracles, n):
+    """Batches that do not fill a pixel tile / a row fragment (n = 1: 361 pixels at 19x19) and odd n."""
+    t = make_tiles(n, seed=77)
+    rm, rs = oracles['f32'].mc_predict(t, 3, 5, mode='head')
+    for dtype, tol in (('f32', 1e-4), ('bf16', 1e-3)):
+        m, s = engines[dtype].mc_infer(dev(t), 3, 5)
+        assert np.abs(m.cpu().numpy() - rm).max() < tol and np.abs(s.cpu().numpy() - rs).max() < tol
+
+
 def test_golden_config1(engines):
     """BASELINE.json config 1: 16 slides x 64 tiles, MC=5, against the committed fixture."""
     g = np.load(os.path.join(GOLDEN, 'producer_cfg1.npz'))
