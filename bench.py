@@ -232,8 +232,15 @@ def main():
             peak = PEAK_HBM / 1e9
             ach = dom.bytes / avg_s / 1e9
             unit = 'GB/s'
+        traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+            if args.dtype == 'bf16' and B == 256 and dom.name in tj:
+                traffic = tj[dom.name]['corrected_bytes_per_launch']
+        except (OSError, ValueError, KeyError):
+            pass
         out['roofline'] = {'kernel': dom.name, 'bound': bound, 'achieved': ach, 'peak': peak, 'unit': unit,
-                           'frac': ach / peak, 'traffic': None,
+                           'frac': ach / peak, 'traffic': traffic,
                            'launches_per_step': dom.launches / psteps, 'avg_launch_ms': dom.ms / dom.launches,
                            'share_of_step': dom.ms / tot,
                            'algorithmic_flops_per_launch': dom.flops, 'algorithmic_bytes_per_launch': dom.bytes}
