@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from biscuit_amd import distributed as D      # noqa: E402
-from biscuit_amd.engine import Engine         # noqa: E402
+from biscuit_amd.engine import EnginePool     # noqa: E402
 from biscuit_amd.weights import synthetic_weights  # noqa: E402
 
 # Algorithmic work per tile (derivation SURVEY.md section 8d)
@@ -117,6 +117,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--cpu-tiles', type=int, default=8)
+    ap.add_argument('--streams', type=int, default=2, help='HIP streams (independent contexts) batches alternate over')
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env('cuda')
@@ -124,9 +125,14 @@ def main():
         print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using {world}', file=sys.stderr)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    # collectives run on the GPU (RCCL) unless a CPU backend was forced for single-GPU testing
+    coll_dev = dev if (world == 1 or dist.get_backend() == 'nccl') else torch.device('cpu')
 
     weights = synthetic_weights(1)
-    eng = Engine(weights, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local)
+    pool_e = EnginePool(weights, n_streams=args.streams, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc,
+                        device=local)
+    eng = pool_e.engines[0]
+    NS = len(pool_e)
     B, K, Wm = args.batch, args.steps, args.warmup
     seed = 1234
 
@@ -137,18 +143,28 @@ def main():
     n_slides_local = (K * B + TILES_PER_SLIDE - 1) // TILES_PER_SLIDE + 1
     slide_of = [torch.div(torch.arange(s * B, (s + 1) * B, device=dev), TILES_PER_SLIDE,
                           rounding_mode='floor').to(torch.int32) for s in range(max(K, Wm))]
-    mean = torch.empty((B, 2), dtype=torch.float32, device=dev)
-    std = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    mean = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NS)]
+    std = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NS)]
     tile_base = rank * K * B                      # global tile index of this rank's shard
 
     def zero_acc():
-        return (torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
-                torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
-                torch.zeros(n_slides_local, dtype=torch.int32, device=dev))
+        # one fixed-point accumulator triple per stream; integer sums add exactly at the end
+        return [(torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
+                 torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
+                 torch.zeros(n_slides_local, dtype=torch.int32, device=dev)) for _ in range(NS)]
 
     def step(i, acc, mode):
-        eng.mc_infer(pool[i % 4], args.mc, seed, tile_idx0=tile_base + i * B, mc_mode=mode, out=(mean, std))
-        eng.slide_reduce(mean, std, slide_of[i], n_slides_local, acc=acc)
+        k = i % NS
+
+        def work(e):
+            e.mc_infer(pool[i % 4], args.mc, seed, tile_idx0=tile_base + i * B, mc_mode=mode, out=(mean[k], std[k]))
+            e.slide_reduce(mean[k], std[k], slide_of[i], n_slides_local, acc=acc[k])
+        pool_e.run(i, work)
+
+    def finish(acc):
+        torch.cuda.synchronize()
+        tot = tuple(sum(a[j] for a in acc[1:]) + acc[0][j] if NS > 1 else acc[0][j] for j in range(3))
+        return eng.slide_finish(tot)
 
     def barrier():
         if world > 1:
@@ -164,15 +180,15 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             step(i, acc, mode)
-        mp, mu, cnt = eng.slide_finish(acc)
+        mp, mu, cnt = finish(acc)
         if world > 1:                              # the path's one collective (RCCL over xGMI)
             ids = np.arange(rank * n_slides_local, (rank + 1) * n_slides_local)
             D.gather_slide_results(ids, mp.cpu().numpy(), mu.cpu().numpy(), cnt.cpu().numpy(),
-                                   world * n_slides_local, n_slides_local, device=dev)
+                                   world * n_slides_local, n_slides_local, device=coll_dev)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         assert int(cnt.sum()) == steps * B and bool(torch.isfinite(mp[cnt > 0]).all())
@@ -189,7 +205,7 @@ def main():
         'config': {'workload': f'BASELINE.json config 2: {TILES_PER_SLIDE} synthetic 299x299x3 tiles/slide, '
                                f'Xception {args.dtype} + fp32 MC head, MC={args.mc}, batch={B}, '
                                f'{K * B} tiles/GPU resident in HBM',
-                   'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B,
+                   'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B, 'hip_streams': NS,
                    'parallelism': f'slide-sharded dp{world}, one all-gather of slide (pred, sigma, n)'},
     }
 
@@ -211,10 +227,14 @@ def main():
     # per-kernel roofline: HIP events on the launch stream around every launch
     if not args.no_profile and rank == 0:
         acc = zero_acc()
+        torch.cuda.synchronize()
         eng.profile_enable(True)
         psteps = 4
-        for i in range(psteps):
-            step(i, acc, args.mode)
+        for i in range(psteps):              # engine 0 / stream 0 only: events bracket each launch on its stream
+            pool_e.run(0, lambda e: (e.mc_infer(pool[i % 4], args.mc, seed, tile_idx0=tile_base + i * B,
+                                                mc_mode=args.mode, out=(mean[0], std[0])),
+                                     e.slide_reduce(mean[0], std[0], slide_of[i], n_slides_local, acc=acc[0])))
+        pool_e.synchronize()
         ents = eng.profile_read()
         eng.profile_enable(False)
         tot = sum(e.ms for e in ents)

@@ -39,9 +39,12 @@ def init_from_env(device_type='cuda'):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hooks: several ranks on one GPU (BQ_LOCAL_DEVICE) need a non-RCCL backend (BQ_DIST_BACKEND=gloo)
+    if 'BQ_LOCAL_DEVICE' in os.environ:
+        local = int(os.environ['BQ_LOCAL_DEVICE'])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = 'nccl' if device_type == 'cuda' else 'gloo'
+        backend = os.environ.get('BQ_DIST_BACKEND') or ('nccl' if device_type == 'cuda' else 'gloo')
         if device_type == 'cuda':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
