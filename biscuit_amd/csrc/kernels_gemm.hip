@@ -37,6 +37,7 @@ __device__ __forceinline__ void produce(const GemmParams& p, unsigned char* smem
     const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
     const int ldi = p.ldi;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    (void)zero4;
 
     for (int c = tc; c < CH; c += cpp) {
         const int ch0 = p.k_off + c * VEC;  // first input channel / unit of this chunk

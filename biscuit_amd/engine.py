@@ -206,9 +206,12 @@ class EnginePool:
     def __len__(self):
         return len(self.engines)
 
-    def run(self, i, fn):
-        """Call fn(engine) with stream i % n current."""
+    def run(self, i, fn, wait_for_current=False):
+        """Call fn(engine) with stream i % n current.  wait_for_current: first make that stream
+        wait for work already enqueued on the caller's stream (inputs prepared there)."""
         k = i % len(self.engines)
+        if wait_for_current:
+            self.streams[k].wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.streams[k]):
             return fn(self.engines[k])
 

@@ -92,7 +92,11 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     offsets = D.global_tile_offsets(counts)
     dev = engine.device
     n_local = len(mine)
-    acc = None
+    # an EnginePool alternates batches over independent contexts / HIP streams
+    pool = engine if hasattr(engine, 'engines') else None
+    engines = pool.engines if pool else [engine]
+    acc = [None] * len(engines)
+    n_batches = 0
     rows_mean, rows_std, rows_slide, rows_true, rows_loc = [], [], [], [], []
 
     # stream tiles of this rank's slides in batches that may span slides
@@ -100,7 +104,7 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     pend_n = 0
 
     def flush(final=False):
-        nonlocal pend_tiles, pend_sidx, pend_gidx, pend_n, acc
+        nonlocal pend_tiles, pend_sidx, pend_gidx, pend_n, n_batches
         while pend_n >= batch or (final and pend_n > 0):
             tiles = torch.cat(pend_tiles) if len(pend_tiles) > 1 else pend_tiles[0]
             sidx = torch.cat(pend_sidx) if len(pend_sidx) > 1 else pend_sidx[0]
@@ -115,15 +119,23 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             std = torch.empty((take, 2), dtype=torch.float32, device=dev)
             brk = np.flatnonzero(np.diff(cg) != 1) + 1
             starts = np.concatenate([[0], brk]); ends = np.concatenate([brk, [take]])
-            if len(starts) == 1:
-                engine.mc_infer(cur, mc_n, seed, tile_idx0=int(cg[0]), mc_mode=mc_mode, out=(mean, std))
+            k = n_batches % len(engines)
+
+            def work(eng):
+                if len(starts) == 1:
+                    eng.mc_infer(cur, mc_n, seed, tile_idx0=int(cg[0]), mc_mode=mc_mode, out=(mean, std))
+                else:
+                    for a, b in zip(starts, ends):
+                        eng.mc_infer(cur[a:b], mc_n, seed, tile_idx0=int(cg[a]), mc_mode=mc_mode,
+                                     out=(mean[a:b], std[a:b]))
+                acc[k] = eng.slide_reduce(mean, std, cs, max(n_local, 1), tile_uq=tile_uq, acc=acc[k])
+            if pool:
+                pool.run(n_batches, work, wait_for_current=True)
             else:
-                for a, b in zip(starts, ends):
-                    engine.mc_infer(cur[a:b], mc_n, seed, tile_idx0=int(cg[a]), mc_mode=mc_mode,
-                                    out=(mean[a:b], std[a:b]))
-            acc = engine.slide_reduce(mean, std, cs, max(n_local, 1), tile_uq=tile_uq, acc=acc)
-            if keep_tiles:
-                rows_mean.append(mean.cpu()); rows_std.append(std.cpu())
+                work(engine)
+            n_batches += 1
+            if keep_tiles:          # device tensors; copied to the host once everything has been enqueued
+                rows_mean.append(mean); rows_std.append(std)
             pend_tiles, pend_sidx, pend_gidx = ([rest] if rest.shape[0] else []), \
                 ([rs] if rs.shape[0] else []), ([rg] if rg.shape[0] else [])
             pend_n = rest.shape[0]
@@ -146,8 +158,13 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
         flush()
     flush(final=True)
 
-    if acc is not None:
-        mp, mu, cnt = engine.slide_finish(acc)
+    if pool:
+        pool.synchronize()
+    live = [a for a in acc if a is not None]
+    if live:
+        # per-stream fixed-point accumulators are integers: their sum is exact and order-free
+        tot = live[0] if len(live) == 1 else tuple(sum(a[j] for a in live[1:]) + live[0][j] for j in range(3))
+        mp, mu, cnt = engines[0].slide_finish(tot)
         mp, mu, cnt = mp.cpu().numpy(), mu.cpu().numpy(), cnt.cpu().numpy()
     else:
         mp = mu = np.zeros(0); cnt = np.zeros(0, dtype=np.int64)
@@ -156,8 +173,8 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                                                   len(slides), cap)
     tile_df = None
     if keep_tiles:
-        mean = torch.cat(rows_mean).numpy() if rows_mean else np.zeros((0, 2), np.float32)
-        std = torch.cat(rows_std).numpy() if rows_std else np.zeros((0, 2), np.float32)
+        mean = torch.cat(rows_mean).cpu().numpy() if rows_mean else np.zeros((0, 2), np.float32)
+        std = torch.cat(rows_std).cpu().numpy() if rows_std else np.zeros((0, 2), np.float32)
         loc = np.concatenate(rows_loc) if rows_loc and sum(len(x) for x in rows_loc) == len(rows_slide) else None
         tile_df = tile_frame(outcome, rows_slide, rows_true, mean, std, loc)
         if save_dir is not None:

@@ -110,6 +110,53 @@ def synthetic_weights(seed=1, n_classes=2, logit_gain=0.3):
     return w
 
 
+def expected_shapes(n_classes=2):
+    """{variable name: shape} of every tensor the hp.nature2022 classifier needs (Keras layout)."""
+    sh = {'block1_conv1/kernel': (3, 3, 3, 32), 'block1_conv2/kernel': (3, 3, 32, 64)}
+
+    def bn(name, c):
+        for v in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+            sh[f'{name}/{v}'] = (c,)
+    bn('block1_conv1_bn', 32)
+    bn('block1_conv2_bn', 64)
+    for name, cin, cout in residual_plan():
+        sh[name + '_conv/kernel'] = (1, 1, cin, cout)
+        bn(name + '_bn', cout)
+    for name, cin, cout in sepconv_plan():
+        sh[name + '/depthwise_kernel'] = (3, 3, cin, 1)
+        sh[name + '/pointwise_kernel'] = (1, 1, cin, cout)
+        bn(name + '_bn', cout)
+    sh.update({'hidden_0/kernel': (2048, 1024), 'hidden_0/bias': (1024,), 'hidden_1/kernel': (1024, 1024),
+               'hidden_1/bias': (1024,), 'logits/kernel': (1024, n_classes), 'logits/bias': (n_classes,)})
+    return sh
+
+
+def validate(w, n_classes=2):
+    """Raise ValueError unless ``w`` holds exactly the expected tensors with the expected shapes."""
+    want = expected_shapes(n_classes)
+    missing = sorted(set(want) - set(w))
+    extra = sorted(set(w) - set(want))
+    bad = sorted(k for k in want if k in w and tuple(np.shape(w[k])) != want[k])
+    if missing or extra or bad:
+        raise ValueError(f'weights do not match the hp.nature2022 classifier: missing {missing[:4]}, '
+                         f'unexpected {extra[:4]}, wrong shape {bad[:4]}')
+    if not all(np.isfinite(np.asarray(w[k], dtype=np.float32)).all() for k in want):
+        raise ValueError('weights contain NaN/Inf')
+    return w
+
+
+def save_npz(path, w):
+    """Portable weight file: one float32 array per Keras variable name.  A converter from a
+    Slideflow/Keras SavedModel only has to write this (it needs TensorFlow, which is not available
+    in the build environment)."""
+    np.savez_compressed(path, **{k.replace('/', '__'): np.asarray(v, np.float32) for k, v in validate(w).items()})
+
+
+def load_npz(path):
+    with np.load(path) as z:
+        return validate({k.replace('__', '/'): z[k].astype(np.float32) for k in z.files})
+
+
 def count_backbone_params(w):
     head = ('hidden_0', 'hidden_1', 'logits')
     return int(sum(v.size for k, v in w.items() if not k.startswith(head)))

@@ -49,6 +49,19 @@ class StandInEngine:
         return acc[0] / c, acc[1] / c, acc[2]
 
 
+class StandInPool:
+    """Same surface as biscuit_amd.engine.EnginePool, on CPU."""
+    def __init__(self, n):
+        self.engines = [StandInEngine() for _ in range(n)]
+        self.hp, self.device = self.engines[0].hp, self.engines[0].device
+
+    def run(self, i, fn, wait_for_current=False):
+        return fn(self.engines[i % len(self.engines)])
+
+    def synchronize(self):
+        pass
+
+
 def make_slides():
     rng = np.random.default_rng(0)
     counts = [7, 0, 13, 5, 21, 1, 9, 4]
@@ -89,6 +102,17 @@ def test_streaming_single_process(batch):
     # slide table in first-appearance order, empty slide dropped
     sf, _ = res.slide_frame()
     assert list(sf['slide']) == [s.name for s in slides if s.n_tiles]
+
+
+def test_engine_pool_round_robin():
+    slides = make_slides()
+    pool = StandInPool(2)
+    res = evaluate(pool, slides, mc_n=30, seed=1, batch=8)
+    pred, unc, cnt = reference_result(slides)
+    np.testing.assert_allclose(res.slide_pred, pred, atol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(res.slide_unc, unc, atol=1e-12, equal_nan=True)
+    assert list(res.slide_count) == list(cnt) and len(res.tile_df) == sum(cnt)
+    assert all(len(e.calls) > 0 for e in pool.engines)          # both contexts were used
 
 
 def test_tile_uq_filter_on_reduce():

@@ -289,3 +289,19 @@ def test_evaluate_driver_matches_direct_calls(engines):
         if c:
             assert abs(res.slide_pred[i] - float(m[off:off + c, 1].double().mean())) < 1e-9
         off += c
+
+
+def test_engine_pool_two_streams_bit_identical(weights):
+    """Batches alternating over two contexts / HIP streams give exactly the single-stream result."""
+    from biscuit_amd.engine import Engine, EnginePool
+    from biscuit_amd.inference import Slide, evaluate
+    counts = [7, 3, 0, 6]
+    slides = [Slide(f's{i}', make_tiles(c, seed=60 + i) if c else np.zeros((0, 299, 299, 3), np.uint8), c,
+                    y_true=i % 2) for i, c in enumerate(counts)]
+    single = evaluate(Engine(weights, dtype='bf16', max_batch=8, max_mc=8), slides, mc_n=4, seed=3, batch=4)
+    pooled = evaluate(EnginePool(weights, n_streams=2, dtype='bf16', max_batch=8, max_mc=8), slides, mc_n=4,
+                      seed=3, batch=4)
+    assert single.tile_df.equals(pooled.tile_df)
+    assert np.array_equal(single.slide_pred, pooled.slide_pred, equal_nan=True)
+    assert np.array_equal(single.slide_unc, pooled.slide_unc, equal_nan=True)
+    assert list(single.slide_count) == list(pooled.slide_count) == counts

@@ -141,3 +141,22 @@ def test_hp_mirror():
     hp.hidden_layers = 3
     with pytest.raises(ValueError):
         hp.validate()
+
+
+def test_weight_file_roundtrip_and_validation(tmp_path):
+    w = W.synthetic_weights(5)
+    assert set(W.expected_shapes()) == set(w)
+    path = str(tmp_path / 'model.npz')
+    W.save_npz(path, w)
+    back = W.load_npz(path)
+    assert all(np.array_equal(back[k], w[k]) for k in w)
+    bad = dict(w)
+    del bad['block7_sepconv2/pointwise_kernel']
+    with pytest.raises(ValueError):
+        W.validate(bad)
+    bad = dict(w); bad['hidden_0/kernel'] = w['hidden_0/kernel'][:, :512]
+    with pytest.raises(ValueError):
+        W.validate(bad)
+    bad = dict(w); bad['logits/bias'] = np.array([np.nan, 0], np.float32)
+    with pytest.raises(ValueError):
+        W.validate(bad)
