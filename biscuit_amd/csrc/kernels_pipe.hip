@@ -16,6 +16,8 @@
 // in the same iteration.  Depthwise taps live in LDS as fp32 (26 KB for 736 channels).
 #include "gemm_common.h"
 
+#include <stdlib.h>
+
 namespace {
 using namespace bqk;
 
@@ -186,14 +188,6 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in);
     const int ldi = p.ldi;
 
-    // depthwise taps -> LDS as fp32 [9][K]
-    for (int i = tid * 4; i < 9 * K; i += NT * 4) {
-        const int t = i / K, k = i - t * K;
-        // stored as (w0,w2,w1,w3): the order the packed-FMA depthwise consumes them in
-        const float4 wv = *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + k);
-        *reinterpret_cast<float4*>(smem + wl_off + i * 4) = make_float4(wv.x, wv.z, wv.y, wv.w);
-    }
-
     // per-thread constants of the depthwise stage (independent of the chunk)
     const int jch = tid & (CPR - 1);               // this thread's 16-byte piece (8 channels)
     unsigned item_mask[NITEM];                     // 9 validity bits ('same' zero padding)
@@ -215,15 +209,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
         item_mask[q] = bits;
     }
 
-    // ---- prologue: raw(0) -> LDS, D(0), raw(1) -> LDS, raw(2) in flight
+    // ---- prologue: every global load the first stages need is issued up front (halo chunk 0, the
+    // first B fragments, then the taps), so their latencies overlap instead of adding up
     Raw3 rreg = raw_load<NT, NRAW>(in, ldi, 0, K, jch, tid, p_lo, p.M);
-    raw_store<NT, RELU, NRAW>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
-    rreg = raw_load<NT, NRAW>(in, ldi, 1, K, jch, tid, p_lo, p.M);
-    __syncthreads();                               // raw[0] and the taps are visible
-    depthwise<NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
-    raw_store<NT, RELU, NRAW>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
-    rreg = raw_load<NT, NRAW>(in, ldi, 2, K, jch, tid, p_lo, p.M);
-
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
     const int nfb = wave * RN;                     // single pass over N: NFp == WN*RN
@@ -237,6 +225,22 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
 #pragma unroll
         for (int j = 0; j < RN; ++j) bq[d][j] = bp0[((size_t)j * p.KBtot + idx) * 64];
     }
+    // depthwise taps -> LDS as fp32 [9][K]
+    for (int i = tid * 4; i < 9 * K; i += NT * 4) {
+        const int t = i / K, k = i - t * K;
+        // stored as (w0,w2,w1,w3): the order the packed-FMA depthwise consumes them in
+        const float4 wv = *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + k);
+        *reinterpret_cast<float4*>(smem + wl_off + i * 4) = make_float4(wv.x, wv.z, wv.y, wv.w);
+    }
+
+    // raw(0) -> LDS, D(0), raw(1) -> LDS, raw(2) in flight
+    raw_store<NT, RELU, NRAW>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
+    rreg = raw_load<NT, NRAW>(in, ldi, 1, K, jch, tid, p_lo, p.M);
+    __syncthreads();                               // raw[0] and the taps are visible
+    depthwise<NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
+    raw_store<NT, RELU, NRAW>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
+    rreg = raw_load<NT, NRAW>(in, ldi, 2, K, jch, tid, p_lo, p.M);
+
     f32x16 acc[MF][RN];
 #pragma unroll
     for (int i = 0; i < MF; ++i)
