@@ -1,0 +1,75 @@
+"""Command-line entry to the hot path: MC-dropout inference over slides, tile table on disk,
+slide-level table and (optionally) thresholded metrics -- what ``Project.evaluate(...,
+save_predictions=True)`` followed by ``threshold.apply`` does in the reference
+(``biscuit/experiment.py:917-922``, ``705-720``).
+
+    python -m biscuit_amd --tfrecords DIR --labels labels.csv --weights model.npz --out eval_dir
+    python -m biscuit_amd --synthetic 16x64 --out eval_dir          # random-init weights, synthetic tiles
+
+labels.csv: columns ``slide,label[,patient]`` (label 0/1).  Needs an MI355X; there is no CPU path.
+"""
+import argparse
+import glob
+import json
+import os
+
+import numpy as np
+import pandas as pd
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog='python -m biscuit_amd', description=__doc__,
+                                 formatter_class=argparse.RawDescriptionHelpFormatter)
+    src = ap.add_mutually_exclusive_group(required=True)
+    src.add_argument('--tfrecords', help='directory of Slideflow *.tfrecords (one per slide)')
+    src.add_argument('--synthetic', help='SxT: S synthetic slides of T tiles')
+    ap.add_argument('--labels', help='CSV with slide,label[,patient]')
+    ap.add_argument('--weights', help='npz written by biscuit_amd.weights.save_npz (default: seeded random init)')
+    ap.add_argument('--outcome', default='cohort')
+    ap.add_argument('--out', required=True)
+    ap.add_argument('--mc', type=int, default=30)
+    ap.add_argument('--seed', type=int, default=1234)
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--streams', type=int, default=2)
+    ap.add_argument('--tile-uq', type=float, default=0.0, help='tile-level uncertainty threshold (0 = off)')
+    ap.add_argument('--slide-uq', type=float, default=0.0, help='slide-level uncertainty threshold (0 = off)')
+    args = ap.parse_args(argv)
+
+    from . import distributed as D, threshold, weights as W
+    from .engine import EnginePool
+    from .inference import Slide, evaluate, slides_from_tfrecords
+    from .predictions import rename_cols
+    from .synthetic import make_slides
+
+    rank, world, local = D.init_from_env('cuda')
+    w = W.load_npz(args.weights) if args.weights else W.synthetic_weights(1)
+    patients = None
+    if args.tfrecords:
+        lab = pd.read_csv(args.labels, dtype={'slide': str}) if args.labels else pd.DataFrame(columns=['slide', 'label'])
+        labels = dict(zip(lab['slide'], lab['label']))
+        patients = dict(zip(lab['slide'], lab['patient'])) if 'patient' in lab.columns else None
+        paths = sorted(glob.glob(os.path.join(args.tfrecords, '*.tfrecords')))
+        slides = slides_from_tfrecords(paths, labels, patients)
+    else:
+        s, t = (int(x) for x in args.synthetic.lower().split('x'))
+        tiles, sidx, y = make_slides(s, t, seed=0)
+        slides = [Slide(f'slide{i:03d}', tiles[sidx == i], t, y_true=int(y[i])) for i in range(s)]
+    pool = EnginePool(w, n_streams=args.streams, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local)
+    res = evaluate(pool, slides, outcome=args.outcome, mc_n=args.mc, seed=args.seed, batch=args.batch,
+                   save_dir=args.out, rank=rank, world=world)
+    if rank == 0:
+        sf, _ = res.slide_frame(0.5)
+        sf.to_csv(os.path.join(args.out, f'slide_predictions_{args.outcome}_eval.csv'), index=False)
+        summary = {'slides': int((res.slide_count > 0).sum()), 'tiles': int(res.slide_count.sum())}
+        if world == 1:
+            df = res.tile_df.copy()
+            rename_cols(df, args.outcome)
+            metrics, _ = threshold.apply(df, tile_uq=args.tile_uq, slide_uq=args.slide_uq, patients=patients)
+            summary.update({k: (None if v is None or (isinstance(v, float) and np.isnan(v)) else float(v))
+                            for k, v in metrics.items()})
+        print(json.dumps(summary))
+
+
+if __name__ == '__main__':
+    main()

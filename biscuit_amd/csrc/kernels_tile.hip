@@ -54,6 +54,10 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(const TileParams p) {
     constexpr int NPASS = CIN / CC;
     constexpr int PPP = CC / 8;                        // 16-byte pieces per halo pixel and pass
     constexpr int PS = CC * 2 + 16;                    // halo pixel stride in LDS (odd # of 16-B slots)
+    // Halo row pitch padded to a multiple of 16 slots: a ds_read_b128 lane group mixes pixels
+    // 0-3/12-15 of one tile row with 4-11 of the next; with pitch = 0 (mod 16 slots) the second
+    // row lands exactly on the slots the first leaves free (measured 24 % conflict cycles before)
+    constexpr int RP = (RW * PS + 255) / 256 * 256;
     constexpr int KB = (MODE == MODE_CONV3 ? 9 * CIN : CIN) / 16;
     constexpr int KBP = KB / NPASS;                    // k-blocks per pass
     constexpr int NLOAD = (RPIX * PPP + NT - 1) / NT;  // raw 16-byte loads per thread and pass
@@ -116,7 +120,8 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(const TileParams p) {
         for (int q = 0; q < NLOAD; ++q) {
             const int idx = tid + q * NT;
             const int pix = idx / PPP, j = idx - pix * PPP;
-            if (ryx[q] >= 0) *reinterpret_cast<uint4*>(smem + BUF_OFF + pix * PS + j * 16) = rreg[q];
+            if (ryx[q] >= 0)
+                *reinterpret_cast<uint4*>(smem + BUF_OFF + (ryx[q] >> 8) * RP + (ryx[q] & 255) * PS + j * 16) = rreg[q];
         }
     };
 
@@ -124,7 +129,7 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(const TileParams p) {
     if (tile < ntiles) load_pass(tile, 0);
     // this wave's pixels: tile rows 2*wave and 2*wave+1, lane&31 -> (row, column)
     const int py = 2 * wave + (r32 >> 4), px = r32 & 15;
-    const int raw_lane = BUF_OFF + (py * RW + px) * PS;        // halo pixel of tap (0,0)
+    const int raw_lane = BUF_OFF + py * RP + px * PS;          // halo pixel of tap (0,0)
 
     for (; tile < ntiles; tile += gridDim.x) {
         f32x16 acc[NF];
@@ -150,7 +155,7 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(const TileParams p) {
                     // k = tap*CIN + channel: this k-block is 16 channels of one tap
                     const int tap = (kb * 16) / CIN, c0 = (kb * 16) % CIN;
                     const int dy = tap / 3, dx = tap - dy * 3;
-                    opnd = *reinterpret_cast<const uint4*>(smem + raw_lane + (dy * RW + dx) * PS + (c0 + h * 8) * 2);
+                    opnd = *reinterpret_cast<const uint4*>(smem + raw_lane + dy * RP + dx * PS + (c0 + h * 8) * 2);
                 } else {
                     // depthwise 3x3 of 8 channels (piece 2*kl + h of this pass) of this lane's pixel
                     const int wbase = W_BYTES + (2 * kb + h) * 32;
@@ -158,7 +163,7 @@ __global__ void __launch_bounds__(256) tile_conv_kernel(const TileParams p) {
                     f32x2t aA = {0.f, 0.f}, aB = {0.f, 0.f}, aC = {0.f, 0.f}, aD = {0.f, 0.f};
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(smem + rbase + ((t / 3) * RW + (t % 3)) * PS);
+                        const uint4 v = *reinterpret_cast<const uint4*>(smem + rbase + (t / 3) * RP + (t % 3) * PS);
                         const float4 w0 = *reinterpret_cast<const float4*>(smem + wbase + t * CIN * 4);
                         const float4 w1 = *reinterpret_cast<const float4*>(smem + wbase + t * CIN * 4 + 16);
                         const f32x2t lo01 = {__uint_as_float(v.x << 16), __uint_as_float(v.y << 16)};
@@ -221,7 +226,7 @@ int launch_tile(const TileParams& p, int num_cus, hipStream_t s) {
     constexpr int KB = (MODE == MODE_CONV3 ? 9 * CIN : CIN) / 16;
     constexpr size_t W_BYTES = (size_t)NF * KB * 1024;
     constexpr size_t TAP_BYTES = MODE == MODE_SEP ? 9 * CIN * 4 : 0;
-    constexpr size_t RAW_BYTES = (size_t)RPIX * ((CIN < 64 ? CIN : 64) * 2 + 16);
+    constexpr size_t RAW_BYTES = (size_t)RH * ((RW * ((CIN < 64 ? CIN : 64) * 2 + 16) + 255) / 256 * 256);
     constexpr size_t STAGE_BYTES = (size_t)TH * TW * (NF * 64 + 16);
     constexpr size_t lds = W_BYTES + TAP_BYTES + (RAW_BYTES > STAGE_BYTES ? RAW_BYTES : STAGE_BYTES);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
