@@ -288,10 +288,10 @@ int tap_nhwc(bq_ctx* c, Tap* t, const char* name, const void* buf, int n, int H,
 #define TAP(name, buf, H, W, C, ld) \
     do { int _t = tap_nhwc(c, tap, name, buf, n, H, W, C, ld, s); if (_t) return _t < 0 ? _t : BQ_OK; } while (0)
 
-int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned char* ws, hipStream_t s,
-                  Tap* tap) {
-    const WsLayout L = ws_layout(c, n, 1);
-    void* A = ws + L.a; void* B = ws + L.b; void* C = ws + L.c; void* R = ws + L.r;
+// Stem + entry flow (blocks 1-4) of n tiles.  A/B/C/R are scratch for n tiles; the block-4 output
+// (19x19x736 per tile) goes to out4.  Returns 1 if a debug tap matched (caller stops).
+int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void* B, void* C, void* R,
+               hipStream_t s, Tap* tap) {
     const int dt = c->cfg.dtype;
     const double es = (double)esize(c);
     if (tap && tap->want && strcmp(tap->want, "staged") == 0) {
@@ -332,14 +332,43 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
             const double px = (double)n * Ho * Ho * co;
             snprintf(tn, sizeof tn, "maxpool_add_%d_c%d", e.Hi, e.cout);
             ProfScope ps(c, s, tn, 9.0 * px, es * ((double)n * e.Hi * e.Hi * co + 2.0 * px));
-            if (launch_pool_add(C, R, B, n, e.Hi, e.Hi, co, dt, s))
+            void* dst = e.block == 4 ? out4 : B;
+            if (launch_pool_add(C, R, dst, n, e.Hi, e.Hi, co, dt, s))
                 return fail(c, BQ_ERR_HIP, "pool_add launch failed");
         }
         snprintf(nm, sizeof nm, "block%d_out", e.block);
-        TAP(nm, B, Ho, Ho, e.cout, co);
+        TAP(nm, e.block == 4 ? out4 : B, Ho, Ho, e.cout, co);
+    }
+    return BQ_OK;
+}
+
+int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned char* ws, hipStream_t s,
+                  Tap* tap) {
+    const WsLayout L = ws_layout(c, n, 1);
+    void* A = ws + L.a; void* B = ws + L.b; void* C = ws + L.c; void* R = ws + L.r;
+    const int dt = c->cfg.dtype;
+    const double es = (double)esize(c);
+    // Entry flow in sub-batches: its activations are the big ones (up to 5.5 MB per tile and layer);
+    // with a small sub-batch every intermediate buffer is re-used at the same addresses and stays in
+    // the 256 MiB Infinity Cache instead of round-tripping through HBM.  The block-4 outputs of all
+    // sub-batches are gathered in the upper half of buffer B (the sub-batches only touch the front).
+    static const int env_sub = getenv("BQ_SUB") ? atoi(getenv("BQ_SUB")) : 0;
+    int sub = (tap && tap->want) ? n : env_sub;
+    if (sub <= 0 || sub > n / 2) sub = n;
+    const size_t tile4 = (size_t)361 * 736 * esize(c);
+    unsigned char* X4 = sub == n ? (unsigned char*)B : (unsigned char*)B + (size_t)(n / 2) * kMaxAct * esize(c);
+    if (sub == n) {
+        RUN(entry_flow(c, in_nchw, n, B, A, B, C, R, s, tap));
+        if (tap && tap->written >= 0) return BQ_OK;
+    } else {
+        for (int i0 = 0; i0 < n; i0 += sub) {
+            const int ns = n - i0 < sub ? n - i0 : sub;
+            const unsigned char* in_i = (const unsigned char*)in_nchw + (size_t)i0 * kStaged * esize(c);
+            RUN(entry_flow(c, in_i, ns, X4 + (size_t)i0 * tile4, A, B, C, R, s, nullptr));
+        }
     }
     // middle flow: blocks 5-12 at 19x19x728 (stride 736)
-    void* X = B; void* Y = A;
+    void* X = X4; void* Y = A;
     for (int block = 5; block <= 12; ++block) {
         char nm[64];
         snprintf(nm, sizeof nm, "block%d_sepconv1", block);
