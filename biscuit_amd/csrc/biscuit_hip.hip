@@ -196,14 +196,19 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     const double flops = 2.0 * M * L.cin * L.cout + (dwp ? 18.0 * M * L.cin : 0.0);
     const double in_rows = (double)a.n * a.Hi * a.Wi;
     const double kin = a.prod == PROD_IM2COL ? (double)a.ldi : (double)L.cin;
-    const double bytes = es * (in_rows * kin + M * L.cout * (a.residual ? 2.0 : 1.0)) +
+    const double bytes = es * (in_rows * kin * (a.prod == PROD_S2 ? 0.25 : 1.0) + M * L.cout * (a.residual ? 2.0 : 1.0)) +
                          es * (double)L.cin * L.cout;
     char cls[96];
     snprintf(cls, sizeof cls, "%s_k%d_n%d_%dx%d",
              a.prod == PROD_S2 ? "res1x1s2" : (a.prod == PROD_IM2COL ? "conv3x3" : "sepconv"), L.cin,
              L.cout, a.H, a.W);
+    // Two-kernel form (depthwise kernel + 128x128-tile GEMM): always for the wide exit-flow layers
+    // (K >= 1024: the fused kernel can only hold 32-64 rows of A in LDS there and re-streams the
+    // 3-6 MB weight matrix per 32-64 rows); BQ_SPLIT=1 forces it for every separable conv.
     static const bool split_env = getenv("BQ_SPLIT") != nullptr;
-    const bool will_split = split_env && dtype == BQ_DTYPE_BF16 && dwp && L.nfp % 4 == 0 && a.dwtmp && nsplit == 1;
+    static const bool no_split = getenv("BQ_NO_SPLIT") != nullptr;
+    const bool will_split = !no_split && (split_env || L.kpad >= 1024) && dtype == BQ_DTYPE_BF16 && dwp &&
+                            L.nfp % 4 == 0 && a.dwtmp && nsplit == 1;
     ProfScope ps(c, s, will_split ? std::string("split_") + cls : std::string(cls), will_split ? 0.0 : flops, will_split ? 0.0 : bytes);
     static const bool no_tile = getenv("BQ_NO_TILE") != nullptr;
     static const int tile_mask = getenv("BQ_TILE_MASK") ? atoi(getenv("BQ_TILE_MASK")) : 7;   // kinds enabled (bit k)
@@ -221,8 +226,7 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
             return BQ_OK;
         }
     }
-    static const bool split = getenv("BQ_SPLIT") != nullptr;
-    if (split && dtype == BQ_DTYPE_BF16 && dwp && L.nfp % 4 == 0 && a.dwtmp && nsplit == 1) {
+    if (will_split) {
         {
             ProfScope pd(c, s, std::string("dw3x3_") + cls, 18.0 * M * L.cin, 2.0 * es * M * L.cin);
             const int e = launch_dw3x3(a.in, L.dw, a.dwtmp, a.n, a.H, a.W, a.ldi, a.prod == PROD_DW_RELU, s);
@@ -312,6 +316,8 @@ int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void*
     TAP("block1_conv2", B, 147, 147, 64, 64);
 
     // entry flow: blocks 2-4.  x lives in B.
+    // (Folding the max-pool + add into the residual kernel's store pass was measured at
+    // +1.2 ms/batch: the 9-tap gather serialises behind the GEMM; kept as separate kernels.)
     struct Entry { int block, cin, cout, Hi; };
     const Entry entry[3] = {{2, 64, 128, 147}, {3, 128, 256, 74}, {4, 256, 728, 37}};
     for (const Entry& e : entry) {
@@ -391,9 +397,9 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
         if (launch_pool_add(C, R, X, n, 19, 19, 1024, dt, s)) return fail(c, BQ_ERR_HIP, "pool_add launch failed");
     }
     TAP("block13_out", X, 10, 10, 1024, 1024);
-    RUN(run_conv(c, {"block14_sepconv1", PROD_DW, X, Y, nullptr, C, n, 10, 10, 10, 10, 1024, 1536, 1}, s));
+    RUN(run_conv(c, {"block14_sepconv1", PROD_DW, X, Y, nullptr, C, n, 10, 10, 10, 10, 1024, 1536, 1, R}, s));
     TAP("block14_sepconv1", Y, 10, 10, 1536, 1536);
-    RUN(run_conv(c, {"block14_sepconv2", PROD_DW, Y, C, nullptr, X, n, 10, 10, 10, 10, 1536, 2048, 1}, s));
+    RUN(run_conv(c, {"block14_sepconv2", PROD_DW, Y, C, nullptr, X, n, 10, 10, 10, 10, 1536, 2048, 1, R}, s));
     TAP("block14_sepconv2", C, 10, 10, 2048, 2048);
     {
         ProfScope ps(c, s, "global_avg_pool", (double)n * 100 * 2048, es * (double)n * 100 * 2048 + 4.0 * n * 2048);
