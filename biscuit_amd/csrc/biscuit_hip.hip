@@ -242,8 +242,36 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
         return BQ_OK;
     }
     static const bool no_pipe = getenv("BQ_NO_PIPE") != nullptr;
+    static const bool no_mid = getenv("BQ_MID") == nullptr;   // experimental persistent 19x19 kernel: opt-in
     static const int dbg = getenv("BQ_DBG") ? atoi(getenv("BQ_DBG")) : 0;
     p.dbg = dbg;
+    if (!no_mid && nsplit == 1 && a.H == a.Hi && a.W == a.Wi &&
+        mid_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, p.M, a.ldo)) {
+        p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
+        p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
+        // diagnostic: BQ_STAMPS=<file> records in-kernel s_memtime stamps of the first such launch
+        static const char* stamp_file = getenv("BQ_STAMPS");
+        static int stamp_state = 0;
+        static unsigned long long* d_stamps = nullptr;
+        if (stamp_file && stamp_state == 0 && a.residual) {
+            if (hipMalloc(&d_stamps, 64 * 8 * 128 * 8) == hipSuccess) {
+                hipMemsetAsync(d_stamps, 0, 64 * 8 * 128 * 8, s);
+                p.stamps = d_stamps;
+                stamp_state = 1;
+            }
+        }
+        const int e = launch_sepconv_mid(a.prod, p, c->num_cus, s);
+        if (stamp_state == 1) {
+            std::vector<unsigned long long> h(64 * 8 * 128);
+            hipStreamSynchronize(s);
+            hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE* f = fopen(stamp_file, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+            stamp_state = 2;
+        }
+        if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(mid) ") + a.layer + ": " +
+                                                   hipGetErrorString((hipError_t)e));
+        return BQ_OK;
+    }
     if (!no_pipe && nsplit == 1 && pipe_supported(dtype, a.prod, L.nfp, a.W, L.kpad)) {
         p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;

@@ -55,6 +55,7 @@ struct GemmParams {
     int layer, mc_n, pass0, in_row_is_tile;
     long long tile0;
     int dbg;               // ablation flags for timing experiments (0 in production)
+    unsigned long long* stamps;   // diagnostic builds: s_memtime stamps [wg][wave][64] (null in production)
 };
 
 size_t gemm_lds_bytes(int dtype, int shape, int K);
@@ -63,6 +64,8 @@ int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t
 int gemm_tile_rows(int shape);
 bool pipe_supported(int dtype, int prod, int nfp, int W, int K);
 int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s);
+bool mid_supported(int dtype, int prod, int nfp, int H, int W, int K, int M, int Nstore);
+int launch_sepconv_mid(int prod, const GemmParams& p, int num_cus, hipStream_t s);
 int launch_dw3x3(const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
 int launch_gemm_tile(const GemmParams& p, hipStream_t s);
 int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, const float* scale,

@@ -1,0 +1,589 @@
+// Persistent SeparableConv2D kernel for the middle flow (728 -> 728 @ 19x19, 25 of the 34
+// separable convolutions, ~60 % of the network's FLOPs), bf16.
+//
+// Compared with kernels_pipe.hip (same math, bit-identical results) it removes what that
+// kernel was measured to be bound by:
+//   * LDS bandwidth of the depthwise stage (3 ds_read_b128 per tap and 16-byte piece: data plus
+//     two fp32 tap vectors).  Here a wave owns ONE 8-channel piece, so its 72 taps are
+//     wave-uniform and live in scalar registers (s_load through the constant address space),
+//     and a lane owns two vertically adjacent output pixels, so the 3x3 windows share rows:
+//     12 ds_read_b128 per lane and chunk instead of ~40, 96 unpack + 144 v_fma instead of ~400
+//     vector instructions.  No per-tap padding masks: the halo lives in LDS as a zero-padded
+//     2-D image (pad columns and out-of-image rows are stored as zeros).
+//   * lock-step HBM phases (every CU loading, then every CU computing, then every CU storing).
+//     Workgroups are persistent: each walks several tiles, the store drain of tile t and the halo
+//     loads of tile t+1 run under compute, and the B (weight) register ring keeps streaming
+//     across tile boundaries.
+//   * the short weight prefetch distance: the ring is one full chunk (4 k-blocks) deep.
+//
+// Tile = TR full image rows of one image (TR*W <= 96 pixels; 19x19 maps: 5 rows, 4 tiles per
+// image, 1024 tiles per 256-image batch = 4 per CU, no ragged last round).  One workgroup of
+// 8 waves; every wave keeps a 96 x 96 fp32 accumulator block (3 x 3 MFMA tiles, 144 VGPRs).
+// Per 64-channel chunk c, one barrier:
+//     load  raw(c+2) halo rows -> registers (coalesced 16-byte loads, 128 B per pixel)
+//     D(c+1) depthwise on the vector ALU from raw[(c+1)&1] -> A[(c+1)&1] (bf16)
+//     store raw(c+2) registers -> raw[c&1]
+//     G(c)  36 v_mfma_f32_32x32x16_bf16 on A[c&1], B fragments from the register ring
+#include "gemm_common.h"
+
+#include <stdlib.h>
+
+namespace {
+using namespace bqk;
+
+constexpr int KC = 64;             // channels per chunk
+constexpr int SLOT = 144;          // bytes per halo pixel slot: 128 B of data + 16 B pad (odd number of
+                                   // 16-byte units -> conflict-free ds_read_b128 / ds_write_b128)
+constexpr int A_STR = 144;         // A chunk row stride, same reasoning
+constexpr int MF = 3, RN = 3, WN = 8;
+constexpr int NT = 64 * WN;        // 512 threads
+constexpr int MT = 32 * MF;        // 96 rows of the M tile
+constexpr int KBC = KC / 16;       // k-blocks per chunk
+
+typedef const float __attribute__((address_space(4))) cfloat_t;   // scalar (s_load) path
+
+struct Raw3 { uint4 a, b, c; };
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu2(unsigned x) {           // ReLU on two packed bf16 (v_pk_max_i16)
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), z));
+}
+
+// per-thread, per-kernel constants of the halo loader (3 slots of 16 bytes per chunk)
+struct Loader {
+    int goff0, goff1, goff2;   // element offset of the slot's pixel from the tile's halo origin
+    int loff0, loff1, loff2;   // LDS byte offset inside a raw buffer
+    unsigned bits;             // halo row of slot i in bits [4i, 4i+4), "slot exists" in bit 12+i
+    __device__ __forceinline__ bool act(int i) const { return (bits >> (12 + i)) & 1u; }
+    __device__ __forceinline__ int ry(int i) const { return (bits >> (4 * i)) & 15u; }
+};
+
+struct TileInfo {
+    const bf16_t* origin;   // pixel (img, y0-1, 0), channel 0
+    int y0;                 // first output row
+    int m0;                 // flattened index of the first output pixel
+    int mvalid;             // output pixels of this tile
+};
+
+template <bool RELU>
+__device__ __forceinline__ uint4 fix(uint4 v, bool rowok) {
+    if (RELU) { v.x = relu2(v.x); v.y = relu2(v.y); v.z = relu2(v.z); v.w = relu2(v.w); }
+    if (!rowok) v = make_uint4(0u, 0u, 0u, 0u);
+    return v;
+}
+
+// rows outside the image load a valid pixel instead (first tile row) and are stored as zeros
+__device__ __forceinline__ Raw3 raw_load(const Loader& L, const TileInfo& t, int c, int K, int H, int gclamp,
+                                         int tid) {
+    int coff = c * KC + (tid & 7) * 8;
+    coff = coff < K - 8 ? coff : K - 8;
+    Raw3 r;
+    const bf16_t* base = t.origin + coff;
+    const int y = t.y0 - 1;
+    r.a = *reinterpret_cast<const uint4*>(base + ((unsigned)(y + L.ry(0)) < (unsigned)H ? L.goff0 : gclamp));
+    r.b = *reinterpret_cast<const uint4*>(base + ((unsigned)(y + L.ry(1)) < (unsigned)H ? L.goff1 : gclamp));
+    // unconditional (threads without a third slot re-load a valid pixel): a load under a branch makes
+    // the number of outstanding loads path-dependent and every later s_waitcnt vmcnt conservative
+    r.c = *reinterpret_cast<const uint4*>(
+        base + ((L.act(2) && (unsigned)(y + L.ry(2)) < (unsigned)H) ? L.goff2 : gclamp));
+    return r;
+}
+
+template <bool RELU>
+__device__ __forceinline__ void raw_store(const Raw3& r, const Loader& L, const TileInfo& t, unsigned char* smem,
+                                          int buf_off, int c, int K, int H, int tid) {
+    if (c * KC + (tid & 7) * 8 >= K) return;       // channel tail of the last chunk: never read
+    const int y = t.y0 - 1;
+    if (L.act(0))
+        *reinterpret_cast<uint4*>(smem + buf_off + L.loff0) = fix<RELU>(r.a, (unsigned)(y + L.ry(0)) < (unsigned)H);
+    if (L.act(1))
+        *reinterpret_cast<uint4*>(smem + buf_off + L.loff1) = fix<RELU>(r.b, (unsigned)(y + L.ry(1)) < (unsigned)H);
+    if (L.act(2))
+        *reinterpret_cast<uint4*>(smem + buf_off + L.loff2) = fix<RELU>(r.c, (unsigned)(y + L.ry(2)) < (unsigned)H);
+}
+
+// D stage.  Wave `w` owns channels [c*64 + 8w, +8); lane = (row pair, column).
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+#define STAMP(ev) do { if (stp && lane == 0) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
+
+struct Tap8 { float w[8]; };
+// The offset goes through an empty asm so the scalar loads cannot be hoisted above this point
+// (they are invariant loads: nothing else orders them) and pile up 72 live scalar registers.
+__device__ __forceinline__ Tap8 load_tap(cfloat_t* wq, int off) {
+    asm volatile("" : "+s"(off));
+    Tap8 r;
+    cfloat_t* q = wq + off;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.w[j] = q[j];
+    return r;
+}
+
+// One tap applied to 4 channels (two packed dwords) of one halo pixel, for the lane's upper output
+// (A), lower output (B) or both.  Written as volatile asm so the 24 steps of the stage stay in program
+// order: left to the scheduler, every ds_read and unpack is hoisted to the top and the stage needs
+// ~150 vector registers next to the 144 accumulators of the matrix-core stage.
+#define BQ_UNPACK4 \
+    "v_lshlrev_b32 %[t0], 16, %[x0]\n\tv_and_b32 %[t1], 0xffff0000, %[x0]\n\t" \
+    "v_lshlrev_b32 %[t2], 16, %[x1]\n\tv_and_b32 %[t3], 0xffff0000, %[x1]\n\t"
+__device__ __forceinline__ void tap4_ab(unsigned x0, unsigned x1, const float* wa, const float* wb, float* a,
+                                        float* b) {
+    float t0, t1, t2, t3;
+    asm volatile(BQ_UNPACK4
+                 "v_fmac_f32 %[a0], %[wa0], %[t0]\n\tv_fmac_f32 %[a1], %[wa1], %[t1]\n\t"
+                 "v_fmac_f32 %[a2], %[wa2], %[t2]\n\tv_fmac_f32 %[a3], %[wa3], %[t3]\n\t"
+                 "v_fmac_f32 %[b0], %[wb0], %[t0]\n\tv_fmac_f32 %[b1], %[wb1], %[t1]\n\t"
+                 "v_fmac_f32 %[b2], %[wb2], %[t2]\n\tv_fmac_f32 %[b3], %[wb3], %[t3]"
+                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a0] "+v"(a[0]),
+                   [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [b0] "+v"(b[0]), [b1] "+v"(b[1]),
+                   [b2] "+v"(b[2]), [b3] "+v"(b[3])
+                 : [x0] "v"(x0), [x1] "v"(x1), [wa0] "s"(wa[0]), [wa1] "s"(wa[1]), [wa2] "s"(wa[2]),
+                   [wa3] "s"(wa[3]), [wb0] "s"(wb[0]), [wb1] "s"(wb[1]), [wb2] "s"(wb[2]), [wb3] "s"(wb[3]));
+}
+__device__ __forceinline__ void tap4_a(unsigned x0, unsigned x1, const float* wa, float* a) {
+    float t0, t1, t2, t3;
+    asm volatile(BQ_UNPACK4
+                 "v_fmac_f32 %[a0], %[wa0], %[t0]\n\tv_fmac_f32 %[a1], %[wa1], %[t1]\n\t"
+                 "v_fmac_f32 %[a2], %[wa2], %[t2]\n\tv_fmac_f32 %[a3], %[wa3], %[t3]"
+                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a0] "+v"(a[0]),
+                   [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3])
+                 : [x0] "v"(x0), [x1] "v"(x1), [wa0] "s"(wa[0]), [wa1] "s"(wa[1]), [wa2] "s"(wa[2]),
+                   [wa3] "s"(wa[3]));
+}
+
+// Tap row 0 of chunk c for this wave (24 scalar registers), fetched an MFMA stage ahead of the depthwise
+// stage that uses it: the layer's taps (26 KB) do not fit the scalar cache, every fetch is an L2 round
+// trip.  Rows 1 and 2 are fetched when the stage starts and first used three steps in.
+struct Taps0 { Tap8 w0[3]; };
+__device__ __forceinline__ Taps0 load_taps0(cfloat_t* dwc, int ldi, int c, int K, int wave) {
+    int ch0 = c * KC + wave * 8;
+    ch0 = ch0 < K ? ch0 : 0;
+    cfloat_t* wq = dwc + ch0;
+    Taps0 t;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) t.w0[dx] = load_tap(wq, dx * ldi);
+    return t;
+}
+
+__device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, cfloat_t* dwc, int ldi,
+                                          int c, int K, int wave, int RW, int dbase, int aoff0, int aoff1,
+                                          bool st0, bool st1, const Taps0& tp, unsigned long long* stp = nullptr,
+                                          int lane = 1) {
+    const int ch0 = c * KC + wave * 8;
+    if (ch0 >= K) {                                // wave-uniform: padded channel tail of the last chunk, A = 0
+        if (st0) *reinterpret_cast<uint4*>(smem + a_off + aoff0) = make_uint4(0u, 0u, 0u, 0u);
+        if (st1) *reinterpret_cast<uint4*>(smem + a_off + aoff1) = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    cfloat_t* wq = dwc + ch0;
+    float accA[8], accB[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
+    // Scalar loads return out of order, so a wait behind one is lgkmcnt(0) and also drains the ds_read
+    // prefetch: one such wait per stage (before step 3).
+    Tap8 w1[3], w2[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) w1[dx] = load_tap(wq, (3 + dx) * ldi);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) w2[dx] = load_tap(wq, (6 + dx) * ldi);
+    STAMP(64);
+    int src = raw_off + dbase;
+    constexpr int AHEAD = 2;                       // ds_read prefetch distance in steps
+    uint4 q[AHEAD + 1];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) q[i] = *reinterpret_cast<const uint4*>(smem + src + ((i / 3) * RW + i % 3) * SLOT);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                  // input row of the 4-row window
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int step = r * 3 + dx;
+            if (step + AHEAD < 12) {               // the read two steps ahead is issued here, not earlier
+                asm volatile("" : "+v"(src));
+                q[AHEAD] = *reinterpret_cast<const uint4*>(
+                    smem + src + (((step + AHEAD) / 3) * RW + (step + AHEAD) % 3) * SLOT);
+            }
+            const uint4 v = q[0];
+            // output A uses tap row r at input row r, output B (one row below) tap row r - 1
+            const float* wa = r == 0 ? tp.w0[dx].w : (r == 1 ? w1[dx].w : w2[dx].w);
+            const float* wb = r == 1 ? tp.w0[dx].w : (r == 2 ? w1[dx].w : w2[dx].w);
+            if (r == 0) {
+                tap4_a(v.x, v.y, wa, accA);
+                tap4_a(v.z, v.w, wa + 4, accA + 4);
+            } else if (r == 3) {
+                tap4_a(v.x, v.y, wb, accB);
+                tap4_a(v.z, v.w, wb + 4, accB + 4);
+            } else {
+                tap4_ab(v.x, v.y, wa, wb, accA, accB);
+                tap4_ab(v.z, v.w, wa + 4, wb + 4, accA + 4, accB + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < AHEAD; ++i) q[i] = q[i + 1];
+            STAMP(65 + step);
+        }
+    }
+    if (st0) *reinterpret_cast<uint4*>(smem + a_off + aoff0) = pack<bf16_t>(accA);
+    if (st1) *reinterpret_cast<uint4*>(smem + a_off + aoff1) = pack<bf16_t>(accB);
+    STAMP(77);
+}
+
+// G stage: one 64-channel chunk of A against the B ring; the ring refills itself PF k-blocks ahead and
+// wraps into the next tile's first k-blocks (same weights).  Straight-line on purpose: all four k-blocks
+// always run (k-blocks past K multiply zero rows of A by a valid, unused weight block), because a load
+// under a branch makes the s_waitcnt vmcnt counts path-dependent and the compiler then drains the whole
+// ring before every k-block.
+template <int PF>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
+                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot) {
+    uint4 a[2][MF];                                // A fragments, one k-block ahead
+#pragma unroll
+    for (int i = 0; i < MF; ++i) a[0][i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR);
+#pragma unroll
+    for (int d = 0; d < KBC; ++d) {
+        const int kb = c * KBC + d;
+        if (d + 1 < KBC) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+                a[(d + 1) & 1][i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR + (d + 1) * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[d & 1][i]);
+        const int nx = kb + PF;
+        const int idx = nx < KB ? nx : (d & (PF - 1));   // wrap: the slot next holds that k-block of the next tile
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * KBtot + idx) * 64];
+    }
+}
+
+// accumulators -> folded BN (+ residual) (+ ReLU) -> bf16 -> LDS staging rows
+__device__ __forceinline__ void acc_to_lds(const GemmParams& p, const f32x16 (&acc)[MF][RN], int nfb, int m0,
+                                           int mvalid, int r32, int h, unsigned char* smem) {
+    const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.residual);
+    const int sstride = stage_stride<bf16_t>(p.Nstore);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = (nfb + j) * 32 + g * 8 + h * 4;
+            if (n0 < p.Nstore) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+                const float4 bi = *reinterpret_cast<const float4*>(p.bias + n0);
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const int rl = i * 32 + r32;
+                    float v[4];
+                    v[0] = fmaf(acc[i][j][g * 4 + 0], sc.x, bi.x);
+                    v[1] = fmaf(acc[i][j][g * 4 + 1], sc.y, bi.y);
+                    v[2] = fmaf(acc[i][j][g * 4 + 2], sc.z, bi.z);
+                    v[3] = fmaf(acc[i][j][g * 4 + 3], sc.w, bi.w);
+                    if (res) {                     // staged by residual_to_lds at the crumb's own address
+                        float rv[4];
+                        load4<bf16_t>(reinterpret_cast<const bf16_t*>(smem + (size_t)rl * sstride) + n0, rv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    store4<bf16_t>(reinterpret_cast<bf16_t*>(smem + (size_t)rl * sstride) + n0, v);
+                }
+            }
+        }
+    }
+}
+
+// residual rows -> LDS staging rows with coalesced 16-byte loads (reading the residual straight into the
+// accumulator layout is 36 loads of 8-byte crumbs from 32 different rows each: measured 42k cycles per tile)
+__device__ __forceinline__ void residual_to_lds(const GemmParams& p, int m0, int mvalid, int tid, unsigned char* smem) {
+    const int sstride = stage_stride<bf16_t>(p.Nstore);
+    const int ppr = p.Nstore / 8;
+    const unsigned char* __restrict__ res = reinterpret_cast<const unsigned char*>(p.residual) + (size_t)m0 * p.ldo * 2;
+    const size_t row_bytes = (size_t)p.ldo * 2;
+    int row = tid / ppr, pc = tid - row * ppr;
+    const int drow = NT / ppr, dpc = NT - drow * ppr;
+    constexpr int BATCH = 6;
+    const int rounds = (mvalid * ppr + NT - 1) / NT;
+    for (int k0 = 0; k0 < rounds; k0 += BATCH) {
+        uint4 v[BATCH];
+        int off[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const bool ok = row < mvalid;
+            const int rr = ok ? row : 0, pp = ok ? pc : 0;
+            v[k] = *reinterpret_cast<const uint4*>(res + (size_t)rr * row_bytes + pp * 16);
+            off[k] = ok ? rr * sstride + pp * 16 : -1;
+            row += drow; pc += dpc;
+            if (pc >= ppr) { pc -= ppr; ++row; }
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+            if (off[k] >= 0) *reinterpret_cast<uint4*>(smem + off[k]) = v[k];
+    }
+}
+
+// staging rows -> global, whole 16-byte pieces, every thread busy (flattened (row, piece) walk)
+__device__ __forceinline__ void lds_to_global(const GemmParams& p, int m0, int mvalid, int tid,
+                                              const unsigned char* smem) {
+    const int sstride = stage_stride<bf16_t>(p.Nstore);
+    const int ppr = p.Nstore / 8;                  // 16-byte pieces per row
+    unsigned char* __restrict__ out = reinterpret_cast<unsigned char*>(p.out) + (size_t)m0 * p.ldo * 2;
+    const size_t row_bytes = (size_t)p.ldo * 2;
+    int row = tid / ppr, pc = tid - row * ppr;
+    const int drow = NT / ppr, dpc = NT - drow * ppr;
+    while (row < mvalid) {
+        *reinterpret_cast<uint4*>(out + (size_t)row * row_bytes + pc * 16) =
+            *reinterpret_cast<const uint4*>(smem + (size_t)row * sstride + pc * 16);
+        row += drow; pc += dpc;
+        if (pc >= ppr) { pc -= ppr; ++row; }
+    }
+}
+
+__device__ __forceinline__ TileInfo tile_info(int v, int ntiles, int TPI, int TR, int H, int W, int ldi,
+                                               const bf16_t* in) {
+    TileInfo t;
+    const int tile = xcd_tile(v, ntiles);
+    const int img = tile / TPI, part = tile - img * TPI;
+    t.y0 = part * TR;
+    const int rows = H - t.y0 < TR ? H - t.y0 : TR;
+    t.m0 = (img * H + t.y0) * W;
+    t.mvalid = rows * W;
+    t.origin = in + (ptrdiff_t)(t.m0 - W) * ldi;
+    return t;
+}
+
+// pad columns of both halo buffers = 0 ('same' padding in x); rows outside the image are stored as zeros
+__device__ __forceinline__ void zero_pads(unsigned char* smem, int tid, int RR, int RW, int raw_bytes) {
+    if (tid < 2 * RR * 2 * 8) {
+        const int per = RR * 2 * 8;
+        const int b = tid / per, rem = tid - b * per;
+        const int k = rem >> 3, ry = k >> 1, rx = (k & 1) ? RW - 1 : 0;
+        *reinterpret_cast<uint4*>(smem + b * raw_bytes + (ry * RW + rx) * SLOT + (rem & 7) * 16) =
+            make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+template <bool RELU, bool PERSIST, int PF>
+__global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, const int TR, const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = p.W, H = p.H;
+    const int RW = W + 2, RR = TR + 2;
+    const int raw_bytes = RR * RW * SLOT;
+    const int a_off0 = 2 * raw_bytes;
+    const int K = p.K, KB = K / 16, NC = (K + KC - 1) / KC;
+    const int ldi = p.ldi;
+    const int TPI = (H + TR - 1) / TR;             // tiles per image
+    const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in);
+    cfloat_t* dwc = (cfloat_t*)(p.dw);
+
+    // ---- per-thread constants ----
+    Loader L;
+    {
+        int go[3], lo[3];
+        unsigned bits = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int sl = (tid >> 3) + 64 * i;
+            const bool act = sl < RR * W;
+            const int sc = act ? sl : 0;
+            const int ry = sc / W, x = sc - ry * W;
+            bits |= (unsigned)ry << (4 * i);
+            bits |= (act ? 1u : 0u) << (12 + i);
+            go[i] = (ry * W + x) * ldi;
+            lo[i] = (ry * RW + x + 1) * SLOT + (tid & 7) * 16;
+        }
+        L.goff0 = go[0]; L.goff1 = go[1]; L.goff2 = go[2];
+        L.loff0 = lo[0]; L.loff1 = lo[1]; L.loff2 = lo[2];
+        L.bits = bits;
+    }
+    const int gclamp = W * ldi;                    // pixel (y0, 0): always inside the image
+    // depthwise lane map
+    const int npair = (TR + 1) / 2;
+    const bool dact = lane < npair * W;
+    const int dl = dact ? lane : 0;
+    const int grp = dl / W, dx0 = dl - grp * W;
+    const int dbase = (2 * grp * RW + dx0) * SLOT + wave * 16;
+    const int aoff0 = (2 * grp * W + dx0) * A_STR + wave * 16;
+    const int aoff1 = aoff0 + W * A_STR;
+    const bool st0 = dact && 2 * grp < TR, st1 = dact && 2 * grp + 1 < TR;
+    // MFMA lane map
+    const int r32 = lane & 31, h = lane >> 5;
+    const int nfb = wave * RN;
+    const bool first_half = (p.dbg & 32) ? true : ((p.dbg & 64) ? (wave & 1) == 0 : wave < WN / 2);
+    const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(p.wp);
+    const uint4* bp0 = wp + ((size_t)nfb * p.KBtot + p.kb0) * 64 + lane;
+
+    int v = blockIdx.x;
+    if (v >= ntiles) return;
+    unsigned long long* stp = (p.stamps && blockIdx.x < 64) ? p.stamps + ((size_t)blockIdx.x * 8 + wave) * 128 : nullptr;
+    STAMP(0);
+    TileInfo T = tile_info(v, ntiles, TPI, TR, H, W, ldi, in);
+    Raw3 r0 = raw_load(L, T, 0, K, H, gclamp, tid);
+    Raw3 r1 = raw_load(L, T, 1, K, H, gclamp, tid);
+    // first B fragments
+    uint4 bq[PF][RN];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        const int idx = d < KB ? d : KB - 1;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bq[d][j] = bp0[((size_t)j * p.KBtot + idx) * 64];
+    }
+    // zero the pad columns of both halo buffers and the unused A rows (once; see the tile loop for pads)
+    zero_pads(smem, tid, RR, RW, raw_bytes);
+    for (int i = tid; i < 2 * (MT - TR * W) * 9; i += NT) {
+        const int b = i / ((MT - TR * W) * 9), rem = i - b * (MT - TR * W) * 9;
+        *reinterpret_cast<uint4*>(smem + a_off0 + b * MT * A_STR + TR * W * A_STR + rem * 16) =
+            make_uint4(0u, 0u, 0u, 0u);
+    }
+
+    for (;;) {
+        // ---- tile prologue: raw(0), raw(1) are in r0, r1 ----
+        raw_store<RELU>(r0, L, T, smem, 0, 0, K, H, tid);
+        raw_store<RELU>(r1, L, T, smem, raw_bytes, 1, K, H, tid);
+        Raw3 rr = raw_load(L, T, 2, K, H, gclamp, tid);
+        f32x16 acc[MF][RN];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        STAMP(1);
+        __syncthreads();
+        STAMP(2);
+        {
+            const Taps0 t0 = load_taps0(dwc, ldi, 0, K, wave);
+            depthwise(smem, 0, a_off0, dwc, ldi, 0, K, wave, RW, dbase, aoff0, aoff1, st0, st1, t0);
+        }
+        // taps of the wave's next depthwise stage: D(1) for both halves
+        Taps0 tp = load_taps0(dwc, ldi, 1, K, wave);
+        STAMP(3);
+        __syncthreads();
+        STAMP(4);
+
+        for (int c = 0; c < NC; ++c) {
+            const int cur = c & 1, nxt = cur ^ 1;
+            // raw[cur]'s last reader D(c) finished before the previous barrier
+            if (c + 2 < NC && !(p.dbg & 16)) raw_store<RELU>(rr, L, T, smem, cur * raw_bytes, c + 2, K, H, tid);
+            // D (vector ALU) and G (matrix cores) of one wave are independent; the two waves of a SIMD run
+            // them in opposite order so one's depthwise overlaps the other's MFMAs.  The halo loads of chunk
+            // c+3 are issued right before the wave's own D stage, which never waits on vmcnt: issued before
+            // G they would sit in front of the B ring's loads in the in-order vmcnt queue and every k-block
+            // would wait out their HBM latency.
+            const bool do_d = c + 1 < NC && !(p.dbg & 1);
+            if (first_half) {
+                if (!(p.dbg & 16)) rr = raw_load(L, T, c + 3, K, H, gclamp, tid);
+                if (do_d)
+                    depthwise(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, dwc, ldi, c + 1, K, wave, RW, dbase,
+                              aoff0, aoff1, st0, st1, tp, c == 5 ? stp : nullptr, lane);
+            }
+            // taps for the wave's next D stage, an MFMA stage ahead of their use: D(c+2) next iteration for
+            // the first half, D(c+1) right after G for the second
+            tp = load_taps0(dwc, ldi, first_half ? c + 2 : c + 1, K, wave);
+            STAMP(5 + 4 * c);
+            const int a_base = a_off0 + cur * MT * A_STR + r32 * A_STR + h * 16;
+            if (!(p.dbg & 2)) mma_chunk<PF>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+            STAMP(6 + 4 * c);
+            if (!first_half) {
+                if (!(p.dbg & 16)) rr = raw_load(L, T, c + 3, K, H, gclamp, tid);
+                if (do_d)
+                    depthwise(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, dwc, ldi, c + 1, K, wave, RW, dbase,
+                              aoff0, aoff1, st0, st1, tp, c == 5 ? stp : nullptr, lane);
+            }
+            STAMP(7 + 4 * c);
+            __syncthreads();
+            STAMP(8 + 4 * c);
+        }
+
+        // ---- tile epilogue; the next tile's first halo chunks load underneath its store pass ----
+        const int vn = v + gridDim.x;
+        const bool more = PERSIST && vn < ntiles;
+        if (!(p.dbg & 4)) {
+            if (p.residual) {
+                STAMP(60);
+                residual_to_lds(p, T.m0, T.mvalid, tid, smem);
+                STAMP(61);
+                __syncthreads();
+                STAMP(62);
+            }
+            acc_to_lds(p, acc, nfb, T.m0, T.mvalid, r32, h, smem);
+        }
+        TileInfo Tn = T;
+        if (more) {                                // the accumulators are dead: registers to spare
+            Tn = tile_info(vn, ntiles, TPI, TR, H, W, ldi, in);
+            r0 = raw_load(L, Tn, 0, K, H, gclamp, tid);
+            r1 = raw_load(L, Tn, 1, K, H, gclamp, tid);
+        }
+        STAMP(57);
+        __syncthreads();
+        STAMP(58);
+        if (!(p.dbg & 4)) lds_to_global(p, T.m0, T.mvalid, tid, smem);
+        STAMP(59);
+        if (!more) break;
+        __syncthreads();
+        zero_pads(smem, tid, RR, RW, raw_bytes);   // the staging rows overwrote them
+        T = Tn;
+        v = vn;
+    }
+}
+
+template <bool RELU>
+int launch_mid(const GemmParams& p, int TR, int num_cus, hipStream_t s) {
+    static const bool persist = getenv("BQ_MID_ONESHOT") == nullptr;
+    static const int pf = getenv("BQ_MID_PF") ? atoi(getenv("BQ_MID_PF")) : 4;
+    auto kern = persist ? (pf == 2 ? sepconv_mid_kernel<RELU, true, 2> : sepconv_mid_kernel<RELU, true, 4>)
+                        : (pf == 2 ? sepconv_mid_kernel<RELU, false, 2> : sepconv_mid_kernel<RELU, false, 4>);
+    const int RW = p.W + 2, RR = TR + 2;
+    size_t lds = (size_t)2 * RR * RW * SLOT + 2 * MT * A_STR;
+    const size_t stage = (size_t)MT * (p.Nstore * 2 + 16);
+    if (stage > lds) lds = stage;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_set = lds;
+    }
+    const int TPI = (p.H + TR - 1) / TR;
+    const int n_img = p.M / (p.H * p.W);
+    const int ntiles = n_img * TPI;
+    static const int env_wgs = getenv("BQ_MID_WGS") ? atoi(getenv("BQ_MID_WGS")) : 0;
+    int grid = env_wgs > 0 ? env_wgs : num_cus;
+    if (grid > ntiles || !persist) grid = ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p, TR, ntiles);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// bf16 SeparableConv2D with 768 (padded) output channels on maps whose rows tile 96 pixels well
+static int mid_rows(int H, int W) {
+    const int TR = MT / W;
+    return TR > H ? H : TR;
+}
+
+bool mid_supported(int dtype, int prod, int nfp, int H, int W, int K, int M, int Nstore) {
+    if (dtype != 1 || (prod != PROD_DW && prod != PROD_DW_RELU) || nfp != WN * RN || K % 16 != 0) return false;
+    if (W > 31 || W < 8 || M % (H * W) != 0) return false;     // W <= 31: >= 3 rows per tile, lanes for row pairs
+    const int TR = mid_rows(H, W);
+    if (TR < 2 || ((TR + 1) / 2) * W > 64) return false;
+    if ((TR + 2) * W > 3 * 64) return false;                   // loader: 3 slots per thread
+    const size_t lds = (size_t)2 * (TR + 2) * (W + 2) * SLOT + 2 * MT * A_STR;
+    const size_t stage = (size_t)MT * (Nstore * 2 + 16);
+    return lds <= 160 * 1024 && stage <= 160 * 1024 && K >= 3 * KC;
+}
+
+int launch_sepconv_mid(int prod, const GemmParams& p, int num_cus, hipStream_t s) {
+    const int TR = mid_rows(p.H, p.W);
+    return prod == PROD_DW_RELU ? launch_mid<true>(p, TR, num_cus, s) : launch_mid<false>(p, TR, num_cus, s);
+}
