@@ -36,6 +36,8 @@ ABI = {
     'bq_load_weights': (_i, [_vp, _vp, _sz]),
     'bq_stage': (_i, [_vp, _vp, _i, _vp, _vp]),
     'bq_stage_f32': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'bq_stain_reinhard_fast': (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp]),
+    'bq_stain_lab_stats': (_i, [_vp, _vp, _i, _vp, _vp]),
     'bq_backbone': (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     'bq_mc_head': (_i, [_vp, _vp, _i, _i64, _i, _i, _u64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'bq_mc_infer': (_i, [_vp, _vp, _i, _i64, _i, _u64, _i, _vp, _vp, _vp, _sz, _vp]),

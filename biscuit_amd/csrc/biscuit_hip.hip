@@ -44,6 +44,7 @@ struct bq_ctx {
     const float* logits_w = nullptr; const float* logits_b = nullptr;
     bool loaded = false;
     int num_cus = 256;
+    float* d_srgb_lut = nullptr;   // 256-entry sRGB -> linear table of the Reinhard normaliser
     // profiling
     bool prof = false;
     std::vector<std::string> prof_names;
@@ -543,12 +544,26 @@ bq_ctx* bq_create(int device_id, const bq_config* cfg) {
     c->cfg = *cfg;
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {   // sRGB -> linear table, float64 evaluation rounded to float32 (oracle/stain.py: same contract)
+        float lut[256];
+        for (int v = 0; v < 256; ++v) {
+            const double x = (double)v / 255.0;
+            lut[v] = (float)(x > 0.04045 ? std::pow((x + 0.055) / 1.055, 2.4) : x / 12.92);
+        }
+        if (hipSetDevice(device_id) != hipSuccess || hipMalloc(&c->d_srgb_lut, sizeof lut) != hipSuccess ||
+            hipMemcpy(c->d_srgb_lut, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) {
+            g_create_error = "cannot allocate the sRGB table";
+            delete c;
+            return nullptr;
+        }
+    }
     return c;
 }
 
 void bq_destroy(bq_ctx* c) {
     if (!c) return;
     if (c->d_blob) (void)hipFree(c->d_blob);
+    if (c->d_srgb_lut) (void)hipFree(c->d_srgb_lut);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
 }
@@ -617,6 +632,39 @@ int bq_stage(bq_ctx* c, const uint8_t* d_tiles, int n, void* d_out, bq_stream_t 
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(c, s, "stage_u8_standardize", 4.0 * n * kStaged, (double)n * kStaged * (1.0 + esize(c)));
     if (launch_stage_u8(d_tiles, n, 299, d_out, c->cfg.dtype, nullptr, s)) return fail(c, BQ_ERR_HIP, "stage launch failed");
+    return BQ_OK;
+}
+
+namespace {
+// float32 colour constants of the Reinhard normaliser: XYZ<-RGB, RGB<-XYZ (its float64 inverse rounded),
+// D65 white (oracle/stain.py: constants())
+const float kReinhardConsts[21] = {
+    0.412452996f, 0.357580006f, 0.180423006f, 0.212670997f, 0.715160012f, 0.0721689984f, 0.0193339996f,
+    0.119193003f, 0.950227022f,
+    3.24048138f, -1.53715158f, -0.498536319f, -0.969254971f, 1.87599003f, 0.0415559262f, 0.0556466393f,
+    -0.204041332f, 1.05731106f,
+    0.950469971f, 1.0f, 1.08882999f};
+}  // namespace
+
+int bq_stain_reinhard_fast(bq_ctx* c, const uint8_t* d_tiles, int n, const float* target_means3,
+                           const float* target_stds3, uint8_t* d_out, bq_stream_t stream) {
+    if (!c || !d_tiles || !d_out || !target_means3 || !target_stds3 || n < 0)
+        return fail(c, BQ_ERR_ARG, "bq_stain_reinhard_fast: bad argument");
+    for (int i = 0; i < 3; ++i)
+        if (!(target_stds3[i] == target_stds3[i]) || !(target_means3[i] == target_means3[i]))
+            return fail(c, BQ_ERR_ARG, "bq_stain_reinhard_fast: NaN in the target statistics");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(c, s, "stain_reinhard_fast", 300.0 * n * 299 * 299, 3.0 * n * kStaged);
+    if (launch_reinhard(d_tiles, n, 299, c->d_srgb_lut, kReinhardConsts, target_means3, target_stds3, d_out, nullptr, s))
+        return fail(c, BQ_ERR_HIP, "reinhard launch failed");
+    return BQ_OK;
+}
+
+int bq_stain_lab_stats(bq_ctx* c, const uint8_t* d_tiles, int n, float* d_stats6, bq_stream_t stream) {
+    if (!c || !d_tiles || !d_stats6 || n < 0) return fail(c, BQ_ERR_ARG, "bq_stain_lab_stats: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (launch_reinhard(d_tiles, n, 299, c->d_srgb_lut, kReinhardConsts, nullptr, nullptr, nullptr, d_stats6, s))
+        return fail(c, BQ_ERR_HIP, "lab stats launch failed");
     return BQ_OK;
 }
 

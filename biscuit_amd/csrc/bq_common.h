@@ -75,6 +75,8 @@ int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, 
 // ---- small kernels (kernels_misc.hip) ----------------------------------------------
 int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, double* stats_scratch,
                     hipStream_t s);
+int launch_reinhard(const uint8_t* tiles, int n, int px, const float* d_lut, const float* consts27,
+                    const float* tgt_mean, const float* tgt_std, uint8_t* dst, float* d_stats, hipStream_t s);
 int launch_stage_f32(const float* tiles, int n, int px, void* out, int dtype, hipStream_t s);
 int launch_stem1(const void* in_nchw, int n, const float* w27x32, const float* scale,
                  const float* bias, void* out_nhwc, int dtype, hipStream_t s);

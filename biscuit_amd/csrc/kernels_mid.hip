@@ -40,8 +40,6 @@ constexpr int NT = 64 * WN;        // 512 threads
 constexpr int MT = 32 * MF;        // 96 rows of the M tile
 constexpr int KBC = KC / 16;       // k-blocks per chunk
 
-typedef const float __attribute__((address_space(4))) cfloat_t;   // scalar (s_load) path
-
 struct Raw3 { uint4 a, b, c; };
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -113,122 +111,61 @@ __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
 
 #define STAMP(ev) do { if (stp && lane == 0) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
 
-struct Tap8 { float w[8]; };
-// The offset goes through an empty asm so the scalar loads cannot be hoisted above this point
-// (they are invariant loads: nothing else orders them) and pile up 72 live scalar registers.
-__device__ __forceinline__ Tap8 load_tap(cfloat_t* wq, int off) {
-    asm volatile("" : "+s"(off));
-    Tap8 r;
-    cfloat_t* q = wq + off;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.w[j] = q[j];
-    return r;
-}
+// D stage on the matrix cores.  The depthwise conv of 16 channels x 16 pixels is nine MFMAs
+//     D[ch][px] += Wdiag_t[ch][k] * X_t[k][px],   k = (term, channel'),  t = tap
+// with v_mfma_f32_16x16x32_bf16: K = 32 holds the 16 channels twice, once for the high and once for the
+// low bf16 half of the fp32 tap (w = hi + lo to 16 mantissa bits; products are exact in fp32), the A
+// operand is the diagonal matrix of the tap and the B operand is simply the 16-byte piece of the shifted
+// halo pixel (lane = pixel, 8 consecutive channels), read straight from the zero-padded LDS image.
+// Measured motivation: the vector-ALU form of this stage (260 instructions per wave and chunk) does not
+// overlap the partner wave's MFMAs - both contend for the SIMD's one vector issue port - and made the
+// stage as long as the matrix stage itself; here it is 27 MFMAs of 16 cycles and ~80 vector instructions.
+struct DwLane {
+    int pbase[3];      // LDS byte offset of the lane's pixel for the wave's three 16-pixel blocks (+ channel piece)
+    int aout[3];       // A-chunk byte offset of the lane's 4-channel crumb for those blocks
+    int tapoff;        // byte offset of the lane's channel in the LDS tap table (row 0)
+    unsigned m0, m1, m2, m3;   // where the lane's one non-zero of the diagonal A operand goes
+    bool lo;           // lane carries the low-half term
+};
 
-// One tap applied to 4 channels (two packed dwords) of one halo pixel, for the lane's upper output
-// (A), lower output (B) or both.  Written as volatile asm so the 24 steps of the stage stay in program
-// order: left to the scheduler, every ds_read and unpack is hoisted to the top and the stage needs
-// ~150 vector registers next to the 144 accumulators of the matrix-core stage.
-#define BQ_UNPACK4 \
-    "v_lshlrev_b32 %[t0], 16, %[x0]\n\tv_and_b32 %[t1], 0xffff0000, %[x0]\n\t" \
-    "v_lshlrev_b32 %[t2], 16, %[x1]\n\tv_and_b32 %[t3], 0xffff0000, %[x1]\n\t"
-__device__ __forceinline__ void tap4_ab(unsigned x0, unsigned x1, const float* wa, const float* wb, float* a,
-                                        float* b) {
-    float t0, t1, t2, t3;
-    asm volatile(BQ_UNPACK4
-                 "v_fmac_f32 %[a0], %[wa0], %[t0]\n\tv_fmac_f32 %[a1], %[wa1], %[t1]\n\t"
-                 "v_fmac_f32 %[a2], %[wa2], %[t2]\n\tv_fmac_f32 %[a3], %[wa3], %[t3]\n\t"
-                 "v_fmac_f32 %[b0], %[wb0], %[t0]\n\tv_fmac_f32 %[b1], %[wb1], %[t1]\n\t"
-                 "v_fmac_f32 %[b2], %[wb2], %[t2]\n\tv_fmac_f32 %[b3], %[wb3], %[t3]"
-                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a0] "+v"(a[0]),
-                   [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [b0] "+v"(b[0]), [b1] "+v"(b[1]),
-                   [b2] "+v"(b[2]), [b3] "+v"(b[3])
-                 : [x0] "v"(x0), [x1] "v"(x1), [wa0] "s"(wa[0]), [wa1] "s"(wa[1]), [wa2] "s"(wa[2]),
-                   [wa3] "s"(wa[3]), [wb0] "s"(wb[0]), [wb1] "s"(wb[1]), [wb2] "s"(wb[2]), [wb3] "s"(wb[3]));
-}
-__device__ __forceinline__ void tap4_a(unsigned x0, unsigned x1, const float* wa, float* a) {
-    float t0, t1, t2, t3;
-    asm volatile(BQ_UNPACK4
-                 "v_fmac_f32 %[a0], %[wa0], %[t0]\n\tv_fmac_f32 %[a1], %[wa1], %[t1]\n\t"
-                 "v_fmac_f32 %[a2], %[wa2], %[t2]\n\tv_fmac_f32 %[a3], %[wa3], %[t3]"
-                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a0] "+v"(a[0]),
-                   [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3])
-                 : [x0] "v"(x0), [x1] "v"(x1), [wa0] "s"(wa[0]), [wa1] "s"(wa[1]), [wa2] "s"(wa[2]),
-                   [wa3] "s"(wa[3]));
-}
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// Tap row 0 of chunk c for this wave (24 scalar registers), fetched an MFMA stage ahead of the depthwise
-// stage that uses it: the layer's taps (26 KB) do not fit the scalar cache, every fetch is an L2 round
-// trip.  Rows 1 and 2 are fetched when the stage starts and first used three steps in.
-struct Taps0 { Tap8 w0[3]; };
-__device__ __forceinline__ Taps0 load_taps0(cfloat_t* dwc, int ldi, int c, int K, int wave) {
-    int ch0 = c * KC + wave * 8;
-    ch0 = ch0 < K ? ch0 : 0;
-    cfloat_t* wq = dwc + ch0;
-    Taps0 t;
+__device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, int taps_off, int c, int Kp,
+                                          int RW, const DwLane& dl, unsigned long long* stp = nullptr, int lane = 1) {
+    f32x4v acc[3];
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) t.w0[dx] = load_tap(wq, dx * ldi);
-    return t;
-}
-
-__device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, cfloat_t* dwc, int ldi,
-                                          int c, int K, int wave, int RW, int dbase, int aoff0, int aoff1,
-                                          bool st0, bool st1, const Taps0& tp, unsigned long long* stp = nullptr,
-                                          int lane = 1) {
-    const int ch0 = c * KC + wave * 8;
-    if (ch0 >= K) {                                // wave-uniform: padded channel tail of the last chunk, A = 0
-        if (st0) *reinterpret_cast<uint4*>(smem + a_off + aoff0) = make_uint4(0u, 0u, 0u, 0u);
-        if (st1) *reinterpret_cast<uint4*>(smem + a_off + aoff1) = make_uint4(0u, 0u, 0u, 0u);
-        return;
-    }
-    cfloat_t* wq = dwc + ch0;
-    float accA[8], accB[8];
+    for (int b = 0; b < 3; ++b) acc[b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    unsigned wv[9];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
-    // Scalar loads return out of order, so a wait behind one is lgkmcnt(0) and also drains the ds_read
-    // prefetch: one such wait per stage (before step 3).
-    Tap8 w1[3], w2[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) w1[dx] = load_tap(wq, (3 + dx) * ldi);
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) w2[dx] = load_tap(wq, (6 + dx) * ldi);
+    for (int t = 0; t < 9; ++t)
+        wv[t] = *reinterpret_cast<const unsigned*>(smem + taps_off + dl.tapoff + (t * Kp + c * KC) * 4);
     STAMP(64);
-    int src = raw_off + dbase;
-    constexpr int AHEAD = 2;                       // ds_read prefetch distance in steps
-    uint4 q[AHEAD + 1];
+    // B operands one tap ahead of the MFMAs that consume them
+    uint4 x[2][3];
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i) q[i] = *reinterpret_cast<const uint4*>(smem + src + ((i / 3) * RW + i % 3) * SLOT);
+    for (int b = 0; b < 3; ++b) x[0][b] = *reinterpret_cast<const uint4*>(smem + raw_off + dl.pbase[b]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {                  // input row of the 4-row window
+    for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) {
+            const int toff = (((t + 1) / 3) * RW + (t + 1) % 3) * SLOT;
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int step = r * 3 + dx;
-            if (step + AHEAD < 12) {               // the read two steps ahead is issued here, not earlier
-                asm volatile("" : "+v"(src));
-                q[AHEAD] = *reinterpret_cast<const uint4*>(
-                    smem + src + (((step + AHEAD) / 3) * RW + (step + AHEAD) % 3) * SLOT);
-            }
-            const uint4 v = q[0];
-            // output A uses tap row r at input row r, output B (one row below) tap row r - 1
-            const float* wa = r == 0 ? tp.w0[dx].w : (r == 1 ? w1[dx].w : w2[dx].w);
-            const float* wb = r == 1 ? tp.w0[dx].w : (r == 2 ? w1[dx].w : w2[dx].w);
-            if (r == 0) {
-                tap4_a(v.x, v.y, wa, accA);
-                tap4_a(v.z, v.w, wa + 4, accA + 4);
-            } else if (r == 3) {
-                tap4_a(v.x, v.y, wb, accB);
-                tap4_a(v.z, v.w, wb + 4, accB + 4);
-            } else {
-                tap4_ab(v.x, v.y, wa, wb, accA, accB);
-                tap4_ab(v.z, v.w, wa + 4, wb + 4, accA + 4, accB + 4);
-            }
-#pragma unroll
-            for (int i = 0; i < AHEAD; ++i) q[i] = q[i + 1];
-            STAMP(65 + step);
+            for (int b = 0; b < 3; ++b)
+                x[(t + 1) & 1][b] = *reinterpret_cast<const uint4*>(smem + raw_off + dl.pbase[b] + toff);
         }
+        const unsigned half = dl.lo ? (wv[t] >> 16) : (wv[t] & 0xffffu);
+        const unsigned dup = half | (half << 16);
+        const uint4 afrag = make_uint4(dup & dl.m0, dup & dl.m1, dup & dl.m2, dup & dl.m3);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag),
+                                                             __builtin_bit_cast(bf16x8, x[t & 1][b]), acc[b], 0, 0, 0);
+        STAMP(65 + t);
     }
-    if (st0) *reinterpret_cast<uint4*>(smem + a_off + aoff0) = pack<bf16_t>(accA);
-    if (st1) *reinterpret_cast<uint4*>(smem + a_off + aoff1) = pack<bf16_t>(accB);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const uint2 o = make_uint2(pack_bf16x2(acc[b][0], acc[b][1]), pack_bf16x2(acc[b][2], acc[b][3]));
+        *reinterpret_cast<uint2*>(smem + a_off + dl.aout[b]) = o;
+    }
     STAMP(77);
 }
 
@@ -384,7 +321,6 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
     const int ldi = p.ldi;
     const int TPI = (H + TR - 1) / TR;             // tiles per image
     const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in);
-    cfloat_t* dwc = (cfloat_t*)(p.dw);
 
     // ---- per-thread constants ----
     Loader L;
@@ -407,15 +343,31 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
         L.bits = bits;
     }
     const int gclamp = W * ldi;                    // pixel (y0, 0): always inside the image
-    // depthwise lane map
-    const int npair = (TR + 1) / 2;
-    const bool dact = lane < npair * W;
-    const int dl = dact ? lane : 0;
-    const int grp = dl / W, dx0 = dl - grp * W;
-    const int dbase = (2 * grp * RW + dx0) * SLOT + wave * 16;
-    const int aoff0 = (2 * grp * W + dx0) * A_STR + wave * 16;
-    const int aoff1 = aoff0 + W * A_STR;
-    const bool st0 = dact && 2 * grp < TR, st1 = dact && 2 * grp + 1 < TR;
+    // depthwise lane map: wave -> 16-channel block (wave & 3) and three 16-pixel blocks; lane -> pixel, k-group
+    const int Kp = NC * KC;                        // row length of the tap table: whole chunks, zero beyond the layer's channels
+    const int taps_off = a_off0 + 2 * MT * A_STR;
+    DwLane dl;
+    {
+        const int cb = wave & 3, pxb0 = (wave >> 2) * 3;
+        const int px = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int P = (pxb0 + b) * 16 + px;    // pixel of the M tile (row-major over TR rows of W)
+            const int row = P / W, x = P - row * W;
+            dl.pbase[b] = (row * RW + x) * SLOT + (cb * 2 + (g & 1)) * 16;
+            dl.aout[b] = P * A_STR + cb * 32 + g * 8;
+        }
+        const int ch = lane & 15;                  // A operand row = channel of the block
+        dl.tapoff = (cb * 16 + ch) * 4;
+        const bool active = (ch >> 3) == (g & 1);
+        const int j = ch & 7;
+        const unsigned hm = (j & 1) ? 0xffff0000u : 0x0000ffffu;
+        dl.m0 = (active && (j >> 1) == 0) ? hm : 0u;
+        dl.m1 = (active && (j >> 1) == 1) ? hm : 0u;
+        dl.m2 = (active && (j >> 1) == 2) ? hm : 0u;
+        dl.m3 = (active && (j >> 1) == 3) ? hm : 0u;
+        dl.lo = (g >> 1) != 0;
+    }
     // MFMA lane map
     const int r32 = lane & 31, h = lane >> 5;
     const int nfb = wave * RN;
@@ -440,6 +392,16 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
     }
     // zero the pad columns of both halo buffers and the unused A rows (once; see the tile loop for pads)
     zero_pads(smem, tid, RR, RW, raw_bytes);
+    // tap table in LDS: fp32 tap split into two bf16 terms, hi | lo << 16, [9][Kp]
+    for (int i = tid; i < 9 * Kp; i += NT) {
+        const int t = i / Kp, ch = i - t * Kp;
+        const float w = ch < ldi ? p.dw[t * ldi + ch] : 0.f;
+        const bf16_t hi = (bf16_t)w;
+        const float r = w - (float)hi;
+        const bf16_t lo = (bf16_t)r;
+        *reinterpret_cast<unsigned*>(smem + taps_off + i * 4) =
+            (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    }
     for (int i = tid; i < 2 * (MT - TR * W) * 9; i += NT) {
         const int b = i / ((MT - TR * W) * 9), rem = i - b * (MT - TR * W) * 9;
         *reinterpret_cast<uint4*>(smem + a_off0 + b * MT * A_STR + TR * W * A_STR + rem * 16) =
@@ -461,12 +423,7 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
         STAMP(1);
         __syncthreads();
         STAMP(2);
-        {
-            const Taps0 t0 = load_taps0(dwc, ldi, 0, K, wave);
-            depthwise(smem, 0, a_off0, dwc, ldi, 0, K, wave, RW, dbase, aoff0, aoff1, st0, st1, t0);
-        }
-        // taps of the wave's next depthwise stage: D(1) for both halves
-        Taps0 tp = load_taps0(dwc, ldi, 1, K, wave);
+        depthwise(smem, 0, a_off0, taps_off, 0, Kp, RW, dl);
         STAMP(3);
         __syncthreads();
         STAMP(4);
@@ -484,12 +441,9 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
             if (first_half) {
                 if (!(p.dbg & 16)) rr = raw_load(L, T, c + 3, K, H, gclamp, tid);
                 if (do_d)
-                    depthwise(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, dwc, ldi, c + 1, K, wave, RW, dbase,
-                              aoff0, aoff1, st0, st1, tp, c == 5 ? stp : nullptr, lane);
+                    depthwise(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, taps_off, c + 1, Kp, RW, dl,
+                              c == 5 ? stp : nullptr, lane);
             }
-            // taps for the wave's next D stage, an MFMA stage ahead of their use: D(c+2) next iteration for
-            // the first half, D(c+1) right after G for the second
-            tp = load_taps0(dwc, ldi, first_half ? c + 2 : c + 1, K, wave);
             STAMP(5 + 4 * c);
             const int a_base = a_off0 + cur * MT * A_STR + r32 * A_STR + h * 16;
             if (!(p.dbg & 2)) mma_chunk<PF>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
@@ -497,8 +451,8 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
             if (!first_half) {
                 if (!(p.dbg & 16)) rr = raw_load(L, T, c + 3, K, H, gclamp, tid);
                 if (do_d)
-                    depthwise(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, dwc, ldi, c + 1, K, wave, RW, dbase,
-                              aoff0, aoff1, st0, st1, tp, c == 5 ? stp : nullptr, lane);
+                    depthwise(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, taps_off, c + 1, Kp, RW, dl,
+                              c == 5 ? stp : nullptr, lane);
             }
             STAMP(7 + 4 * c);
             __syncthreads();
@@ -544,7 +498,7 @@ int launch_mid(const GemmParams& p, int TR, int num_cus, hipStream_t s) {
     auto kern = persist ? (pf == 2 ? sepconv_mid_kernel<RELU, true, 2> : sepconv_mid_kernel<RELU, true, 4>)
                         : (pf == 2 ? sepconv_mid_kernel<RELU, false, 2> : sepconv_mid_kernel<RELU, false, 4>);
     const int RW = p.W + 2, RR = TR + 2;
-    size_t lds = (size_t)2 * RR * RW * SLOT + 2 * MT * A_STR;
+    size_t lds = (size_t)2 * RR * RW * SLOT + 2 * MT * A_STR + (size_t)9 * ((p.K + KC - 1) / KC * KC) * 4;
     const size_t stage = (size_t)MT * (p.Nstore * 2 + 16);
     if (stage > lds) lds = stage;
     static size_t lds_set = 0;

@@ -449,3 +449,144 @@ int launch_nchw_to_f32_nhwc(const void* x, int n, int C, int HW, float* out, int
                                      s, (const float*)x, n, C, HW, out));
     return (int)hipGetLastError();
 }
+
+// ---- K0 (optional front half): Reinhard-fast stain normalisation -------------------------------
+// hp.py:19 normalizer='reinhard_fast', applied to the uint8 tile before the standardisation
+// (results.py:251-256).  One workgroup per tile: pass 1 converts every pixel to CIE-LAB and reduces
+// the six channel statistics in float64 (fixed thread map and tree: bit-reproducible); pass 2
+// re-reads the (L2-resident) tile, converts again, applies (lab - mu) * (target_std / sd) + target_mean,
+// converts back and stores uint8.  The precision contract (float64 for cbrt / pow / the statistics,
+// one float32 rounding per other operation, no FMA contraction) is written out in oracle/stain.py;
+// it makes the uint8 result comparable bit for bit.
+namespace {
+
+struct ReinhardConst {
+    float m[9];        // XYZ from linear RGB
+    float minv[9];     // linear RGB from XYZ
+    float white[3];
+    float tgt_mean[3];
+    float tgt_std[3];
+};
+
+struct Lab { float L, a, b; };
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ Lab rgb_to_lab(const float* __restrict__ lut, const ReinhardConst& k, unsigned r8,
+                                          unsigned g8, unsigned b8) {
+    const float r = lut[r8], g = lut[g8], b = lut[b8];
+    float f[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float xyz = (k.m[3 * i] * r + k.m[3 * i + 1] * g) + k.m[3 * i + 2] * b;
+        const float t = xyz / k.white[i];
+        f[i] = t > 0.008856f ? (float)cbrt((double)t) : 7.787f * t + (float)(16.0 / 116.0);
+    }
+    Lab o;
+    o.L = 116.0f * f[1] - 16.0f;
+    o.a = 500.0f * (f[0] - f[1]);
+    o.b = 200.0f * (f[1] - f[2]);
+    return o;
+}
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void lab_to_rgb8(const ReinhardConst& k, float L, float a, float b, uint8_t* out) {
+    const float fy = (L + 16.0f) / 116.0f;
+    const float fx = a / 500.0f + fy;
+    const float fz = fy - b / 200.0f;
+    const float fv[3] = {fx, fy, fz};
+    float xyz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float v = fv[i];
+        const float t = v > 0.2068966f ? (v * v) * v : (v - (float)(16.0 / 116.0)) / 7.787f;
+        xyz[i] = t * k.white[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float c = (k.minv[3 * i] * xyz[0] + k.minv[3 * i + 1] * xyz[1]) + k.minv[3 * i + 2] * xyz[2];
+        if (c > 0.0031308f) {
+            const float p = (float)pow((double)c, 1.0 / 2.4);
+            c = 1.055f * p - 0.055f;
+        } else {
+            c = c * 12.92f;
+        }
+        c = fminf(fmaxf(c, 0.0f), 1.0f);
+        const float v = truncf(c * 255.0f);
+        out[i] = (uint8_t)fminf(fmaxf(v, 0.0f), 255.0f);
+    }
+}
+
+// stats_out (optional): [n][6] = mean L, a, b, std L, a, b.  dst may be null (statistics only) or == src.
+__global__ void __launch_bounds__(512) reinhard_kernel(const uint8_t* __restrict__ tiles, int px,
+                                                       const float* __restrict__ lut, const ReinhardConst k,
+                                                       uint8_t* dst, float* __restrict__ stats_out) {
+    const int npix = px * px;
+    const uint8_t* src = tiles + (size_t)blockIdx.x * npix * 3;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ float slut[256];
+    __shared__ double red[6][8];
+    __shared__ float stat[6];
+    for (int i = tid; i < 256; i += nt) slut[i] = lut[i];
+    __syncthreads();
+
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < npix; i += nt) {
+        const Lab v = rgb_to_lab(slut, k, src[3 * i], src[3 * i + 1], src[3 * i + 2]);
+        s[0] += (double)v.L; s[1] += (double)v.a; s[2] += (double)v.b;
+        s[3] += (double)v.L * (double)v.L; s[4] += (double)v.a * (double)v.a; s[5] += (double)v.b * (double)v.b;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o);
+        if ((tid & 63) == 0) red[q][tid >> 6] = s[q];
+    }
+    __syncthreads();
+    if (tid < 3) {
+        double a = 0, b = 0;
+        for (int i = 0; i < nt / 64; ++i) { a += red[tid][i]; b += red[tid + 3][i]; }
+        const double mu = a / (double)npix;
+        double var = b / (double)npix - mu * mu;
+        if (var < 0) var = 0;
+        stat[tid] = (float)mu;
+        stat[tid + 3] = (float)sqrt(var);
+        if (stats_out) {
+            stats_out[(size_t)blockIdx.x * 6 + tid] = (float)mu;
+            stats_out[(size_t)blockIdx.x * 6 + tid + 3] = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    if (!dst) return;
+    uint8_t* o = dst + (size_t)blockIdx.x * npix * 3;
+    float sc[3];
+    {
+#pragma clang fp contract(off)
+        sc[0] = k.tgt_std[0] / stat[3]; sc[1] = k.tgt_std[1] / stat[4]; sc[2] = k.tgt_std[2] / stat[5];
+    }
+    for (int i = tid; i < npix; i += nt) {
+#pragma clang fp contract(off)
+        const Lab v = rgb_to_lab(slut, k, src[3 * i], src[3 * i + 1], src[3 * i + 2]);
+        const float L = (v.L - stat[0]) * sc[0] + k.tgt_mean[0];
+        const float a = (v.a - stat[1]) * sc[1] + k.tgt_mean[1];
+        const float b = (v.b - stat[2]) * sc[2] + k.tgt_mean[2];
+        uint8_t rgb[3];
+        lab_to_rgb8(k, L, a, b, rgb);
+        o[3 * i] = rgb[0]; o[3 * i + 1] = rgb[1]; o[3 * i + 2] = rgb[2];
+    }
+}
+
+}  // namespace
+
+int launch_reinhard(const uint8_t* tiles, int n, int px, const float* d_lut, const float* consts27,
+                    const float* tgt_mean, const float* tgt_std, uint8_t* dst, float* d_stats, hipStream_t s) {
+    if (n <= 0) return 0;
+    ReinhardConst k;
+    for (int i = 0; i < 9; ++i) { k.m[i] = consts27[i]; k.minv[i] = consts27[9 + i]; }
+    for (int i = 0; i < 3; ++i) {
+        k.white[i] = consts27[18 + i];
+        k.tgt_mean[i] = tgt_mean ? tgt_mean[i] : 0.f;
+        k.tgt_std[i] = tgt_std ? tgt_std[i] : 1.f;
+    }
+    hipLaunchKernelGGL(reinhard_kernel, dim3(n), dim3(512), 0, s, tiles, px, d_lut, k, dst, d_stats);
+    return (int)hipGetLastError();
+}

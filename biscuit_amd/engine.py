@@ -104,6 +104,27 @@ class Engine:
         self._check(self._lib.bq_stage(self._ctx, _ptr(tiles_u8), n, _ptr(out), self._stream()))
         return out
 
+    def reinhard_fast(self, tiles_u8, target_means, target_stds, out=None):
+        """`reinhard_fast` stain normalisation (hp.py:19; results.py:251-252 `wsi_normalizer.rgb_to_rgb`):
+        uint8 NHWC [n,299,299,3] -> uint8 NHWC.  target_means/target_stds: the CIE-LAB `norm_fit` of the
+        model's params.json (3 floats each).  `out` may be the input tensor (in place)."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
+        tm = (C.c_float * 3)(*[float(v) for v in target_means])
+        ts = (C.c_float * 3)(*[float(v) for v in target_stds])
+        if out is None:
+            out = torch.empty_like(tiles_u8)
+        self._check(self._lib.bq_stain_reinhard_fast(self._ctx, _ptr(tiles_u8), tiles_u8.shape[0], tm, ts,
+                                                     _ptr(out), self._stream()))
+        return out
+
+    def lab_stats(self, tiles_u8):
+        """Per-tile CIE-LAB statistics [n,6] = mean L,a,b, std L,a,b (what the normaliser's fit() stores)."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
+        out = torch.empty((tiles_u8.shape[0], 6), dtype=torch.float32, device=self.device)
+        self._check(self._lib.bq_stain_lab_stats(self._ctx, _ptr(tiles_u8), tiles_u8.shape[0], _ptr(out),
+                                                 self._stream()))
+        return out
+
     def stage_f32(self, tiles_f32):
         assert tiles_f32.dtype == torch.float32 and tiles_f32.is_cuda and tiles_f32.is_contiguous()
         n = tiles_f32.shape[0]
@@ -226,11 +247,14 @@ class UncertaintyInterface:
     tiles, returns ``(mean, uncertainty)`` each ``[B, 2]``; ``uncertainty[0][0]`` is what
     ``results.py:258`` compares with the tile-UQ threshold."""
 
-    wsi_normalizer = None   # stain normalisation is the caller's (results.py:252-255)
-
-    def __init__(self, engine: Engine, uq_n=30, seed=0):
+    def __init__(self, engine: Engine, uq_n=30, seed=0, norm_fit=None):
         self.engine, self.uq_n, self.seed = engine, int(uq_n), int(seed)
         self._calls = 0
+        # results.py:251-252: `if interface.wsi_normalizer: norm_image = ...rgb_to_rgb(image)`
+        self.wsi_normalizer = None
+        if norm_fit is not None:
+            from .stain import ReinhardFast
+            self.wsi_normalizer = ReinhardFast(engine, norm_fit['target_means'], norm_fit['target_stds'])
 
     def __call__(self, batch):
         eng = self.engine

@@ -77,12 +77,16 @@ def _to_device(t, device):
 
 
 def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=None, batch=256,
-             mc_mode='head', tile_uq=None, save_dir=None, keep_tiles=True, rank=0, world=1):
+             mc_mode='head', tile_uq=None, save_dir=None, keep_tiles=True, rank=0, world=1, norm_fit=None):
     """Run MC-dropout inference over ``slides`` and return tile- and slide-level results.
 
     Every rank passes the SAME slide list; rank r processes ``partition_slides(...)[r]``.
     The slide-level arrays are all-gathered (one collective); tile rows stay rank-local and
-    are written as ``{save_dir}/tile_predictions_eval[.rankR].csv`` when requested."""
+    are written as ``{save_dir}/tile_predictions_eval[.rankR].csv`` when requested.
+
+    ``norm_fit`` (``{'target_means': [3], 'target_stds': [3]}``, the block of that name in the model's
+    params.json) switches on the `reinhard_fast` stain normaliser of hp.py:19 in front of the staging
+    kernel, where results.py:251-252 applies it."""
     hp = engine.hp
     mc_n = int(mc_n or hp.uq_n)
     seed = int(hp.seed if seed is None else seed)
@@ -121,7 +125,9 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             starts = np.concatenate([[0], brk]); ends = np.concatenate([brk, [take]])
             k = n_batches % len(engines)
 
-            def work(eng):
+            def work(eng, cur=cur):
+                if norm_fit is not None:
+                    cur = eng.reinhard_fast(cur, norm_fit['target_means'], norm_fit['target_stds'])
                 if len(starts) == 1:
                     eng.mc_infer(cur, mc_n, seed, tile_idx0=int(cg[0]), mc_mode=mc_mode, out=(mean, std))
                 else:

@@ -5,6 +5,7 @@
  * through Python calls into Slideflow/TensorFlow and leaves through a tile-prediction
  * table.  Each entry point below names the reference call site it replaces:
  *
+ *   bq_stain_reinhard_fast  interface.wsi_normalizer.rgb_to_rgb(image)   results.py:251-252, hp.py:19
  *   bq_stage        tf.image.per_image_standardization(norm_image)      results.py:256
  *   bq_backbone     keras Xception(include_top=False, pooling='avg')     biscuit/hp.py:4,20,22
  *   bq_mc_head      the UQ loop behind UncertaintyInterface(model)(batch) -> (mean, std)
@@ -74,6 +75,19 @@ int bq_load_weights(bq_ctx* ctx, const void* host_blob, size_t nbytes);
  * of the context dtype.  (x - mean) / max(std, 1/sqrt(N)). */
 int bq_stage(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, void* d_out_nchw,
              bq_stream_t stream);
+
+/* K0, optional front half: the `reinhard_fast` stain normaliser hp.py:19 selects, applied to the
+ * uint8 tile before the standardisation exactly where results.py:251-252 calls
+ * interface.wsi_normalizer.rgb_to_rgb(image).  uint8 NHWC [n,px,px,3] -> uint8 NHWC; d_out may equal
+ * d_tiles.  target_means3 / target_stds3 are HOST pointers to the model's params.json `norm_fit`
+ * (CIE-LAB L, a, b).  The algorithm lives in Slideflow, not in the reference: parity unpinned
+ * (oracle/stain.py states the arithmetic both sides implement). */
+int bq_stain_reinhard_fast(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, const float* target_means3,
+                           const float* target_stds3, uint8_t* d_out_nhwc, bq_stream_t stream);
+
+/* Per-tile CIE-LAB channel statistics [n][6] = mean L, a, b, population std L, a, b: what the
+ * normaliser's fit() stores as norm_fit for a target image. */
+int bq_stain_lab_stats(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, float* d_stats6, bq_stream_t stream);
 
 /* Variant for callers that already hold standardised float32 NHWC tiles (the
  * UncertaintyInterface contract, results.py:256-257): converts to planar NCHW. */
