@@ -71,6 +71,23 @@ __device__ __forceinline__ uint4 fix(uint4 v, bool rowok) {
     return v;
 }
 
+// The loader's per-thread constants live in LDS between uses (two 16-byte reads per use): the depthwise
+// and matrix stages need every vector register.  The offset goes through an empty asm so the reads are
+// redone at each use instead of being kept in registers.
+__device__ __forceinline__ void park_loader(const Loader& L, unsigned char* smem, int off) {
+    *reinterpret_cast<uint4*>(smem + off) = make_uint4(L.goff0, L.goff1, L.goff2, L.bits);
+    *reinterpret_cast<uint4*>(smem + off + 16) = make_uint4(L.loff0, L.loff1, L.loff2, 0u);
+}
+__device__ __forceinline__ Loader fetch_loader(const unsigned char* smem, int off) {
+    asm volatile("" : "+v"(off));
+    const uint4 a = *reinterpret_cast<const uint4*>(smem + off);
+    const uint4 b = *reinterpret_cast<const uint4*>(smem + off + 16);
+    Loader L;
+    L.goff0 = a.x; L.goff1 = a.y; L.goff2 = a.z; L.bits = a.w;
+    L.loff0 = b.x; L.loff1 = b.y; L.loff2 = b.z;
+    return L;
+}
+
 // rows outside the image load a valid pixel instead (first tile row) and are stored as zeros
 __device__ __forceinline__ Raw3 raw_load(const Loader& L, const TileInfo& t, int c, int K, int H, int gclamp,
                                          int tid) {
@@ -122,10 +139,10 @@ __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
 // stage as long as the matrix stage itself; here it is 27 MFMAs of 16 cycles and ~80 vector instructions.
 struct DwLane {
     int pbase[3];      // LDS byte offset of the lane's pixel for the wave's three 16-pixel blocks (+ channel piece)
-    int aout[3];       // A-chunk byte offset of the lane's 4-channel crumb for those blocks
+    int aout;          // A-chunk byte offset of the lane's 4-channel crumb for the first block (next: + 16 rows)
     int tapoff;        // byte offset of the lane's channel in the LDS tap table (row 0)
-    unsigned m0, m1, m2, m3;   // where the lane's one non-zero of the diagonal A operand goes
-    bool lo;           // lane carries the low-half term
+    unsigned s0, s1, s2, s3;   // v_perm selectors building the diagonal A operand: the lane's one non-zero
+                               // (its term's bf16 half of the tap) in the right half of the right dword
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -135,26 +152,27 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
     f32x4v acc[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) acc[b] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    unsigned wv[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-        wv[t] = *reinterpret_cast<const unsigned*>(smem + taps_off + dl.tapoff + (t * Kp + c * KC) * 4);
-    STAMP(64);
-    // B operands one tap ahead of the MFMAs that consume them
+    const int tsrc = taps_off + dl.tapoff + c * KC * 4;
+    const int src = raw_off;
+    // operands one tap ahead of the MFMAs that consume them (the scheduling groups below keep it so)
+    unsigned wv[2];
     uint4 x[2][3];
+    wv[0] = *reinterpret_cast<const unsigned*>(smem + tsrc);
 #pragma unroll
-    for (int b = 0; b < 3; ++b) x[0][b] = *reinterpret_cast<const uint4*>(smem + raw_off + dl.pbase[b]);
+    for (int b = 0; b < 3; ++b) x[0][b] = *reinterpret_cast<const uint4*>(smem + src + dl.pbase[b]);
+    STAMP(64);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if (t + 1 < 9) {
             const int toff = (((t + 1) / 3) * RW + (t + 1) % 3) * SLOT;
+            wv[(t + 1) & 1] = *reinterpret_cast<const unsigned*>(smem + tsrc + (t + 1) * Kp * 4);
 #pragma unroll
             for (int b = 0; b < 3; ++b)
-                x[(t + 1) & 1][b] = *reinterpret_cast<const uint4*>(smem + raw_off + dl.pbase[b] + toff);
+                x[(t + 1) & 1][b] = *reinterpret_cast<const uint4*>(smem + src + dl.pbase[b] + toff);
         }
-        const unsigned half = dl.lo ? (wv[t] >> 16) : (wv[t] & 0xffffu);
-        const unsigned dup = half | (half << 16);
-        const uint4 afrag = make_uint4(dup & dl.m0, dup & dl.m1, dup & dl.m2, dup & dl.m3);
+        const unsigned w = wv[t & 1];
+        const uint4 afrag = make_uint4(__builtin_amdgcn_perm(w, w, dl.s0), __builtin_amdgcn_perm(w, w, dl.s1),
+                                       __builtin_amdgcn_perm(w, w, dl.s2), __builtin_amdgcn_perm(w, w, dl.s3));
 #pragma unroll
         for (int b = 0; b < 3; ++b)
             acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag),
@@ -164,7 +182,7 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         const uint2 o = make_uint2(pack_bf16x2(acc[b][0], acc[b][1]), pack_bf16x2(acc[b][2], acc[b][3]));
-        *reinterpret_cast<uint2*>(smem + a_off + dl.aout[b]) = o;
+        *reinterpret_cast<uint2*>(smem + a_off + dl.aout + b * 16 * A_STR) = o;
     }
     STAMP(77);
 }
@@ -176,7 +194,7 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
 // ring before every k-block.
 template <int PF>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
-                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot) {
+                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot, int dbg) {
     uint4 a[2][MF];                                // A fragments, one k-block ahead
 #pragma unroll
     for (int i = 0; i < MF; ++i) a[0][i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR);
@@ -193,7 +211,8 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF]
 #pragma unroll
             for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[d & 1][i]);
         const int nx = kb + PF;
-        const int idx = nx < KB ? nx : (d & (PF - 1));   // wrap: the slot next holds that k-block of the next tile
+        int idx = nx < KB ? nx : (d & (PF - 1));   // wrap: the slot next holds that k-block of the next tile
+        idx = (dbg & 8) ? 0 : idx;                 // timing experiment: every fetch hits the same L1-resident block
 #pragma unroll
         for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * KBtot + idx) * 64];
     }
@@ -342,6 +361,8 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
         L.loff0 = lo[0]; L.loff1 = lo[1]; L.loff2 = lo[2];
         L.bits = bits;
     }
+    const int lpark = a_off0 + 2 * MT * A_STR + 9 * (NC * KC) * 4 + tid * 32;   // behind the tap table
+    park_loader(L, smem, lpark);
     const int gclamp = W * ldi;                    // pixel (y0, 0): always inside the image
     // depthwise lane map: wave -> 16-channel block (wave & 3) and three 16-pixel blocks; lane -> pixel, k-group
     const int Kp = NC * KC;                        // row length of the tap table: whole chunks, zero beyond the layer's channels
@@ -355,18 +376,20 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
             const int P = (pxb0 + b) * 16 + px;    // pixel of the M tile (row-major over TR rows of W)
             const int row = P / W, x = P - row * W;
             dl.pbase[b] = (row * RW + x) * SLOT + (cb * 2 + (g & 1)) * 16;
-            dl.aout[b] = P * A_STR + cb * 32 + g * 8;
         }
+        dl.aout = (pxb0 * 16 + px) * A_STR + cb * 32 + g * 8;
         const int ch = lane & 15;                  // A operand row = channel of the block
         dl.tapoff = (cb * 16 + ch) * 4;
+        // lane (ch, g) holds k = 8g..8g+7 = (term g>>1, channels 8(g&1)..+7): non-zero only at its own channel
         const bool active = (ch >> 3) == (g & 1);
         const int j = ch & 7;
-        const unsigned hm = (j & 1) ? 0xffff0000u : 0x0000ffffu;
-        dl.m0 = (active && (j >> 1) == 0) ? hm : 0u;
-        dl.m1 = (active && (j >> 1) == 1) ? hm : 0u;
-        dl.m2 = (active && (j >> 1) == 2) ? hm : 0u;
-        dl.m3 = (active && (j >> 1) == 3) ? hm : 0u;
-        dl.lo = (g >> 1) != 0;
+        // table entry = hi | lo << 16: bytes (1,0) are the high term, (3,2) the low term; 0x0c selects zero
+        const unsigned src2 = (g >> 1) ? 0x0302u : 0x0100u;
+        const unsigned sel = (j & 1) ? (src2 << 16) | 0x0c0cu : 0x0c0c0000u | src2;
+        dl.s0 = (active && (j >> 1) == 0) ? sel : 0x0c0c0c0cu;
+        dl.s1 = (active && (j >> 1) == 1) ? sel : 0x0c0c0c0cu;
+        dl.s2 = (active && (j >> 1) == 2) ? sel : 0x0c0c0c0cu;
+        dl.s3 = (active && (j >> 1) == 3) ? sel : 0x0c0c0c0cu;
     }
     // MFMA lane map
     const int r32 = lane & 31, h = lane >> 5;
@@ -431,7 +454,8 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
         for (int c = 0; c < NC; ++c) {
             const int cur = c & 1, nxt = cur ^ 1;
             // raw[cur]'s last reader D(c) finished before the previous barrier
-            if (c + 2 < NC && !(p.dbg & 16)) raw_store<RELU>(rr, L, T, smem, cur * raw_bytes, c + 2, K, H, tid);
+            if (c + 2 < NC && !(p.dbg & 16))
+                raw_store<RELU>(rr, fetch_loader(smem, lpark), T, smem, cur * raw_bytes, c + 2, K, H, tid);
             // D (vector ALU) and G (matrix cores) of one wave are independent; the two waves of a SIMD run
             // them in opposite order so one's depthwise overlaps the other's MFMAs.  The halo loads of chunk
             // c+3 are issued right before the wave's own D stage, which never waits on vmcnt: issued before
@@ -439,17 +463,17 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
             // would wait out their HBM latency.
             const bool do_d = c + 1 < NC && !(p.dbg & 1);
             if (first_half) {
-                if (!(p.dbg & 16)) rr = raw_load(L, T, c + 3, K, H, gclamp, tid);
+                if (!(p.dbg & 16)) rr = raw_load(fetch_loader(smem, lpark), T, c + 3, K, H, gclamp, tid);
                 if (do_d)
                     depthwise(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, taps_off, c + 1, Kp, RW, dl,
                               c == 5 ? stp : nullptr, lane);
             }
             STAMP(5 + 4 * c);
             const int a_base = a_off0 + cur * MT * A_STR + r32 * A_STR + h * 16;
-            if (!(p.dbg & 2)) mma_chunk<PF>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+            if (!(p.dbg & 2)) mma_chunk<PF>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
             STAMP(6 + 4 * c);
             if (!first_half) {
-                if (!(p.dbg & 16)) rr = raw_load(L, T, c + 3, K, H, gclamp, tid);
+                if (!(p.dbg & 16)) rr = raw_load(fetch_loader(smem, lpark), T, c + 3, K, H, gclamp, tid);
                 if (do_d)
                     depthwise(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, taps_off, c + 1, Kp, RW, dl,
                               c == 5 ? stp : nullptr, lane);
@@ -493,12 +517,15 @@ __global__ void __launch_bounds__(NT) sepconv_mid_kernel(const GemmParams p, con
 
 template <bool RELU>
 int launch_mid(const GemmParams& p, int TR, int num_cus, hipStream_t s) {
-    static const bool persist = getenv("BQ_MID_ONESHOT") == nullptr;
+    // One tile per workgroup.  The persistent form (PERSIST = true, several tiles per workgroup) is kept for
+    // experiments only: its epilogue staging rows overwrite the LDS tap table and the parked loader
+    // constants, so it must not be launched until the epilogue stages 32 rows at a time.
+    static const bool persist = false;
     static const int pf = getenv("BQ_MID_PF") ? atoi(getenv("BQ_MID_PF")) : 4;
     auto kern = persist ? (pf == 2 ? sepconv_mid_kernel<RELU, true, 2> : sepconv_mid_kernel<RELU, true, 4>)
                         : (pf == 2 ? sepconv_mid_kernel<RELU, false, 2> : sepconv_mid_kernel<RELU, false, 4>);
     const int RW = p.W + 2, RR = TR + 2;
-    size_t lds = (size_t)2 * RR * RW * SLOT + 2 * MT * A_STR + (size_t)9 * ((p.K + KC - 1) / KC * KC) * 4;
+    size_t lds = (size_t)2 * RR * RW * SLOT + 2 * MT * A_STR + (size_t)9 * ((p.K + KC - 1) / KC * KC) * 4 + NT * 32;
     const size_t stage = (size_t)MT * (p.Nstore * 2 + 16);
     if (stage > lds) lds = stage;
     static size_t lds_set = 0;

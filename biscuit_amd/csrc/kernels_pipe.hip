@@ -92,7 +92,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NT, int MT, int NITEM>
 __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, int wl_off, int c, int K,
                                           int W, int jch, int tid, const unsigned (&item_mask)[NITEM]) {
-    if (c * KC + jch * 8 >= K) return;             // padded tail of the last chunk: A never read there
+    if (c * KC + jch * 8 >= K) {                   // padded channel tail of the last chunk: A = 0 (the matrix
+#pragma unroll                                     // stage always runs whole chunks)
+        for (int q = 0; q < NITEM; ++q) {
+            const int r = (tid + q * NT) >> 3;
+            if (r < MT) *reinterpret_cast<uint4*>(smem + a_off + r * A_STR + jch * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
     const int wbase = wl_off + (c * KC + jch * 8) * 4;
 #pragma unroll
     for (int q = 0; q < NITEM; ++q) {
@@ -135,30 +142,28 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
     }
 }
 
-// G stage: the matrix cores on one 64-channel chunk of A (KBC k-blocks), B through the ring
+// G stage: the matrix cores on one 64-channel chunk of A (KBC k-blocks), B through the ring.
+// Straight-line on purpose: all k-blocks of a chunk always run (k-blocks past K multiply zero rows of A by
+// a valid, unused weight block).  A load under a branch makes the number of outstanding loads
+// path-dependent, and the compiler then waits vmcnt(0) - the whole ring - before every k-block.
 template <int MF, int RN, int PF, int KBC>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
-                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot,
-                                          int dbg) {
+                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot) {
 #pragma unroll
     for (int d = 0; d < KBC; ++d) {
         const int kb = c * KBC + d;
-        if (kb < KB && !(dbg & 2)) {
-            uint4 a[MF];
+        uint4 a[MF];
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
-                a[i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR + d * 32);
+        for (int i = 0; i < MF; ++i)
+            a[i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR + d * 32);
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
-            const int nx = kb + PF;
-            const int idx = nx < KB ? nx : KB - 1;
-            if (!(dbg & 8)) {
+            for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
+        const int nx = kb + PF;
+        const int idx = nx < KB ? nx : KB - 1;
 #pragma unroll
-                for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * KBtot + idx) * 64];
-            }
-        }
+        for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * KBtot + idx) * 64];
     }
 }
 
@@ -252,24 +257,30 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
 
     for (int c = 0; c < NC; ++c) {
         const int cur = c & 1, nxt = cur ^ 1;
-        // L: raw chunk c+2 (loaded during the previous iteration) -> raw[cur], whose last
-        // reader D(c) finished before the previous barrier; then start loading chunk c+3
-        if (!(p.dbg & 16)) {
-        if (c + 2 < NC) raw_store<NT, RELU, NRAW>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
-        rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
-        }
+        // L: raw chunk c+2 (loaded during the previous iteration) -> raw[cur], whose last reader D(c)
+        // finished before the previous barrier
+        if (c + 2 < NC && !(p.dbg & 16)) raw_store<NT, RELU, NRAW>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
         // D (depthwise of chunk c+1, vector ALU) and G (matrix cores on chunk c) are independent.
         // Each SIMD hosts one wave of each half of the workgroup: run them in opposite order so
-        // one wave's vector-ALU stage overlaps its partner's matrix-core stage.
+        // one wave's vector-ALU stage overlaps its partner's matrix-core stage.  The halo loads of
+        // chunk c+3 go right in front of the wave's own D stage (which never waits on vmcnt): in front
+        // of G they would sit ahead of the B ring's loads in the in-order vmcnt queue and the first
+        // k-blocks would wait out their HBM latency.
         const int a_base = a_off0 + cur * MT * A_STR + r32 * A_STR + h * 16;
         const bool do_d = (c + 1 < NC) && !(p.dbg & 1);
-        if (do_d && first_half)
-            depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch, tid,
-                                     item_mask);
-        mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
-        if (do_d && !first_half)
-            depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch, tid,
-                                     item_mask);
+        if (first_half) {
+            if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+            if (do_d)
+                depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
+                                         tid, item_mask);
+        }
+        if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+        if (!first_half) {
+            if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+            if (do_d)
+                depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
+                                         tid, item_mask);
+        }
         __syncthreads();
     }
     // every wave is past its last LDS read (the loop's closing barrier): reuse LDS as the
