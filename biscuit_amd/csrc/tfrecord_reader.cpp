@@ -1,0 +1,378 @@
+// libbiscuit_io.so: Slideflow tile TFRecords -> uint8 RGB tiles on the host (include/biscuit_io.h).
+// TFRecord framing + CRC-32C, the subset of protobuf a tf.train.Example needs, and a PNG decoder
+// (zlib inflate + scanline unfilter).  Host code only: g++, -lz, -lpthread.
+#include "../../include/biscuit_io.h"
+
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+std::string g_open_error;
+
+// ---- CRC-32C (Castagnoli), slicing-by-8 ------------------------------------------------
+uint32_t g_crc[8][256];
+bool g_crc_ready = false;
+
+void crc_init() {
+    if (g_crc_ready) return;
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+        g_crc[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t) g_crc[t][i] = (g_crc[t - 1][i] >> 8) ^ g_crc[0][g_crc[t - 1][i] & 255];
+    g_crc_ready = true;
+}
+
+uint32_t crc32c(const uint8_t* p, size_t n) {
+    uint32_t c = 0xFFFFFFFFu;
+    while (n && ((uintptr_t)p & 7)) { c = g_crc[0][(c ^ *p++) & 255] ^ (c >> 8); --n; }
+    while (n >= 8) {
+        uint64_t v;
+        memcpy(&v, p, 8);
+        v ^= c;
+        c = g_crc[7][v & 255] ^ g_crc[6][(v >> 8) & 255] ^ g_crc[5][(v >> 16) & 255] ^ g_crc[4][(v >> 24) & 255] ^
+            g_crc[3][(v >> 32) & 255] ^ g_crc[2][(v >> 40) & 255] ^ g_crc[1][(v >> 48) & 255] ^ g_crc[0][v >> 56];
+        p += 8; n -= 8;
+    }
+    while (n--) c = g_crc[0][(c ^ *p++) & 255] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+uint32_t masked(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xA282EAD8u; }
+
+// ---- protobuf subset ----------------------------------------------------------------------
+struct Span { const uint8_t* p = nullptr; size_t n = 0; };
+
+bool varint(const uint8_t*& p, const uint8_t* end, uint64_t& v) {
+    v = 0;
+    for (int shift = 0; p < end && shift < 64; shift += 7) {
+        const uint8_t b = *p++;
+        v |= (uint64_t)(b & 0x7F) << shift;
+        if (!(b & 0x80)) return true;
+    }
+    return false;
+}
+
+// iterate the fields of one message; returns false on malformed input
+template <typename F>
+bool fields(Span m, F&& f) {
+    const uint8_t* p = m.p;
+    const uint8_t* end = m.p + m.n;
+    while (p < end) {
+        uint64_t key;
+        if (!varint(p, end, key)) return false;
+        const int fn = (int)(key >> 3), wt = (int)(key & 7);
+        if (wt == 0) {
+            uint64_t v;
+            if (!varint(p, end, v)) return false;
+            f(fn, wt, v, Span{});
+        } else if (wt == 2) {
+            uint64_t len;
+            if (!varint(p, end, len) || len > (uint64_t)(end - p)) return false;
+            f(fn, wt, 0, Span{p, (size_t)len});
+            p += len;
+        } else if (wt == 1) {
+            if (end - p < 8) return false;
+            p += 8;
+        } else if (wt == 5) {
+            if (end - p < 4) return false;
+            p += 4;
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+
+struct Example {
+    Span image, slide;
+    int64_t loc_x = 0, loc_y = 0;
+};
+
+bool parse_example(Span rec, Example& ex) {
+    bool ok = true;
+    ok &= fields(rec, [&](int fn, int, uint64_t, Span features) {
+        if (fn != 1) return;
+        ok &= fields(features, [&](int fn2, int, uint64_t, Span entry) {
+            if (fn2 != 1) return;
+            Span key, feat;
+            ok &= fields(entry, [&](int fn3, int, uint64_t, Span v) {
+                if (fn3 == 1) key = v;
+                else if (fn3 == 2) feat = v;
+            });
+            if (!key.p || !feat.p) return;
+            const std::string k((const char*)key.p, key.n);
+            ok &= fields(feat, [&](int kind, int, uint64_t, Span lst) {
+                if (kind == 1) {               // BytesList
+                    Span first;
+                    ok &= fields(lst, [&](int f, int, uint64_t, Span v) { if (f == 1 && !first.p) first = v; });
+                    if (k == "image_raw") ex.image = first;
+                    else if (k == "slide") ex.slide = first;
+                } else if (kind == 3) {        // Int64List, packed or not
+                    int64_t val = 0;
+                    bool have = false;
+                    ok &= fields(lst, [&](int f, int wt, uint64_t v, Span packed) {
+                        if (f != 1 || have) return;
+                        if (wt == 0) { val = (int64_t)v; have = true; }
+                        else {
+                            const uint8_t* q = packed.p;
+                            uint64_t x;
+                            if (varint(q, packed.p + packed.n, x)) { val = (int64_t)x; have = true; }
+                        }
+                    });
+                    if (k == "loc_x") ex.loc_x = val;
+                    else if (k == "loc_y") ex.loc_y = val;
+                }
+            });
+        });
+    });
+    return ok;
+}
+
+// ---- PNG ------------------------------------------------------------------------------------
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int image_format(Span img) {
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (img.n >= 8 && memcmp(img.p, sig, 8) == 0) return BQIO_IMG_PNG;
+    if (img.n >= 3 && img.p[0] == 0xFF && img.p[1] == 0xD8 && img.p[2] == 0xFF) return BQIO_IMG_JPEG;
+    return BQIO_IMG_UNKNOWN;
+}
+
+inline uint8_t paeth(int a, int b, int c) {
+    const int p = a + b - c;
+    const int pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+    return (uint8_t)((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c));
+}
+
+// returns BQIO_OK / BQIO_ERR_FORMAT (wrong size) / BQIO_ERR_UNSUPPORTED / BQIO_ERR_CORRUPT
+int decode_png(Span img, int px, uint8_t* out, std::vector<uint8_t>& zbuf, std::vector<uint8_t>& raw) {
+    const uint8_t* p = img.p + 8;
+    const uint8_t* end = img.p + img.n;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    uint8_t pal[256][3];
+    int npal = 0;
+    zbuf.clear();
+    bool seen_end = false;
+    while (end - p >= 12 && !seen_end) {
+        const uint32_t len = be32(p);
+        if ((uint64_t)len + 12 > (uint64_t)(end - p)) return BQIO_ERR_CORRUPT;
+        const uint8_t* type = p + 4;
+        const uint8_t* data = p + 8;
+        if (!memcmp(type, "IHDR", 4)) {
+            if (len < 13) return BQIO_ERR_CORRUPT;
+            w = be32(data); h = be32(data + 4);
+            depth = data[8]; ctype = data[9]; interlace = data[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            npal = (int)(len / 3 < 256 ? len / 3 : 256);
+            memcpy(pal, data, (size_t)npal * 3);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            zbuf.insert(zbuf.end(), data, data + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            seen_end = true;
+        }
+        p += (size_t)len + 12;
+    }
+    if (ctype < 0 || zbuf.empty()) return BQIO_ERR_CORRUPT;
+    if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 6))
+        return BQIO_ERR_UNSUPPORTED;
+    if ((int)w != px || (int)h != px) return BQIO_ERR_FORMAT;
+    const int bpp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : 4;
+    const size_t stride = (size_t)w * bpp;
+    raw.resize((stride + 1) * h);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, zbuf.data(), (uLong)zbuf.size()) != Z_OK || got != raw.size())
+        return BQIO_ERR_CORRUPT;
+    // unfilter in place (the filter byte stays in front of every scanline)
+    for (uint32_t y = 0; y < h; ++y) {
+        uint8_t* cur = raw.data() + (stride + 1) * y + 1;
+        const uint8_t* up = y ? cur - (stride + 1) : nullptr;
+        const int ft = cur[-1];
+        switch (ft) {
+        case 0: break;
+        case 1: for (size_t i = bpp; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]); break;
+        case 2: if (up) for (size_t i = 0; i < stride; ++i) cur[i] = (uint8_t)(cur[i] + up[i]); break;
+        case 3:
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                cur[i] = (uint8_t)(cur[i] + ((a + b) >> 1));
+            }
+            break;
+        case 4:
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0;
+                const int c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+                cur[i] = (uint8_t)(cur[i] + paeth(a, b, c));
+            }
+            break;
+        default: return BQIO_ERR_CORRUPT;
+        }
+        uint8_t* o = out + (size_t)y * w * 3;
+        if (ctype == 2) {
+            memcpy(o, cur, stride);
+        } else if (ctype == 6) {
+            for (uint32_t x = 0; x < w; ++x) { o[3 * x] = cur[4 * x]; o[3 * x + 1] = cur[4 * x + 1]; o[3 * x + 2] = cur[4 * x + 2]; }
+        } else if (ctype == 0) {
+            for (uint32_t x = 0; x < w; ++x) o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = cur[x];
+        } else {
+            for (uint32_t x = 0; x < w; ++x) {
+                const int idx = cur[x];
+                if (idx >= npal) return BQIO_ERR_CORRUPT;
+                o[3 * x] = pal[idx][0]; o[3 * x + 1] = pal[idx][1]; o[3 * x + 2] = pal[idx][2];
+            }
+        }
+    }
+    return BQIO_OK;
+}
+
+}  // namespace
+
+struct bqio_reader {
+    int fd = -1;
+    const uint8_t* base = nullptr;
+    size_t size = 0;
+    std::vector<Span> records;
+    std::string err;
+};
+
+extern "C" {
+
+const char* bqio_last_error(bqio_reader* r) { return r ? r->err.c_str() : g_open_error.c_str(); }
+
+uint32_t bqio_masked_crc32c(const uint8_t* data, size_t len) {
+    crc_init();
+    return masked(crc32c(data, len));
+}
+
+bqio_reader* bqio_open(const char* path, int verify) {
+    crc_init();
+    if (!path) { g_open_error = "path is null"; return nullptr; }
+    bqio_reader* r = new (std::nothrow) bqio_reader();
+    if (!r) { g_open_error = "out of memory"; return nullptr; }
+    auto fail = [&](const std::string& m) { g_open_error = std::string(path) + ": " + m; bqio_close(r); return nullptr; };
+    r->fd = open(path, O_RDONLY);
+    if (r->fd < 0) return fail("cannot open");
+    struct stat st;
+    if (fstat(r->fd, &st) != 0) return fail("cannot stat");
+    r->size = (size_t)st.st_size;
+    if (r->size) {
+        void* m = mmap(nullptr, r->size, PROT_READ, MAP_PRIVATE, r->fd, 0);
+        if (m == MAP_FAILED) return fail("cannot map");
+        r->base = (const uint8_t*)m;
+    }
+    size_t off = 0;
+    while (off < r->size) {
+        if (r->size - off < 12) return fail("truncated record header");
+        uint64_t len;
+        uint32_t lcrc;
+        memcpy(&len, r->base + off, 8);
+        memcpy(&lcrc, r->base + off + 8, 4);
+        if (verify != BQIO_VERIFY_NONE && masked(crc32c(r->base + off, 8)) != lcrc) return fail("corrupt record length");
+        if (len > r->size - off - 12 || r->size - off - 12 - len < 4) return fail("truncated record");
+        const uint8_t* data = r->base + off + 12;
+        if (verify == BQIO_VERIFY_FULL) {
+            uint32_t dcrc;
+            memcpy(&dcrc, data + len, 4);
+            if (masked(crc32c(data, (size_t)len)) != dcrc) return fail("corrupt record data");
+        }
+        r->records.push_back(Span{data, (size_t)len});
+        off += 12 + (size_t)len + 4;
+    }
+    return r;
+}
+
+void bqio_close(bqio_reader* r) {
+    if (!r) return;
+    if (r->base) munmap((void*)r->base, r->size);
+    if (r->fd >= 0) close(r->fd);
+    delete r;
+}
+
+int64_t bqio_count(bqio_reader* r) { return r ? (int64_t)r->records.size() : BQIO_ERR_ARG; }
+
+int bqio_slide_name(bqio_reader* r, char* buf, int buflen) {
+    if (!r || !buf || buflen <= 0) return BQIO_ERR_ARG;
+    buf[0] = 0;
+    if (r->records.empty()) return 0;
+    Example ex;
+    if (!parse_example(r->records[0], ex)) { r->err = "malformed Example"; return BQIO_ERR_CORRUPT; }
+    const int n = (int)(ex.slide.n < (size_t)(buflen - 1) ? ex.slide.n : (size_t)(buflen - 1));
+    if (n) memcpy(buf, ex.slide.p, (size_t)n);
+    buf[n] = 0;
+    return n;
+}
+
+int bqio_image_bytes(bqio_reader* r, int64_t index, const uint8_t** data, size_t* len) {
+    if (!r || index < 0 || index >= (int64_t)r->records.size() || !data || !len) return BQIO_ERR_ARG;
+    Example ex;
+    if (!parse_example(r->records[(size_t)index], ex) || !ex.image.p) { r->err = "record without image_raw"; return BQIO_ERR_CORRUPT; }
+    *data = ex.image.p;
+    *len = ex.image.n;
+    return BQIO_OK;
+}
+
+int bqio_image_format(bqio_reader* r, int64_t index) {
+    const uint8_t* d;
+    size_t n;
+    const int e = bqio_image_bytes(r, index, &d, &n);
+    return e < 0 ? e : image_format(Span{d, n});
+}
+
+int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc, int n_threads,
+                int64_t* bad_index) {
+    if (!r || first < 0 || count < 0 || first + count > (int64_t)r->records.size() || tile_px <= 0 || (count && !out))
+        return BQIO_ERR_ARG;
+    if (bad_index) *bad_index = -1;
+    if (count == 0) return BQIO_OK;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > count) n_threads = (int)count;
+    std::atomic<int64_t> next(0);
+    std::atomic<int> status(BQIO_OK);
+    std::atomic<int64_t> bad(-1);
+    const size_t tile_bytes = (size_t)tile_px * tile_px * 3;
+    auto work = [&]() {
+        std::vector<uint8_t> zbuf, raw;
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= count || status.load() != BQIO_OK) return;
+            Example ex;
+            int e = BQIO_OK;
+            if (!parse_example(r->records[(size_t)(first + i)], ex) || !ex.image.p) e = BQIO_ERR_CORRUPT;
+            else if (image_format(ex.image) != BQIO_IMG_PNG) e = BQIO_ERR_UNSUPPORTED;
+            else e = decode_png(ex.image, tile_px, out + (size_t)i * tile_bytes, zbuf, raw);
+            if (e != BQIO_OK) {
+                int expect = BQIO_OK;
+                if (status.compare_exchange_strong(expect, e)) bad.store(first + i);
+                return;
+            }
+            if (loc) { loc[2 * i] = ex.loc_x; loc[2 * i + 1] = ex.loc_y; }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    const int e = status.load();
+    if (e != BQIO_OK) {
+        if (bad_index) *bad_index = bad.load();
+        r->err = e == BQIO_ERR_UNSUPPORTED ? "image_raw is not a PNG this decoder handles"
+                 : e == BQIO_ERR_FORMAT    ? "tile size differs from tile_px"
+                                           : "corrupt record or PNG";
+    }
+    return e;
+}
+
+}  // extern "C"

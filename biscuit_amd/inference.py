@@ -36,17 +36,28 @@ class Slide:
         return t
 
 
-def slides_from_tfrecords(paths, labels, patients=None, tile_px=299):
+def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None):
     """One ``Slide`` per ``*.tfrecords`` file (Slideflow writes one file per slide).  Tiles are
-    decoded lazily when the slide's turn comes; only the record headers are scanned up front.
-    labels: {slide name (file stem): 0/1}."""
+    decoded lazily when the slide's turn comes (``evaluate`` decodes one slide ahead on a host thread);
+    only the record headers are scanned up front.  labels: {slide name (file stem): 0/1}.
+    ``pinned`` (default: when a GPU is present) decodes into page-locked memory so the H2D copy is
+    asynchronous and overlaps the next slide's decode."""
     import os
     from . import tfrecord
+    if pinned is None:
+        pinned = torch.cuda.is_available()
     out = []
     for path in paths:
         name = os.path.splitext(os.path.basename(path))[0]
-        loader = (lambda pth=path: tfrecord.read_slide(pth, tile_px)[1])
-        out.append(Slide(name, loader, tfrecord.count_records(path), y_true=int(labels.get(name, 0)),
+        count = tfrecord.count_records(path)
+
+        def loader(pth=path, n=count):
+            if pinned and n:
+                t = torch.empty((n, tile_px, tile_px, 3), dtype=torch.uint8, pin_memory=True)
+                tfrecord.read_slide(pth, tile_px, out=t.numpy())
+                return t
+            return tfrecord.read_slide(pth, tile_px)[1]
+        out.append(Slide(name, loader, count, y_true=int(labels.get(name, 0)),
                          patient=(patients or {}).get(name)))
     return out
 
@@ -146,9 +157,20 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 ([rs] if rs.shape[0] else []), ([rg] if rg.shape[0] else [])
             pend_n = rest.shape[0]
 
+    # slides whose tiles come from a loader (TFRecords) are decoded one slide ahead on a host thread:
+    # the native decoder releases the GIL, so decode, H2D copy and the GPU work of the previous slide overlap
+    from concurrent.futures import ThreadPoolExecutor
+    lazy = any(callable(slides[si].tiles) for si in mine)
+    prefetch = ThreadPoolExecutor(1) if lazy else None
+    pending = prefetch.submit(slides[mine[0]].load) if prefetch and mine else None
     for li, si in enumerate(mine):
         s = slides[si]
-        t = _to_device(s.load(), dev)
+        if prefetch:
+            loaded = pending.result()
+            pending = prefetch.submit(slides[mine[li + 1]].load) if li + 1 < len(mine) else None
+        else:
+            loaded = s.load()
+        t = _to_device(loaded, dev)
         assert t.shape[0] == s.n_tiles, (s.name, t.shape, s.n_tiles)
         if s.n_tiles == 0:
             continue
@@ -163,6 +185,8 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 rows_loc.append(np.asarray(s.loc))
         flush()
     flush(final=True)
+    if prefetch:
+        prefetch.shutdown()
 
     if pool:
         pool.synchronize()

@@ -6,7 +6,9 @@ them: the container is length-prefixed records
     uint64 length | uint32 masked_crc32c(length) | bytes[length] | uint32 masked_crc32c(data)
 each holding a ``tf.train.Example`` protobuf with features ``slide`` (bytes), ``image_raw``
 (bytes: PNG or JPEG), ``loc_x`` / ``loc_y`` (int64).  Only that subset of protobuf is parsed.
-Image decoding uses Pillow on the host.  A writer for the same wire format is included so the
+PNG tiles are decoded by the native reader (libbiscuit_io.so: C++ framing, protobuf subset, zlib inflate +
+unfilter, a pool of host threads; include/biscuit_io.h); Pillow handles JPEG payloads and is the fallback
+when the library is not built.  A writer for the same wire format is included so the
 reader can be tested without TensorFlow (there are no real TFRecords in this environment).
 """
 import io
@@ -163,8 +165,27 @@ def decode_image(raw, tile_px=299):
     return img
 
 
-def read_slide(path, tile_px=299, verify='length'):
-    """One slide's TFRecord -> (slide name, tiles uint8 [T,px,px,3], loc int64 [T,2])."""
+def read_slide(path, tile_px=299, verify='length', native=None, out=None, threads=None):
+    """One slide's TFRecord -> (slide name, tiles uint8 [T,px,px,3], loc int64 [T,2]).
+
+    ``native=None`` uses libbiscuit_io.so (C++ framing / protobuf / PNG decode on a thread pool) when it
+    is built and falls back to the pure-Python reader otherwise; records the native decoder does not
+    handle (JPEG) are decoded with Pillow either way.  ``out``: optional uint8 buffer [T,px,px,3] to
+    decode into (pinned memory for an overlapped H2D copy)."""
+    if native is None:
+        from . import tfrecord_native
+        native = tfrecord_native.available()
+    if native:
+        from . import tfrecord_native as tn
+        with tn.NativeReader(path, verify) as r:
+            n = len(r)
+            if n == 0:
+                return r.slide, np.zeros((0, tile_px, tile_px, 3), np.uint8), np.zeros((0, 2), np.int64)
+            try:
+                tiles, locs = r.decode(0, n, tile_px, out=out, threads=threads)
+                return r.slide, tiles, locs
+            except tn.UnsupportedImage:
+                name = r.slide            # JPEG payloads: Pillow below
     tiles, locs, name = [], [], None
     for payload in read_records(path, verify):
         ex = parse_example(payload)
@@ -174,7 +195,11 @@ def read_slide(path, tile_px=299, verify='length'):
         locs.append((ex.get('loc_x', [0])[0], ex.get('loc_y', [0])[0]))
     if not tiles:
         return name, np.zeros((0, tile_px, tile_px, 3), np.uint8), np.zeros((0, 2), np.int64)
-    return name, np.stack(tiles), np.asarray(locs, dtype=np.int64)
+    tiles = np.stack(tiles)
+    if out is not None:
+        out[...] = tiles
+        tiles = out
+    return name, tiles, np.asarray(locs, dtype=np.int64)
 
 
 # ---- writer (tests / synthetic datasets) ---------------------------------------------

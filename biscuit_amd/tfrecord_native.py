@@ -1,0 +1,135 @@
+"""ctypes binding of libbiscuit_io.so (include/biscuit_io.h): the native TFRecord / PNG reader.
+
+`NativeReader(path)` indexes one slide's TFRecord; `decode(first, count)` returns uint8 tiles
+``[count, px, px, 3]`` decoded by a pool of host threads, optionally straight into a caller-supplied
+(e.g. pinned) buffer so the H2D copy of one batch overlaps the decode of the next.  JPEG payloads are
+not decoded natively: `decode` raises `UnsupportedImage` and the caller (tfrecord.read_slide) decodes
+those records with Pillow.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libbiscuit_io.so')
+
+VERIFY = {None: 0, False: 0, 'none': 0, 'length': 1, 'full': 2}
+IMG_PNG, IMG_JPEG = 1, 2
+ERR_UNSUPPORTED = -5
+ERR_FORMAT = -3
+
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+ABI = {
+    'bqio_open': (_vp, [C.c_char_p, _i]),
+    'bqio_close': (None, [_vp]),
+    'bqio_last_error': (C.c_char_p, [_vp]),
+    'bqio_count': (_i64, [_vp]),
+    'bqio_slide_name': (_i, [_vp, C.c_char_p, _i]),
+    'bqio_image_format': (_i, [_vp, _i64]),
+    'bqio_image_bytes': (_i, [_vp, _i64, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
+    'bqio_decode': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
+    'bqio_masked_crc32c': (C.c_uint32, [C.c_char_p, C.c_size_t]),
+}
+
+
+def load(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError(f'{path} not found; build it with `make -C biscuit_amd/csrc`')
+    lib = C.CDLL(path)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+class UnsupportedImage(ValueError):
+    def __init__(self, index):
+        super().__init__(f'record {index}: image_raw is not a PNG the native decoder handles')
+        self.index = index
+
+
+def default_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+class NativeReader:
+    def __init__(self, path, verify='length'):
+        self._lib = lib()
+        self._h = self._lib.bqio_open(os.fsencode(path), VERIFY[verify])
+        if not self._h:
+            raise IOError(self._lib.bqio_last_error(None).decode())
+        self.path = path
+
+    def close(self):
+        if self._h:
+            self._lib.bqio_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    def __len__(self):
+        return int(self._lib.bqio_count(self._h))
+
+    @property
+    def slide(self):
+        buf = C.create_string_buffer(512)
+        n = self._lib.bqio_slide_name(self._h, buf, 512)
+        if n < 0:
+            raise IOError(self._lib.bqio_last_error(self._h).decode())
+        return buf.value.decode() if n else None
+
+    def image_format(self, index):
+        return int(self._lib.bqio_image_format(self._h, index))
+
+    def image_bytes(self, index):
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        if self._lib.bqio_image_bytes(self._h, index, C.byref(p), C.byref(n)) != 0:
+            raise IOError(self._lib.bqio_last_error(self._h).decode())
+        return C.string_at(p, n.value)
+
+    def decode(self, first=0, count=None, tile_px=299, out=None, threads=None):
+        """-> (tiles uint8 [count,px,px,3], loc int64 [count,2]).  `out`: optional C-contiguous uint8
+        array / tensor-backed numpy view to decode into (e.g. pinned memory)."""
+        total = len(self)
+        count = total - first if count is None else count
+        if out is None:
+            out = np.empty((count, tile_px, tile_px, 3), np.uint8)
+        assert out.dtype == np.uint8 and out.flags['C_CONTIGUOUS'] and out.size == count * tile_px * tile_px * 3
+        loc = np.zeros((count, 2), np.int64)
+        bad = _i64(-1)
+        e = self._lib.bqio_decode(self._h, first, count, tile_px, out.ctypes.data, loc.ctypes.data,
+                                  threads or default_threads(), C.byref(bad))
+        if e == ERR_UNSUPPORTED:
+            raise UnsupportedImage(bad.value)
+        if e == ERR_FORMAT:       # same exception the Python reader raises for a tile of the wrong size
+            raise ValueError(f'{self.path}: record {bad.value}: tile size differs from {(tile_px, tile_px, 3)}')
+        if e != 0:
+            raise IOError(f'{self.path}: {self._lib.bqio_last_error(self._h).decode()} (record {bad.value})')
+        return out, loc

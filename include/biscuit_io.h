@@ -1,0 +1,61 @@
+/* biscuit_io.h -- C ABI of libbiscuit_io.so: host-side reader of Slideflow tile TFRecords
+ * (SURVEY.md section 8f row 1), the data format in front of the staging kernel.
+ *
+ * Replaces, for the hot path's input side, what the reference gets from Slideflow's tf.data
+ * pipeline (`Project.evaluate(...)`, experiment.py:917-922; tiles are PNG, 299 px / 302 um,
+ * configure.py:118-124): TFRecord framing
+ *     uint64 length | uint32 masked_crc32c(length) | bytes[length] | uint32 masked_crc32c(data)
+ * a `tf.train.Example` holding `slide` (bytes), `image_raw` (bytes, PNG or JPEG), `loc_x`,
+ * `loc_y` (int64), and the PNG decode (zlib inflate + scanline unfilter written here; the image
+ * has no libpng).  JPEG payloads are reported, not decoded: the caller hands those bytes to its
+ * own decoder.  No TensorFlow, no Slideflow.  Plain pointers and sizes only.
+ */
+#ifndef BISCUIT_IO_H
+#define BISCUIT_IO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bqio_reader bqio_reader;
+
+enum { BQIO_OK = 0, BQIO_ERR_ARG = -1, BQIO_ERR_IO = -2, BQIO_ERR_FORMAT = -3, BQIO_ERR_CORRUPT = -4,
+       BQIO_ERR_UNSUPPORTED = -5 };
+enum { BQIO_VERIFY_NONE = 0, BQIO_VERIFY_LENGTH = 1, BQIO_VERIFY_FULL = 2 };
+enum { BQIO_IMG_UNKNOWN = 0, BQIO_IMG_PNG = 1, BQIO_IMG_JPEG = 2 };
+
+/* Map the file and index its records (checking the CRCs `verify` asks for).  NULL on failure;
+ * bqio_last_error(NULL) then says why. */
+bqio_reader* bqio_open(const char* path, int verify);
+void bqio_close(bqio_reader* r);
+const char* bqio_last_error(bqio_reader* r);
+
+/* Number of records (= tiles of the slide). */
+int64_t bqio_count(bqio_reader* r);
+
+/* `slide` feature of the first record, NUL-terminated into buf; returns its length or <0. */
+int bqio_slide_name(bqio_reader* r, char* buf, int buflen);
+
+/* Format of record `index`'s image_raw payload (BQIO_IMG_*), and a pointer to / length of the
+ * payload inside the mapping (valid until bqio_close). */
+int bqio_image_format(bqio_reader* r, int64_t index);
+int bqio_image_bytes(bqio_reader* r, int64_t index, const uint8_t** data, size_t* len);
+
+/* Decode records [first, first+count): RGB uint8 tiles into out[count][tile_px][tile_px][3],
+ * loc_x/loc_y into loc[count][2] (may be NULL), with n_threads worker threads.  PNG only
+ * (8-bit grey, RGB, palette, RGBA -- alpha dropped; non-interlaced).  A JPEG or otherwise
+ * unsupported payload returns BQIO_ERR_UNSUPPORTED and leaves the index of the first such record
+ * in *bad_index (may be NULL); a tile of the wrong size returns BQIO_ERR_FORMAT. */
+int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc,
+                int n_threads, int64_t* bad_index);
+
+/* masked CRC-32C of a buffer (the TFRecord checksum), exported for tests and writers. */
+uint32_t bqio_masked_crc32c(const uint8_t* data, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
