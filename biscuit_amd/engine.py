@@ -9,6 +9,7 @@ HIP stream.  All arithmetic happens in ``libbiscuit_hip.so``.
 ``results.py:234,257-258``: ``interface(batch) -> (mean[B,2], std[B,2])``.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np

@@ -39,17 +39,42 @@ def main():
         lines += ['', f'Total GPU kernel time in trace: {tot/1e6:.1f} ms', '']
     trace = newest(os.path.join(src, 'trace', '*', '*_kernel_trace.csv'))
     if trace:
+        rows = list(csv.DictReader(open(trace[0])))
+        iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows)
+        tot = sum(b - a for a, b in iv)
+        uni, (cs, ce) = 0, iv[0]
+        for a, b in iv[1:]:
+            if a > ce:
+                uni += ce - cs
+                cs, ce = a, b
+            else:
+                ce = max(ce, b)
+        uni += ce - cs
+        queues = len({r['Queue_Id'] for r in rows})
+        lines += [f'Two-stream run: {queues} hardware queue(s); sum of kernel durations {tot/1e6:.1f} ms, union of their '
+                  f'intervals {uni/1e6:.1f} ms: kernels of the two batches in flight overlap, so a launch\'s start..end '
+                  'interval in this trace includes time spent waiting for CUs.', '']
+    trace1 = newest(os.path.join(src, 'trace1', '*', '*_kernel_trace.csv'))
+    per_launch = trace1 or trace
+    if per_launch:
         # the same kernel symbol serves several layers: split by grid size so a layer's average
         # launch duration can be compared with bench.py's event-timed figure
         acc = defaultdict(lambda: [0, 0.0])
-        for r in csv.DictReader(open(trace[0])):
+        for r in csv.DictReader(open(per_launch[0])):
             k = (short(r['Kernel_Name']), int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1))
             acc[k][0] += 1
             acc[k][1] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
-        lines += ['## Per (kernel, workgroups) average launch duration (from the kernel trace)', '',
+        which = ('the same command with `--streams 1` (no overlap between launches; this is what bench.py\'s '
+                 'per-launch HIP-event durations are comparable with)') if trace1 else 'the two-stream trace'
+        lines += ['## Per (kernel, workgroups) average launch duration', '', f'From {which}.', '',
                   '| kernel | workgroups | launches | avg us | total ms |', '|---|---:|---:|---:|---:|']
         for (kn, wg), (n, dur) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:16]:
             lines.append(f'| `{kn}` | {wg} | {n} | {dur/n/1e3:.1f} | {dur/1e6:.2f} |')
+        dom = [(n, dur) for (kn, wg), (n, dur) in acc.items() if 'sepconv_pipe_kernel' in kn and wg == 963]
+        if dom:
+            n = sum(x[0] for x in dom); dur = sum(x[1] for x in dom)
+            lines += ['', f'Dominant layer class (sepconv 728->728 @19x19, 963 workgroups): {n} launches, '
+                          f'average {dur/n/1e3:.1f} us.']
         lines.append('')
     pmc = {}
     for key in ('pmc_fetch', 'pmc_write'):
