@@ -117,7 +117,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--cpu-tiles', type=int, default=8)
-    ap.add_argument('--streams', type=int, default=2, help='HIP streams (independent contexts) batches alternate over')
+    ap.add_argument('--streams', type=int, default=4,
+                    help='batches in flight: independent contexts on HIP streams that own disjoint groups of XCDs (2 or 4)')
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env('cuda')

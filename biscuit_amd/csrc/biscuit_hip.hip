@@ -544,6 +544,7 @@ bq_ctx* bq_create(int device_id, const bq_config* cfg) {
     c->cfg = *cfg;
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("BQ_NUM_CUS")) { const int v = atoi(e); if (v > 0) c->num_cus = v; }   // persistent-grid sizing (experiments)
     {   // sRGB -> linear table, float64 evaluation rounded to float32 (oracle/stain.py: same contract)
         float lut[256];
         for (int v = 0; v < 256; ++v) {
@@ -665,6 +666,21 @@ int bq_stain_lab_stats(bq_ctx* c, const uint8_t* d_tiles, int n, float* d_stats6
     hipStream_t s = (hipStream_t)stream;
     if (launch_reinhard(d_tiles, n, 299, c->d_srgb_lut, kReinhardConsts, nullptr, nullptr, nullptr, d_stats6, s))
         return fail(c, BQ_ERR_HIP, "lab stats launch failed");
+    return BQ_OK;
+}
+
+int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, bq_stream_t* out) {
+    if (!c || !cu_mask || mask_words <= 0 || !out) return fail(c, BQ_ERR_ARG, "bq_stream_create_masked: bad argument");
+    hipStream_t s = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask));
+    *out = (bq_stream_t)s;
+    return BQ_OK;
+}
+
+int bq_stream_destroy(bq_ctx* c, bq_stream_t stream) {
+    if (!c || !stream) return fail(c, BQ_ERR_ARG, "bq_stream_destroy: bad argument");
+    HIPCHK(c, hipStreamDestroy((hipStream_t)stream));
     return BQ_OK;
 }
 

@@ -76,6 +76,12 @@ int bq_load_weights(bq_ctx* ctx, const void* host_blob, size_t nbytes);
 int bq_stage(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, void* d_out_nchw,
              bq_stream_t stream);
 
+/* A HIP stream restricted to the compute units whose bits are set in cu_mask (mask_words 32-bit
+ * words, bit i = CU i): lets two batches in flight own disjoint halves of the chip instead of
+ * interleaving workgroups on every CU.  No reference counterpart (scheduling only). */
+int bq_stream_create_masked(bq_ctx* ctx, const uint32_t* cu_mask, int mask_words, bq_stream_t* out_stream);
+int bq_stream_destroy(bq_ctx* ctx, bq_stream_t stream);
+
 /* K0, optional front half: the `reinhard_fast` stain normaliser hp.py:19 selects, applied to the
  * uint8 tile before the standardisation exactly where results.py:251-252 calls
  * interface.wsi_normalizer.rgb_to_rgb(image).  uint8 NHWC [n,px,px,3] -> uint8 NHWC; d_out may equal
