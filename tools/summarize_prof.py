@@ -21,8 +21,8 @@ def main():
     src, out = sys.argv[1], sys.argv[2]
     lines = [f'# rocprofv3 summary ({os.path.basename(src)})', '',
              'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 8 '
-             '--warmup 2 --no-cpu-baseline --no-profile` (plus two separate `--pmc` passes, FETCH_SIZE and '
-             'WRITE_SIZE, which do not fit one pass on gfx950).', '']
+             '--warmup 2 --no-cpu-baseline --no-profile` (the default: 4 batches in flight), the same with '
+             '`--streams 1`, plus two separate `--pmc` passes, FETCH_SIZE and WRITE_SIZE, which do not fit one pass on gfx950.', '']
     def newest(pattern):
         f = sorted(glob.glob(pattern), key=os.path.getmtime)
         return f[-1:] if f else []
@@ -51,9 +51,9 @@ def main():
                 ce = max(ce, b)
         uni += ce - cs
         queues = len({r['Queue_Id'] for r in rows})
-        lines += [f'Two-stream run: {queues} hardware queue(s); sum of kernel durations {tot/1e6:.1f} ms, union of their '
-                  f'intervals {uni/1e6:.1f} ms: kernels of the two batches in flight overlap, so a launch\'s start..end '
-                  'interval in this trace includes time spent waiting for CUs.', '']
+        lines += [f'Default run (several batches in flight on CU-masked streams): {queues} hardware queue(s); sum of kernel durations {tot/1e6:.1f} ms, union of their '
+                  f'intervals {uni/1e6:.1f} ms: kernels of the batches in flight run side by side on disjoint XCD groups, so a launch\'s '
+                  'start..end interval in this trace is its duration on a fraction of the chip.', '']
     trace1 = newest(os.path.join(src, 'trace1', '*', '*_kernel_trace.csv'))
     per_launch = trace1 or trace
     if per_launch:
