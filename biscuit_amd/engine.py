@@ -213,9 +213,8 @@ class Engine:
 
 
 class EnginePool:
-    """Round-robin pool of independent contexts, each on its own HIP stream, so consecutive
-    batches overlap on the GPU: one batch's launch tails, prologues and store drains fill under the
-    next batch's kernels (measured +8.6 % tiles/s with 2 streams at batch 256; a third adds nothing).
+    """Round-robin pool of independent contexts, each on its own HIP stream, so consecutive batches are in
+    flight together; by default every stream owns a disjoint group of XCDs (see __init__ and DESIGN.md).
     Every context owns its weights copy and workspace; results are independent of the stream used."""
 
     def __init__(self, weights, n_streams=2, cu_split='contig', **kw):
@@ -229,32 +228,41 @@ class EnginePool:
         # 'xcd', 'interleave' (experiments) or None / BQ_CU_SPLIT=none for plain streams.
         split = os.environ.get('BQ_CU_SPLIT', cu_split)
         split = None if split in (None, '', 'none', '0') else split
+        self.cu_split = None
         if split and len(self.engines) >= 2:
-            import ctypes
-            self._masked = []
-            self.streams = []
-            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-            for k, eng in enumerate(self.engines):
-                bits = [0] * ((ncu + 31) // 32)
-                for cu in range(ncu):
-                    nst = len(self.engines)
-                    if split == 'contig':
-                        mine = cu * nst // ncu == k
-                    elif split == 'xcd':          # bit i -> XCD i % 8
-                        mine = (cu % 8) * nst // 8 == k
-                    else:
-                        mine = (cu % nst) == k
-                    if mine:
-                        bits[cu // 32] |= 1 << (cu % 32)
-                arr = (ctypes.c_uint32 * len(bits))(*bits)
-                h = ctypes.c_void_p()
-                eng._check(eng._lib.bq_stream_create_masked(eng._ctx, arr, len(bits), ctypes.byref(h)))
-                self._masked.append((eng, h))
-                self.streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+            try:
+                self._masked_streams(split, dev)
+                self.cu_split = split
+            except BiscuitHipError as e:       # scheduling aid only: plain streams compute the same results
+                import warnings
+                warnings.warn(f'CU-masked streams unavailable ({e}); using plain HIP streams')
+                self.streams = [torch.cuda.Stream(device=dev) for _ in self.engines]
         else:
             self.streams = [torch.cuda.Stream(device=dev) for _ in self.engines]
         self.device = dev
         self.hp = self.engines[0].hp
+
+    def _masked_streams(self, split, dev):
+        self._masked = []
+        self.streams = []
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        nst = len(self.engines)
+        for k, eng in enumerate(self.engines):
+            bits = [0] * ((ncu + 31) // 32)
+            for cu in range(ncu):
+                if split == 'contig':
+                    mine = cu * nst // ncu == k
+                elif split == 'xcd':              # bit i -> XCD i % 8 (experiment)
+                    mine = (cu % 8) * nst // 8 == k
+                else:
+                    mine = (cu % nst) == k
+                if mine:
+                    bits[cu // 32] |= 1 << (cu % 32)
+            arr = (C.c_uint32 * len(bits))(*bits)
+            h = C.c_void_p()
+            eng._check(eng._lib.bq_stream_create_masked(eng._ctx, arr, len(bits), C.byref(h)))
+            self._masked.append((eng, h))
+            self.streams.append(torch.cuda.ExternalStream(h.value, device=dev))
 
     def __len__(self):
         return len(self.engines)
