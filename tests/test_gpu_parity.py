@@ -305,3 +305,26 @@ def test_engine_pool_two_streams_bit_identical(weights):
     assert np.array_equal(single.slide_pred, pooled.slide_pred, equal_nan=True)
     assert np.array_equal(single.slide_unc, pooled.slide_unc, equal_nan=True)
     assert list(single.slide_count) == list(pooled.slide_count) == counts
+
+
+@pytest.mark.gpu
+def test_heatmap_front_end(engines, oracles, tiles):
+    """results.py:216-265: the grid layout, the uncertainty mask and the incl/excl split."""
+    from biscuit_amd.heatmap import Heatmap
+    n = min(6, tiles.shape[0])
+    grid = np.array([[0, 0], [2, 0], [1, 1], [3, 1], [0, 2], [3, 2]])[:n]
+    hm = Heatmap(engines['f32'], tiles[:n], grid, grid_shape=(3, 4), mc_n=4, seed=9, batch=4)
+    rm, rs = oracles['f32'].mc_predict(tiles[:n], 4, 9, mode='head')
+    assert hm.logits.shape == (3, 4, 2)
+    assert np.abs(hm.logits[grid[:, 1], grid[:, 0]] - rm).max() < 1e-4
+    assert np.abs(hm.uncertainty[grid[:, 1], grid[:, 0]] - rs).max() < 1e-4
+    assert (hm.logits[0, 1] == -1).all()                       # empty cell
+    thr = float(np.median(rs[:, 0]))
+    incl, excl = hm.split_by_uncertainty(thr)
+    assert sorted(i for i, _ in incl + excl) == list(range(n))
+    assert all(rs[i, 0] > thr - 1e-4 for i, _ in excl) and all(rs[i, 0] <= thr + 1e-4 for i, _ in incl)
+    assert incl[0][1].endswith(f'-{grid[incl[0][0]][0]}-{grid[incl[0][0]][1]}.png')
+    mask = hm.mask_uncertain(thr)
+    assert mask.sum() == len(excl) and (hm.logits[mask] == -1).all()
+    with pytest.raises(ValueError):
+        Heatmap(engines['f32'], tiles[:2], [[0, 0]], mc_n=2)
