@@ -545,15 +545,39 @@ bq_ctx* bq_create(int device_id, const bq_config* cfg) {
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("BQ_NUM_CUS")) { const int v = atoi(e); if (v > 0) c->num_cus = v; }   // persistent-grid sizing (experiments)
-    {   // sRGB -> linear table, float64 evaluation rounded to float32 (oracle/stain.py: same contract)
-        float lut[256];
+    {   // tables of the Reinhard normaliser (oracle/stain.py states the same arithmetic):
+        // [0,256)   sRGB -> linear, float64 evaluation rounded to float32
+        // [256,511) linear -> 8-bit sRGB as 255 switching points: entry v-1 is the smallest float32 c for which
+        //           clip(trunc(255 * clip(gamma(c), 0, 1)), 0, 255) >= v, gamma(c) = c > 0.0031308 ?
+        //           1.055f * float(pow(double(c), 1/2.4)) - 0.055f : 12.92f * c, found by bisection on the
+        //           float bit pattern (the function is monotone)
+        float lut[512];
         for (int v = 0; v < 256; ++v) {
             const double x = (double)v / 255.0;
             lut[v] = (float)(x > 0.04045 ? std::pow((x + 0.055) / 1.055, 2.4) : x / 12.92);
         }
+        auto level = [](float cf) {
+            float g;
+            if (cf > 0.0031308f) { const float p = (float)std::pow((double)cf, 1.0 / 2.4); g = 1.055f * p - 0.055f; }
+            else g = cf * 12.92f;
+            g = g < 0.f ? 0.f : (g > 1.f ? 1.f : g);
+            const float t = truncf(g * 255.0f);
+            return (int)(t < 0.f ? 0.f : (t > 255.f ? 255.f : t));
+        };
+        for (int v = 1; v <= 255; ++v) {
+            uint32_t lo = 0, hi = 0x3F800000u;               // bit patterns of 0.0f and 1.0f; level(1.0f) = 255
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                float f;
+                memcpy(&f, &mid, 4);
+                if (level(f) >= v) hi = mid; else lo = mid + 1;
+            }
+            memcpy(&lut[256 + v - 1], &lo, 4);
+        }
+        lut[511] = 0.f;
         if (hipSetDevice(device_id) != hipSuccess || hipMalloc(&c->d_srgb_lut, sizeof lut) != hipSuccess ||
             hipMemcpy(c->d_srgb_lut, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) {
-            g_create_error = "cannot allocate the sRGB table";
+            g_create_error = "cannot allocate the sRGB tables";
             delete c;
             return nullptr;
         }

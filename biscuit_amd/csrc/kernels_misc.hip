@@ -489,7 +489,8 @@ __device__ __forceinline__ Lab rgb_to_lab(const float* __restrict__ lut, const R
 }
 
 #pragma clang fp contract(off)
-__device__ __forceinline__ void lab_to_rgb8(const ReinhardConst& k, float L, float a, float b, uint8_t* out) {
+__device__ __forceinline__ void lab_to_rgb8(const ReinhardConst& k, const float* __restrict__ thr, float L, float a,
+                                            float b, uint8_t* out) {
     const float fy = (L + 16.0f) / 116.0f;
     const float fx = a / 500.0f + fy;
     const float fz = fy - b / 200.0f;
@@ -503,16 +504,18 @@ __device__ __forceinline__ void lab_to_rgb8(const ReinhardConst& k, float L, flo
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float c = (k.minv[3 * i] * xyz[0] + k.minv[3 * i + 1] * xyz[1]) + k.minv[3 * i + 2] * xyz[2];
-        if (c > 0.0031308f) {
-            const float p = (float)pow((double)c, 1.0 / 2.4);
-            c = 1.055f * p - 0.055f;
-        } else {
-            c = c * 12.92f;
+        const float c = (k.minv[3 * i] * xyz[0] + k.minv[3 * i + 1] * xyz[1]) + k.minv[3 * i + 2] * xyz[2];
+        // out = clip(trunc(255 * clip(gamma(c), 0, 1)), 0, 255) is a monotone step function of c: the host
+        // evaluates the reference formula (float64 power rounded to float32, then float32 steps) once per
+        // output level and hands over the 255 switching points, so eight compares replace the power here
+        // and give the formula's result exactly.  thr[v-1] = smallest float32 c whose output is >= v.
+        int lo = 0, hi = 255;                       // invariant: out >= lo, out < hi + 1
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (c >= thr[mid - 1]) lo = mid; else hi = mid - 1;
         }
-        c = fminf(fmaxf(c, 0.0f), 1.0f);
-        const float v = truncf(c * 255.0f);
-        out[i] = (uint8_t)fminf(fmaxf(v, 0.0f), 255.0f);
+        out[i] = (uint8_t)lo;                       // NaN compares false everywhere -> 0, like the clip
     }
 }
 
@@ -524,9 +527,10 @@ __global__ void __launch_bounds__(512) reinhard_kernel(const uint8_t* __restrict
     const uint8_t* src = tiles + (size_t)blockIdx.x * npix * 3;
     const int tid = threadIdx.x, nt = blockDim.x;
     __shared__ float slut[256];
+    __shared__ float sthr[256];
     __shared__ double red[6][8];
     __shared__ float stat[6];
-    for (int i = tid; i < 256; i += nt) slut[i] = lut[i];
+    for (int i = tid; i < 256; i += nt) { slut[i] = lut[i]; sthr[i] = lut[256 + i]; }
     __syncthreads();
 
     double s[6] = {0, 0, 0, 0, 0, 0};
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(512) reinhard_kernel(const uint8_t* __restrict
         const float a = (v.a - stat[1]) * sc[1] + k.tgt_mean[1];
         const float b = (v.b - stat[2]) * sc[2] + k.tgt_mean[2];
         uint8_t rgb[3];
-        lab_to_rgb8(k, L, a, b, rgb);
+        lab_to_rgb8(k, sthr, L, a, b, rgb);
         o[3 * i] = rgb[0]; o[3 * i + 1] = rgb[1]; o[3 * i + 2] = rgb[2];
     }
 }
