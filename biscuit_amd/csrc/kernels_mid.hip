@@ -118,14 +118,6 @@ __device__ __forceinline__ void raw_store(const Raw3& r, const Loader& L, const 
         *reinterpret_cast<uint4*>(smem + buf_off + L.loff2) = fix<RELU>(r.c, (unsigned)(y + L.ry(2)) < (unsigned)H);
 }
 
-// D stage.  Wave `w` owns channels [c*64 + 8w, +8); lane = (row pair, column).
-__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-}
-
 #define STAMP(ev) do { if (stp && lane == 0) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // D stage on the matrix cores.  The depthwise conv of 16 channels x 16 pixels is nine MFMAs
