@@ -141,9 +141,10 @@ def main():
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     pool = [torch.randint(0, 256, (B, 299, 299, 3), dtype=torch.uint8, device=dev, generator=g)
             for _ in range(4)]
-    n_slides_local = (K * B + TILES_PER_SLIDE - 1) // TILES_PER_SLIDE + 1
+    NSTEP = max(K, Wm, 8)                         # the per-kernel pass and the full-mode leg run up to 8 steps
+    n_slides_local = (NSTEP * B + TILES_PER_SLIDE - 1) // TILES_PER_SLIDE + 1
     slide_of = [torch.div(torch.arange(s * B, (s + 1) * B, device=dev), TILES_PER_SLIDE,
-                          rounding_mode='floor').to(torch.int32) for s in range(max(K, Wm))]
+                          rounding_mode='floor').to(torch.int32) for s in range(NSTEP)]
     mean = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NS)]
     std = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NS)]
     tile_base = rank * K * B                      # global tile index of this rank's shard
@@ -154,10 +155,8 @@ def main():
                  torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
                  torch.zeros(n_slides_local, dtype=torch.int32, device=dev)) for _ in range(NS)]
 
-    single = [False]          # set by the calibration below: keep every batch on stream 0
-
     def step(i, acc, mode):
-        k = 0 if single[0] else i % NS
+        k = i % len(pool_e)           # batches in flight (set by the calibration below)
 
         def work(e):
             e.mc_infer(pool[i % 4], args.mc, seed, tile_idx0=tile_base + i * B, mc_mode=mode, out=(mean[k], std[k]))
@@ -197,21 +196,24 @@ def main():
         assert int(cnt.sum()) == steps * B and bool(torch.isfinite(mp[cnt > 0]).all())
         return dt
 
-    # Untimed calibration.  Two batches in flight usually win 3-4 % (one batch's tails and store drains
-    # fill under the other's kernels), but now and then the two streams land on hardware queues that
-    # interleave their workgroups CU by CU and lose 15 % for the life of the process (measured: 12.8 or
-    # 15.3 ms per batch from run to run, 13.1 ms on one stream every time).  Time a few steps each way
-    # and keep one stream when two are not faster.
-    streams_used = NS
-    if NS > 1:
-        t_multi = timed(args.mode, 8)
-        single[0] = True
-        t_single = timed(args.mode, 8)
-        flag = torch.tensor([1.0 if t_single < 0.99 * t_multi else 0.0], device=coll_dev)
+    # Untimed calibration of the number of batches in flight.  Each batch in flight owns 1/n of the chip's
+    # XCDs (CU-masked streams), which lets batches run out of phase (one's HBM-bound prologues and store
+    # drains under another's compute): 4 in flight measured 12.3 ms per batch, 2 12.5, one whole-chip stream
+    # 13.0.  But n in flight only pays when the K timed steps fill whole rounds of n (10 steps on 4
+    # quarter-chips are 3 rounds), and plain streams (if CU masks are unavailable) are bimodal.  So time
+    # min(K, 32) steps each way and keep the fastest; every rank adopts the same choice.
+    cands = sorted({n for n in (NS, NS // 2, 1) if n >= 1}, reverse=True)
+    if len(cands) > 1:
+        cal = min(K, 32)
+        times = []
+        for n in cands:
+            pool_e.set_in_flight(n)
+            times.append(timed(args.mode, cal))
+        tt = torch.tensor(times, dtype=torch.float64, device=coll_dev)
         if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        single[0] = bool(flag.item() > 0)
-        streams_used = 1 if single[0] else NS
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        pool_e.set_in_flight(cands[int(torch.argmin(tt).item())])
+    streams_used = len(pool_e)
     dt = timed(args.mode, K)
     value = world * K * B / dt
 
@@ -238,7 +240,7 @@ def main():
     # the other MC structure on the same kernels (N=1 only; a few steps)
     if world == 1 and rank == 0:
         other = 'full' if args.mode == 'head' else 'head'
-        k2 = max(2, NS) if other == 'full' else K     # at least one batch per stream: every XCD group busy
+        k2 = max(2, len(pool_e)) if other == 'full' else K     # a batch per stream keeps every XCD group busy
         dt2 = timed(other, k2)
         out[f'{other}_mode_value'] = k2 * B / dt2
 

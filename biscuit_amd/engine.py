@@ -228,26 +228,45 @@ class EnginePool:
         # 'xcd', 'interleave' (experiments) or None / BQ_CU_SPLIT=none for plain streams.
         split = os.environ.get('BQ_CU_SPLIT', cu_split)
         split = None if split in (None, '', 'none', '0') else split
-        self.cu_split = None
-        if split and len(self.engines) >= 2:
+        self.device = dev
+        self.hp = self.engines[0].hp
+        self.cu_split = split
+        self._sets = {}                 # batches in flight -> list of streams
+        self.active = len(self.engines)
+        self.streams = self._stream_set(self.active)
+
+    def _stream_set(self, n):
+        """n streams: CU-masked (each owns 1/n of the chip's XCDs) when n >= 2 and masks are available,
+        one plain whole-chip stream for n = 1."""
+        if n in self._sets:
+            return self._sets[n]
+        dev = self.device
+        streams = None
+        if n >= 2 and self.cu_split:
             try:
-                self._masked_streams(split, dev)
-                self.cu_split = split
+                streams = self._masked_streams(self.cu_split, dev, n)
             except BiscuitHipError as e:       # scheduling aid only: plain streams compute the same results
                 import warnings
                 warnings.warn(f'CU-masked streams unavailable ({e}); using plain HIP streams')
-                self.streams = [torch.cuda.Stream(device=dev) for _ in self.engines]
-        else:
-            self.streams = [torch.cuda.Stream(device=dev) for _ in self.engines]
-        self.device = dev
-        self.hp = self.engines[0].hp
+                self.cu_split = None
+        if streams is None:
+            streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        self._sets[n] = streams
+        return streams
 
-    def _masked_streams(self, split, dev):
-        self._masked = []
-        self.streams = []
+    def set_in_flight(self, n):
+        """Use the first n contexts, each on its own share of the chip (n = 1: one whole-chip stream).
+        Results do not depend on n."""
+        n = max(1, min(int(n), len(self.engines)))
+        self.synchronize()
+        self.active = n
+        self.streams = self._stream_set(n)
+
+    def _masked_streams(self, split, dev, nst):
+        streams = []
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        nst = len(self.engines)
-        for k, eng in enumerate(self.engines):
+        for k in range(nst):
+            eng = self.engines[k]
             bits = [0] * ((ncu + 31) // 32)
             for cu in range(ncu):
                 if split == 'contig':
@@ -261,16 +280,16 @@ class EnginePool:
             arr = (C.c_uint32 * len(bits))(*bits)
             h = C.c_void_p()
             eng._check(eng._lib.bq_stream_create_masked(eng._ctx, arr, len(bits), C.byref(h)))
-            self._masked.append((eng, h))
-            self.streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+            streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+        return streams
 
     def __len__(self):
-        return len(self.engines)
+        return self.active
 
     def run(self, i, fn, wait_for_current=False):
         """Call fn(engine) with stream i % n current.  wait_for_current: first make that stream
         wait for work already enqueued on the caller's stream (inputs prepared there)."""
-        k = i % len(self.engines)
+        k = i % self.active
         if wait_for_current:
             self.streams[k].wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.streams[k]):

@@ -109,7 +109,7 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     n_local = len(mine)
     # an EnginePool alternates batches over independent contexts / HIP streams
     pool = engine if hasattr(engine, 'engines') else None
-    engines = pool.engines if pool else [engine]
+    engines = pool.engines[:len(pool)] if pool else [engine]      # len(pool) = batches in flight
     acc = [None] * len(engines)
     n_batches = 0
     rows_mean, rows_std, rows_slide, rows_true, rows_loc = [], [], [], [], []

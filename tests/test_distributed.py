@@ -55,6 +55,9 @@ class StandInPool:
         self.engines = [StandInEngine() for _ in range(n)]
         self.hp, self.device = self.engines[0].hp, self.engines[0].device
 
+    def __len__(self):
+        return len(self.engines)
+
     def run(self, i, fn, wait_for_current=False):
         return fn(self.engines[i % len(self.engines)])
 
