@@ -276,7 +276,26 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     if (!no_pipe && nsplit == 1 && pipe_supported(dtype, a.prod, L.nfp, a.W, L.kpad)) {
         p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
+        static const char* pstamp_file = getenv("BQ_STAMPS_PIPE");
+        static int pstamp_state = 0;
+        static unsigned long long* d_pstamps = nullptr;
+        static const bool pstamp_res = getenv("BQ_STAMPS_NORES") == nullptr;
+        if (pstamp_file && pstamp_state == 0 && a.W == 19 && (a.residual != nullptr) == pstamp_res) {
+            if (hipMalloc(&d_pstamps, 64 * 8 * 128 * 8) == hipSuccess) {
+                (void)hipMemsetAsync(d_pstamps, 0, 64 * 8 * 128 * 8, s);
+                p.stamps = d_pstamps;
+                pstamp_state = 1;
+            }
+        }
         const int e = launch_sepconv_pipe(a.prod, p, s);
+        if (pstamp_state == 1) {
+            std::vector<unsigned long long> hbuf(64 * 8 * 128);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(hbuf.data(), d_pstamps, hbuf.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE* f = fopen(pstamp_file, "wb")) { fwrite(hbuf.data(), 8, hbuf.size(), f); fclose(f); }
+            pstamp_state = 2;
+            p.stamps = nullptr;
+        }
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(pipe) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;

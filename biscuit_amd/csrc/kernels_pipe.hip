@@ -167,6 +167,9 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF]
     }
 }
 
+// diagnostic s_memtime stamps (BQ_STAMPS; p.stamps is null in production)
+#define PSTAMP(ev) do { if (stp && (tid & 63) == 0) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
+
 template <bool RELU, int MF, int WN, int RN, int NRAW>
 __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams p) {
     constexpr int NT = 64 * WN;
@@ -186,6 +189,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
 
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = tile * MT;
+    unsigned long long* stp = (p.stamps && blockIdx.x < 64) ? p.stamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 128 : nullptr;
+    PSTAMP(0);
     const int p_lo = m0 - (W + 1);
     const int K = p.K;                             // padded input channels (multiple of 16)
     const int KB = K / 16;
@@ -241,7 +246,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     // raw(0) -> LDS, D(0), raw(1) -> LDS, raw(2) in flight
     raw_store<NT, RELU, NRAW>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
     rreg = raw_load<NT, NRAW>(in, ldi, 1, K, jch, tid, p_lo, p.M);
+    PSTAMP(1);
     __syncthreads();                               // raw[0] and the taps are visible
+    PSTAMP(2);
     depthwise<NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
     raw_store<NT, RELU, NRAW>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
     rreg = raw_load<NT, NRAW>(in, ldi, 2, K, jch, tid, p_lo, p.M);
@@ -253,7 +260,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
         for (int j = 0; j < RN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    PSTAMP(3);
     __syncthreads();                               // A(0) and raw[1] visible
+    PSTAMP(4);
 
     for (int c = 0; c < NC; ++c) {
         const int cur = c & 1, nxt = cur ^ 1;
@@ -274,21 +283,28 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask);
         }
+        PSTAMP(5 + 4 * c);
         if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+        PSTAMP(6 + 4 * c);
         if (!first_half) {
             if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask);
         }
+        PSTAMP(7 + 4 * c);
         __syncthreads();
+        PSTAMP(8 + 4 * c);
     }
     // every wave is past its last LDS read (the loop's closing barrier): reuse LDS as the
     // output staging tile
     if (!(p.dbg & 4)) {
         epilogue_to_lds<bf16_t, MF, RN>(p, acc, nfb, 0, m0, r32, h, smem);
+        PSTAMP(57);
         __syncthreads();
+        PSTAMP(58);
         lds_rows_to_global<bf16_t, NT, MT>(p, m0, tid, smem);
+        PSTAMP(59);
     }
 }
 
