@@ -283,6 +283,16 @@ class EnginePool:
             streams.append(torch.cuda.ExternalStream(h.value, device=dev))
         return streams
 
+    def close(self):
+        """Destroy the CU-masked streams this pool created (plain torch streams are torch's)."""
+        self.synchronize()
+        for n, streams in list(self._sets.items()):
+            for k, st in enumerate(streams):
+                if isinstance(st, torch.cuda.ExternalStream):
+                    self.engines[k]._lib.bq_stream_destroy(self.engines[k]._ctx, C.c_void_p(st.cuda_stream))
+            del self._sets[n]
+        self.streams = []
+
     def __len__(self):
         return self.active
 

@@ -147,6 +147,13 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                                      out=(mean[a:b], std[a:b]))
                 acc[k] = eng.slide_reduce(mean, std, cs, max(n_local, 1), tile_uq=tile_uq, acc=acc[k])
             if pool:
+                # these tensors were allocated on the caller's stream and are read on the pool's: tell the
+                # caching allocator, or the next batch's temporaries may reuse their memory while this
+                # batch's kernels are still in flight
+                st = getattr(pool, 'streams', None)
+                if st and cur.is_cuda:
+                    for t in (cur, cs, mean, std):
+                        t.record_stream(st[k])
                 pool.run(n_batches, work, wait_for_current=True)
             else:
                 work(engine)

@@ -305,6 +305,17 @@ def test_engine_pool_two_streams_bit_identical(weights):
     assert np.array_equal(single.slide_pred, pooled.slide_pred, equal_nan=True)
     assert np.array_equal(single.slide_unc, pooled.slide_unc, equal_nan=True)
     assert list(single.slide_count) == list(pooled.slide_count) == counts
+    # four contexts on CU-masked streams (each owns two XCDs), then the same pool cut back to two and one
+    # batches in flight: the partition of the chip never changes a result
+    pool4 = EnginePool(weights, n_streams=4, dtype='bf16', max_batch=8, max_mc=8)
+    assert pool4.cu_split == 'contig' and len(pool4) == 4
+    for n in (4, 2, 1):
+        pool4.set_in_flight(n)
+        assert len(pool4) == n
+        got = evaluate(pool4, slides, mc_n=4, seed=3, batch=4)
+        assert single.tile_df.equals(got.tile_df)
+        assert np.array_equal(single.slide_pred, got.slide_pred, equal_nan=True)
+        assert np.array_equal(single.slide_unc, got.slide_unc, equal_nan=True)
 
 
 @pytest.mark.gpu
