@@ -135,3 +135,43 @@ def test_errors(tmp_path):
     with tn.NativeReader(empty) as r:
         assert len(r) == 0 and r.slide is None
     assert tfr.read_slide(empty)[1].shape == (0, 299, 299, 3)
+
+
+def test_mutated_files_never_crash(tmp_path):
+    """Byte-mutated / truncated records must come back as errors, not as a crash of the process
+    (the reader parses untrusted files in C++): decode them in a child process and check it survives."""
+    import random
+    import subprocess
+    import sys
+    tiles = _tiles(2, 5)
+    path = str(tmp_path / 'a.tfrecords')
+    tfr.write_slide(path, 's', tiles)
+    raw = open(path, 'rb').read()
+    rnd = random.Random(7)
+    paths = []
+    for k in range(120):
+        b = bytearray(raw)
+        for _ in range(rnd.choice([1, 2, 5, 20])):
+            i = rnd.randrange(400) if rnd.random() < 0.4 else rnd.randrange(len(b))
+            b[i] = rnd.randrange(256)
+        if rnd.random() < 0.2:
+            b = b[:rnd.randrange(len(b))]
+        q = str(tmp_path / f'm{k}.tfrecords')
+        open(q, 'wb').write(b)
+        paths.append(q)
+    code = (
+        "import sys\n"
+        "from biscuit_amd import tfrecord_native as tn\n"
+        "for p in sys.argv[1:]:\n"
+        "    try:\n"
+        "        with tn.NativeReader(p, verify=None) as r:\n"
+        "            for i in range(len(r)):\n"
+        "                try: r.image_format(i); r.image_bytes(i)\n"
+        "                except Exception: pass\n"
+        "            try: r.slide; r.decode(threads=2)\n"
+        "            except Exception: pass\n"
+        "    except Exception: pass\n"
+        "print('survived')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(tn.LIB_PATH)))
+    out = subprocess.run([sys.executable, '-c', code] + paths, capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0 and 'survived' in out.stdout, out.stderr[-500:]
