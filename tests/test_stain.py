@@ -67,6 +67,45 @@ def test_constants_are_float32_inverse():
     assert np.allclose(k['m'].astype(np.float64) @ k['minv'].astype(np.float64), np.eye(3), atol=1e-6)
 
 
+def _golden():
+    import hashlib
+    import os
+    from oracle.make_stain_golden import smooth_tiles
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'stain_reinhard.npz')))
+    g['tiles'] = smooth_tiles(3, seed=int(g['seed']))[:2]
+    assert hashlib.sha256(g['tiles'].tobytes()).digest() == g['input_sha256'].tobytes()   # same inputs as the fixture's
+    return g
+
+
+def test_oracle_matches_committed_fixture():
+    """tests/golden/stain_reinhard.npz (oracle/make_stain_golden.py) pins the oracle's arithmetic."""
+    import hashlib
+    g = _golden()
+    out = stain.reinhard_fast(g['tiles'], g['target_means'], g['target_stds'])
+    np.testing.assert_array_equal(out[:, 100:132, 100:132], g['output_crop'])
+    assert hashlib.sha256(out.tobytes()).digest() == g['output_sha256'].tobytes()
+    L, a, b = stain.rgb_to_lab(g['tiles'])
+    mu, sd = stain.lab_stats(L, a, b)
+    np.testing.assert_array_equal(mu, g['lab_means'])
+    np.testing.assert_array_equal(sd, g['lab_stds'])
+
+
+@pytest.mark.gpu
+def test_reinhard_kernel_matches_committed_fixture():
+    import torch
+    from biscuit_amd.engine import Engine
+    from biscuit_amd.weights import synthetic_weights
+    g = _golden()
+    eng = Engine(synthetic_weights(seed=1), dtype='bf16', max_batch=8, max_mc=4)
+    dt = torch.from_numpy(g['tiles']).cuda()
+    got = eng.reinhard_fast(dt, g['target_means'], g['target_stds']).cpu().numpy()
+    d = np.abs(got[:, 100:132, 100:132].astype(int) - g['output_crop'].astype(int))
+    assert d.max() <= 1 and (d != 0).sum() <= 1
+    st = eng.lab_stats(dt).cpu().numpy()
+    np.testing.assert_allclose(st[:, :3], g['lab_means'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(st[:, 3:], g['lab_stds'], rtol=0, atol=1e-5)
+
+
 @pytest.mark.gpu
 def test_reinhard_kernel_matches_oracle():
     import torch
