@@ -32,6 +32,7 @@ def main(argv=None):
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--streams', type=int, default=2)
+    ap.add_argument('--params', help="Slideflow params.json: its norm_fit switches on the reinhard_fast stain normaliser (hp.py:19)")
     ap.add_argument('--tile-uq', type=float, default=0.0, help='tile-level uncertainty threshold (0 = off)')
     ap.add_argument('--slide-uq', type=float, default=0.0, help='slide-level uncertainty threshold (0 = off)')
     args = ap.parse_args(argv)
@@ -55,9 +56,15 @@ def main(argv=None):
         s, t = (int(x) for x in args.synthetic.lower().split('x'))
         tiles, sidx, y = make_slides(s, t, seed=0)
         slides = [Slide(f'slide{i:03d}', tiles[sidx == i], t, y_true=int(y[i])) for i in range(s)]
+    norm_fit = None
+    if args.params:
+        with open(args.params) as f:
+            norm_fit = json.load(f).get('norm_fit')
+        if not norm_fit:
+            raise SystemExit(f'{args.params}: no norm_fit block')
     pool = EnginePool(w, n_streams=args.streams, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local)
     res = evaluate(pool, slides, outcome=args.outcome, mc_n=args.mc, seed=args.seed, batch=args.batch,
-                   save_dir=args.out, rank=rank, world=world)
+                   save_dir=args.out, rank=rank, world=world, norm_fit=norm_fit)
     if rank == 0:
         sf, _ = res.slide_frame(0.5)
         sf.to_csv(os.path.join(args.out, f'slide_predictions_{args.outcome}_eval.csv'), index=False)
