@@ -91,7 +91,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT, int MT, int NITEM>
 __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, int wl_off, int c, int K,
-                                          int W, int jch, int tid, const unsigned (&item_mask)[NITEM]) {
+                                          int W, int jch, int tid, const unsigned (&item_mask)[NITEM], int dbg = 0) {
     if (c * KC + jch * 8 >= K) {                   // padded channel tail of the last chunk: A = 0 (the matrix
 #pragma unroll                                     // stage always runs whole chunks)
         for (int q = 0; q < NITEM; ++q) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
             // one tap row at a time (outer loop not unrolled): keeps the live set small, the
             // accumulators of the matrix-core stage leave few spare registers
 #pragma unroll 1
-            for (int dy = 0; dy < 3; ++dy) {
+            for (int dy = (dbg & 64) ? 1 : 0; dy < ((dbg & 64) ? 2 : 3); ++dy) {
                 const int rowoff = base + (dy - 1) * W * RAW_ROW;
                 const int woff = wbase + dy * 3 * K * 4;
                 const unsigned mrow = item_mask[q] >> (dy * 3);
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
             if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
-                                         tid, item_mask);
+                                         tid, item_mask, p.dbg);
         }
         PSTAMP(5 + 4 * c);
         if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
             if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
-                                         tid, item_mask);
+                                         tid, item_mask, p.dbg);
         }
         PSTAMP(7 + 4 * c);
         __syncthreads();
