@@ -170,10 +170,14 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF]
 // diagnostic s_memtime stamps (BQ_STAMPS; p.stamps is null in production)
 #define PSTAMP(ev) do { if (stp && (tid & 63) == 0) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <bool RELU, int MF, int WN, int RN, int NRAW>
-__global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams p) {
-    constexpr int NT = 64 * WN;
-    constexpr int MT = 32 * MF;
+// WM groups of WN waves: group g owns rows [32*MF*g, 32*MF*(g+1)) of the tile, every group all output columns.
+// WM = 2 (16 waves, 192-row tiles) is for the 256-wide layers on large maps: a 74-wide map needs 150 halo
+// pixels around ANY flattened tile, so twice the rows per tile means 30 % less halo traffic per pixel, the
+// weights are streamed once per 192 rows, and the 1024-thread workgroup runs 4 waves per SIMD.
+template <bool RELU, int MF, int WN, int RN, int NRAW, int WM>
+__global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmParams p) {
+    constexpr int NT = 64 * WN * WM;
+    constexpr int MT = 32 * MF * WM;
     constexpr int NITEM = (MT * CPR + NT - 1) / NT;
     constexpr int KBC = KC / 16;                   // k-blocks per chunk (4)
     constexpr int PF = 2;                          // B register ring depth (k-blocks ahead)
@@ -224,8 +228,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     Raw3 rreg = raw_load<NT, NRAW>(in, ldi, 0, K, jch, tid, p_lo, p.M);
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
-    const int nfb = wave * RN;                     // single pass over N: NFp == WN*RN
-    const bool first_half = __builtin_amdgcn_readfirstlane(wave) < WN / 2;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int nfb = wn * RN;                       // single pass over N: NFp == WN*RN
+    const bool first_half = __builtin_amdgcn_readfirstlane(wave) < WN * WM / 2;
     const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(p.wp);
     const uint4* bp0 = wp + ((size_t)nfb * p.KBtot + p.kb0) * 64 + lane;
     uint4 bq[PF][RN];
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
         // chunk c+3 go right in front of the wave's own D stage (which never waits on vmcnt): in front
         // of G they would sit ahead of the B ring's loads in the in-order vmcnt queue and the first
         // k-blocks would wait out their HBM latency.
-        const int a_base = a_off0 + cur * MT * A_STR + r32 * A_STR + h * 16;
+        const int a_base = a_off0 + cur * MT * A_STR + (wm * MF * 32 + r32) * A_STR + h * 16;
         const bool do_d = (c + 1 < NC) && !(p.dbg & 1);
         if (first_half) {
             if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     // every wave is past its last LDS read (the loop's closing barrier): reuse LDS as the
     // output staging tile
     if (!(p.dbg & 4)) {
-        epilogue_to_lds<bf16_t, MF, RN>(p, acc, nfb, 0, m0, r32, h, smem);
+        epilogue_to_lds<bf16_t, MF, RN>(p, acc, nfb, wm * MF * 32, m0, r32, h, smem);
         PSTAMP(57);
         __syncthreads();
         PSTAMP(58);
@@ -308,16 +313,16 @@ __global__ void __launch_bounds__(64 * WN) sepconv_pipe_kernel(const GemmParams 
     }
 }
 
-template <bool RELU, int RN, int NRAW>
+template <bool RELU, int RN, int NRAW, int WM>
 int launch_pipe(const GemmParams& p, hipStream_t s) {
     constexpr int MF = 3, WN = 8;
-    auto kern = sepconv_pipe_kernel<RELU, MF, WN, RN, NRAW>;
-    const int MT = 32 * MF;
+    auto kern = sepconv_pipe_kernel<RELU, MF, WN, RN, NRAW, WM>;
+    const int MT = 32 * MF * WM;
     const int HP = MT + 2 * (p.W + 1);
     size_t lds = (size_t)2 * HP * RAW_ROW + 2 * MT * A_STR + (size_t)9 * p.K * 4;
     const size_t stage = (size_t)MT * (p.Nstore * 2 + 16);
     if (stage > lds) lds = stage;
-    if (p.NFp != WN * RN || p.K % 16 != 0 || HP * CPR > NRAW * 64 * WN || lds > 160 * 1024 || p.k_off != 0)
+    if (p.NFp != WN * RN || p.K % 16 != 0 || HP * CPR > NRAW * 64 * WN * WM || lds > 160 * 1024 || p.k_off != 0)
         return (int)hipErrorInvalidValue;
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -327,7 +332,7 @@ int launch_pipe(const GemmParams& p, hipStream_t s) {
         lds_set = lds;
     }
     const int grid = (p.M + MT - 1) / MT;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN * WM), lds, s, p);
     return (int)hipGetLastError();
 }
 
@@ -352,6 +357,11 @@ bool pipe_supported(int dtype, int prod, int nfp, int W, int K) {
 
 int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s) {
     const bool relu = prod == PROD_DW_RELU;
-    if (pipe_variant(p.NFp, p.W) == 0) return relu ? launch_pipe<true, 3, 3>(p, s) : launch_pipe<false, 3, 3>(p, s);
-    return relu ? launch_pipe<true, 1, 4>(p, s) : launch_pipe<false, 1, 4>(p, s);
+    if (pipe_variant(p.NFp, p.W) == 0) return relu ? launch_pipe<true, 3, 3, 1>(p, s) : launch_pipe<false, 3, 3, 1>(p, s);
+    // 256-wide: 192-row tiles on 16 waves where the halo of a 96-row tile is larger than the tile itself
+    static const bool no_wide = getenv("BQ_PIPE_NO_WM2") != nullptr;
+    const size_t lds2 = (size_t)2 * (192 + 2 * (p.W + 1)) * RAW_ROW + 2 * 192 * A_STR + (size_t)9 * p.K * 4;
+    if (!no_wide && p.W >= 48 && lds2 <= 160 * 1024 && (192 + 2 * (p.W + 1)) * CPR <= 3 * 1024)
+        return relu ? launch_pipe<true, 1, 3, 2>(p, s) : launch_pipe<false, 1, 3, 2>(p, s);
+    return relu ? launch_pipe<true, 1, 4, 1>(p, s) : launch_pipe<false, 1, 4, 1>(p, s);
 }
