@@ -44,7 +44,8 @@ struct bq_ctx {
     const float* logits_w = nullptr; const float* logits_b = nullptr;
     bool loaded = false;
     int num_cus = 256;
-    float* d_srgb_lut = nullptr;   // 256-entry sRGB -> linear table of the Reinhard normaliser
+    float* d_srgb_lut = nullptr;   // tables of the Reinhard normaliser
+    double* d_stage_stats = nullptr;   // 2 x 64-bit integer sums per tile for the staging kernel pair
     // profiling
     bool prof = false;
     std::vector<std::string> prof_names;
@@ -601,6 +602,12 @@ bq_ctx* bq_create(int device_id, const bq_config* cfg) {
             return nullptr;
         }
     }
+    if (hipMalloc(&c->d_stage_stats, (size_t)(cfg->max_batch > 0 ? cfg->max_batch : 1) * 16) != hipSuccess) {
+        g_create_error = "cannot allocate the staging statistics";
+        (void)hipFree(c->d_srgb_lut);
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -608,6 +615,7 @@ void bq_destroy(bq_ctx* c) {
     if (!c) return;
     if (c->d_blob) (void)hipFree(c->d_blob);
     if (c->d_srgb_lut) (void)hipFree(c->d_srgb_lut);
+    if (c->d_stage_stats) (void)hipFree(c->d_stage_stats);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     delete c;
 }
@@ -675,7 +683,9 @@ int bq_stage(bq_ctx* c, const uint8_t* d_tiles, int n, void* d_out, bq_stream_t 
     if (!c || !d_tiles || !d_out || n < 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_stage: bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(c, s, "stage_u8_standardize", 4.0 * n * kStaged, (double)n * kStaged * (1.0 + esize(c)));
-    if (launch_stage_u8(d_tiles, n, 299, d_out, c->cfg.dtype, nullptr, s)) return fail(c, BQ_ERR_HIP, "stage launch failed");
+    static const bool one_kernel = getenv("BQ_STAGE_1K") != nullptr;
+    if (launch_stage_u8(d_tiles, n, 299, d_out, c->cfg.dtype, one_kernel ? nullptr : c->d_stage_stats, s))
+        return fail(c, BQ_ERR_HIP, "stage launch failed");
     return BQ_OK;
 }
 
