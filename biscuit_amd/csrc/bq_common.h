@@ -54,6 +54,7 @@ struct GemmParams {
     float dscale;
     int layer, mc_n, pass0, in_row_is_tile;
     long long tile0;
+    int lds_total;         // dynamic LDS bytes of the launch (set by the pipe launcher)
     int dbg;               // ablation flags for timing experiments (0 in production)
     unsigned long long* stamps;   // diagnostic builds: s_memtime stamps [wg][wave][64] (null in production)
 };

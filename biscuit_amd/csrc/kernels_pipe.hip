@@ -148,7 +148,8 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
 // path-dependent, and the compiler then waits vmcnt(0) - the whole ring - before every k-block.
 template <int MF, int RN, int PF, int KBC>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
-                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot) {
+                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot,
+                                          int dbg = 0) {
 #pragma unroll
     for (int d = 0; d < KBC; ++d) {
         const int kb = c * KBC + d;
@@ -161,9 +162,105 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF]
 #pragma unroll
             for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
         const int nx = kb + PF;
-        const int idx = nx < KB ? nx : KB - 1;
+        const int idx = (dbg & 128) ? 0 : (nx < KB ? nx : KB - 1);   // 128: timing probe, B stays L1-resident
 #pragma unroll
         for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * KBtot + idx) * 64];
+    }
+}
+
+// Epilogue, part 1: folded BN (+ residual) (+ ReLU) in registers, result parked in LDS in its final dtype.
+// Same arithmetic as gemm_common.h's epilogue_to_lds, but nothing here is a global load under a branch:
+// scale and bias come from LDS (`sb`, written in the prologue) and the residual tile, when there is one, was
+// copied into the staging rows by LDS-DMA (`residual_dma`) -- each lane then reads back exactly the 8 bytes it
+// is about to overwrite.  With the loads in the branches the compiler waited vmcnt(0) after every one of them:
+// 24 (scale/bias) + 36 (residual) serialised L2/HBM round trips, 11 k and 30 k cycles of a 117-146 k tile.
+template <int MF, int RN>
+__device__ __forceinline__ void pipe_epilogue_to_lds(const GemmParams& p, const f32x16 (&acc)[MF][RN], int nfb,
+                                                     int row_local0, int r32, int h, unsigned char* smem,
+                                                     const float* sb, int nfp32, bool res_in_lds) {
+    const int sstride = stage_stride<bf16_t>(p.Nstore);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n0 = (nfb + j) * 32 + g * 8 + h * 4;
+            const float4 sc = *reinterpret_cast<const float4*>(sb + n0);
+            const float4 bi = *reinterpret_cast<const float4*>(sb + nfp32 + n0);
+            if (n0 < p.Nstore) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const int rl = row_local0 + i * 32 + r32;
+                    bf16_t* slot = reinterpret_cast<bf16_t*>(smem + (size_t)rl * sstride) + n0;
+                    float v[4];
+                    v[0] = fmaf(acc[i][j][g * 4 + 0], sc.x, bi.x);
+                    v[1] = fmaf(acc[i][j][g * 4 + 1], sc.y, bi.y);
+                    v[2] = fmaf(acc[i][j][g * 4 + 2], sc.z, bi.z);
+                    v[3] = fmaf(acc[i][j][g * 4 + 3], sc.w, bi.w);
+                    if (res_in_lds) {
+                        float rv[4];
+                        load4<bf16_t>(slot, rv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    store4<bf16_t>(slot, v);
+                }
+            }
+        }
+    }
+}
+
+// The residual tile goes into the staging rows by LDS-DMA, no registers involved: a wave instruction writes
+// 64 x 16 contiguous bytes of LDS, so a row of up to 128 pieces takes two.  Rows past M are left alone (their
+// staging rows are never stored).
+template <int NT, int MT>
+__device__ __forceinline__ void residual_dma(const GemmParams& p, int m0, int tid, unsigned char* smem, int r_begin,
+                                             int r_end) {
+    const int row_bytes = p.ldo * 2;
+    const int ppr = p.Nstore >> 3;                 // 16-byte pieces per row
+    const int sstride = stage_stride<bf16_t>(p.Nstore);
+    int rows = p.M - m0 < MT ? p.M - m0 : MT;
+    if (rows > r_end) rows = r_end;
+    const unsigned char* __restrict__ src = reinterpret_cast<const unsigned char*>(p.residual) + (size_t)m0 * row_bytes;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    constexpr int NW = NT / 64;
+    for (int r = r_begin + wave; r < rows; r += NW) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int piece = half * 64 + lane;
+            if (piece < ppr)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + (size_t)r * row_bytes + piece * 16),
+                    (__attribute__((address_space(3))) void*)(smem + (size_t)r * sstride + half * 1024), 16, 0, 0);
+        }
+    }
+}
+
+// The same copy for use INSIDE the K loop, as inline asm: the compiler treats a visible LDS-DMA as aliasing
+// every later LDS read (vmcnt(0) in front of each ds_read of the depthwise stage: +20 % per chunk).  An asm load
+// is absent from its vmcnt bookkeeping, which only makes its counted waits stricter (the DMA is younger than
+// the loads they guard); the epilogue waits vmcnt(0) itself before the barrier that publishes the rows.
+template <int NT, int MT>
+__device__ __forceinline__ void residual_dma_row_asm(const GemmParams& p, int m0, int tid, unsigned lds_base, int r) {
+    const int row_bytes = p.ldo * 2;
+    const int ppr = p.Nstore >> 3;
+    const int sstride = stage_stride<bf16_t>(p.Nstore);
+    if (m0 + r >= p.M) return;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(p.residual) + (size_t)(m0 + r) * row_bytes;
+    const int lane = tid & 63;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int piece = half * 64 + lane;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(r * sstride + half * 1024));
+        if (piece < ppr) {
+            const unsigned char* g = src + piece * 16;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
     }
 }
 
@@ -182,7 +279,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     constexpr int KBC = KC / 16;                   // k-blocks per chunk (4)
     constexpr int PF = 2;                          // B register ring depth (k-blocks ahead)
     static_assert(NT % CPR == 0, "a thread must keep the same channel piece for all its items");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem0[];
 
     const int tid = threadIdx.x;
     const int W = p.W, H = p.H;
@@ -190,6 +287,14 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     const int raw_bytes = HP * RAW_ROW;            // LDS map: raw[0] | raw[1] | A[0] | A[1] | taps
     const int a_off0 = 2 * raw_bytes;
     const int wl_off = a_off0 + 2 * MT * A_STR;
+    // The loop's buffers sit at the END of the allocation (scale/bias last): the staging rows below them are free
+    // during the K loop, and the first `npre` rows of a residual tile are copied there while the loop runs.
+    const int K0 = p.K;
+    const int sb_off = (wl_off + 9 * K0 * 4 + 15) & ~15;
+    const int lb = (p.lds_total - (sb_off + WN * RN * 32 * 8)) & ~15;
+    unsigned char* smem = smem0 + lb;
+    const bool res_dma = p.residual != nullptr && p.Nstore <= 1024;
+    const int npre = res_dma ? lb / stage_stride<bf16_t>(p.Nstore) : 0;
 
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = tile * MT;
@@ -226,11 +331,27 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     // ---- prologue: every global load the first stages need is issued up front (halo chunk 0, the
     // first B fragments, then the taps), so their latencies overlap instead of adding up
     Raw3 rreg = raw_load<NT, NRAW>(in, ldi, 0, K, jch, tid, p_lo, p.M);
+    constexpr int nfp32 = WN * RN * 32;
+    constexpr int NSB = (nfp32 + NT - 1) / NT;
+    float sbv[NSB][2];
+    {
+        const float* scp = p.scale ? p.scale : p.dw;       // any readable floats: the value is discarded if null
+        const float* bip = p.bias ? p.bias : p.dw;
+#pragma unroll
+        for (int q = 0; q < NSB; ++q) {
+            const int i = tid + q * NT;
+            const int ic = i < p.Nstore ? i : 0;
+            sbv[q][0] = scp[ic];
+            sbv[q][1] = bip[ic];
+        }
+    }
     const int lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int nfb = wn * RN;                       // single pass over N: NFp == WN*RN
     const bool first_half = __builtin_amdgcn_readfirstlane(wave) < WN * WM / 2;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem0;
     const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(p.wp);
     const uint4* bp0 = wp + ((size_t)nfb * p.KBtot + p.kb0) * 64 + lane;
     uint4 bq[PF][RN];
@@ -246,6 +367,18 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         // stored as (w0,w2,w1,w3): the order the packed-FMA depthwise consumes them in
         const float4 wv = *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + k);
         *reinterpret_cast<float4*>(smem + wl_off + i * 4) = make_float4(wv.x, wv.z, wv.y, wv.w);
+    }
+
+    // folded-BN scale and bias -> LDS behind everything the epilogue's staging tile will overwrite (loaded at the
+    // top of the prologue, unconditionally, so their latency runs under the halo loads')
+    float* sb = reinterpret_cast<float*>(smem + sb_off);
+#pragma unroll
+    for (int q = 0; q < NSB; ++q) {
+        const int i = tid + q * NT;
+        if (i < nfp32) {
+            sb[i] = (p.scale && i < p.Nstore) ? sbv[q][0] : 1.f;
+            sb[nfp32 + i] = (p.bias && i < p.Nstore) ? sbv[q][1] : 0.f;
+        }
     }
 
     // raw(0) -> LDS, D(0), raw(1) -> LDS, raw(2) in flight
@@ -284,15 +417,17 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         const bool do_d = (c + 1 < NC) && !(p.dbg & 1);
         if (first_half) {
             if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+            if (c * (NT / 64) + wave_u < npre) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, c * (NT / 64) + wave_u);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask, p.dbg);
         }
         PSTAMP(5 + 4 * c);
-        if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+        if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
         PSTAMP(6 + 4 * c);
         if (!first_half) {
             if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+            if (c * (NT / 64) + wave_u < npre) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, c * (NT / 64) + wave_u);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask, p.dbg);
@@ -304,11 +439,21 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     // every wave is past its last LDS read (the loop's closing barrier): reuse LDS as the
     // output staging tile
     if (!(p.dbg & 4)) {
-        epilogue_to_lds<bf16_t, MF, RN>(p, acc, nfb, wm * MF * 32, m0, r32, h, smem);
+        if (res_dma) {
+            residual_dma<NT, MT>(p, m0, tid, smem0, min(npre, NC * (NT / 64)), MT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the in-loop asm copies too
+            __syncthreads();                       // (waits for this wave's DMA, then for everyone's)
+            PSTAMP(56);
+            pipe_epilogue_to_lds<MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, true);
+        } else if (p.residual) {
+            epilogue_to_lds<bf16_t, MF, RN>(p, acc, nfb, wm * MF * 32, m0, r32, h, smem0);
+        } else {
+            pipe_epilogue_to_lds<MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, false);
+        }
         PSTAMP(57);
         __syncthreads();
         PSTAMP(58);
-        lds_rows_to_global<bf16_t, NT, MT>(p, m0, tid, smem);
+        lds_rows_to_global<bf16_t, NT, MT>(p, m0, tid, smem0);
         PSTAMP(59);
     }
 }
@@ -322,6 +467,9 @@ int launch_pipe(const GemmParams& p, hipStream_t s) {
     size_t lds = (size_t)2 * HP * RAW_ROW + 2 * MT * A_STR + (size_t)9 * p.K * 4;
     const size_t stage = (size_t)MT * (p.Nstore * 2 + 16);
     if (stage > lds) lds = stage;
+    lds = ((lds + 15) & ~(size_t)15) + (size_t)p.NFp * 32 * 8 + 16;      // + scale and bias
+    // one workgroup per CU anyway (2 waves per SIMD): take all of LDS so a residual tile can be prefetched
+    if (p.residual && WM == 1 && RN == 3 && lds <= 160 * 1024) lds = 160 * 1024;
     if (p.NFp != WN * RN || p.K % 16 != 0 || HP * CPR > NRAW * 64 * WN * WM || lds > 160 * 1024 || p.k_off != 0)
         return (int)hipErrorInvalidValue;
     static size_t lds_set = 0;
@@ -332,7 +480,9 @@ int launch_pipe(const GemmParams& p, hipStream_t s) {
         lds_set = lds;
     }
     const int grid = (p.M + MT - 1) / MT;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN * WM), lds, s, p);
+    GemmParams q = p;
+    q.lds_total = (int)lds;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WN * WM), lds, s, q);
     return (int)hipGetLastError();
 }
 
@@ -352,7 +502,8 @@ bool pipe_supported(int dtype, int prod, int nfp, int W, int K) {
     if (pipe_variant(nfp, W) < 0) return false;
     const int HP = 96 + 2 * (W + 1);
     const size_t lds = (size_t)2 * HP * RAW_ROW + 2 * 96 * A_STR + (size_t)9 * K * 4;
-    return lds <= 160 * 1024 && (size_t)96 * (nfp * 64 + 16) <= 160 * 1024;
+    const size_t sbb = (size_t)nfp * 32 * 8 + 16;
+    return lds + sbb <= 160 * 1024 && (size_t)96 * (nfp * 64 + 16) + sbb <= 160 * 1024;
 }
 
 int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s) {
@@ -361,7 +512,7 @@ int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s) {
     // 256-wide: 192-row tiles on 16 waves where the halo of a 96-row tile is larger than the tile itself
     static const bool no_wide = getenv("BQ_PIPE_NO_WM2") != nullptr;
     const size_t lds2 = (size_t)2 * (192 + 2 * (p.W + 1)) * RAW_ROW + 2 * 192 * A_STR + (size_t)9 * p.K * 4;
-    if (!no_wide && p.W >= 48 && lds2 <= 160 * 1024 && (192 + 2 * (p.W + 1)) * CPR <= 3 * 1024)
+    if (!no_wide && p.W >= 48 && lds2 + (size_t)p.NFp * 32 * 8 + 16 <= 160 * 1024 && (192 + 2 * (p.W + 1)) * CPR <= 3 * 1024)
         return relu ? launch_pipe<true, 1, 3, 2>(p, s) : launch_pipe<false, 1, 3, 2>(p, s);
     return relu ? launch_pipe<true, 1, 4, 1>(p, s) : launch_pipe<false, 1, 4, 1>(p, s);
 }

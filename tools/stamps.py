@@ -5,7 +5,7 @@ import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(64, 8, 128).astype(np.int64)
 nwg = int((a[:, 0, 0] > 0).sum())
 print('workgroups with stamps:', nwg)
-names = {0: 'start', 1: 'prologue issued', 2: 'barrier0', 3: 'D(0)', 4: 'barrier1', 57: 'acc->lds', 58: 'barrier', 59: 'lds->global'}
+names = {0: 'start', 1: 'prologue issued', 2: 'barrier0', 3: 'D(0)', 4: 'barrier1', 56: 'residual dma+bar', 57: 'acc->lds', 58: 'barrier', 59: 'lds->global'}
 for wg in (0, 1, min(9, nwg - 1)):
     for wave in (0, 4):
         t = a[wg, wave]
@@ -19,7 +19,7 @@ for wg in (0, 1, min(9, nwg - 1)):
             e = [t[5 + 4 * c + k] for k in range(4)]
             print(f'   chunk {c:2d}: top/D1 {e[0]-prev:6d}  G {e[1]-e[0]:6d}  D2 {e[2]-e[1]:6d}  barrier {e[3]-e[2]:6d}   (@{e[3]-t0})')
             prev = e[3]
-        for ev in [57, 58, 59]:
+        for ev in ([56] if t[56] > 0 else []) + [57, 58, 59]:
             print(f'   {names[ev]:18s} +{t[ev]-prev:7d}  (@{t[ev]-t0})')
             prev = t[ev]
 # averages over workgroups and waves
