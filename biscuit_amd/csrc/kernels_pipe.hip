@@ -179,34 +179,39 @@ __device__ __forceinline__ void pipe_epilogue_to_lds(const GemmParams& p, const 
                                                      int row_local0, int r32, int h, unsigned char* smem,
                                                      const float* sb, int nfp32, bool res_in_lds) {
     const int sstride = stage_stride<bf16_t>(p.Nstore);
+    // branch-free ReLU: med3(v, lo, +inf) = max(v, lo), one instruction and no canonicalising max in front
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    const int nfbu = __builtin_amdgcn_readfirstlane(nfb);
+    unsigned char* lane_base = smem + (size_t)(row_local0 + r32) * sstride + h * 8;
+    const float* sbl = sb + h * 4;
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int n0 = (nfb + j) * 32 + g * 8 + h * 4;
-            const float4 sc = *reinterpret_cast<const float4*>(sb + n0);
-            const float4 bi = *reinterpret_cast<const float4*>(sb + nfp32 + n0);
-            if (n0 < p.Nstore) {
+            const int ng = (nfbu + j) * 32 + g * 8;        // wave-uniform; Nstore is a multiple of 8
+            if (ng < p.Nstore) {
+                const float4 sc = *reinterpret_cast<const float4*>(sbl + ng);
+                const float4 bi = *reinterpret_cast<const float4*>(sbl + nfp32 + ng);
 #pragma unroll
                 for (int i = 0; i < MF; ++i) {
-                    const int rl = row_local0 + i * 32 + r32;
-                    bf16_t* slot = reinterpret_cast<bf16_t*>(smem + (size_t)rl * sstride) + n0;
-                    float v[4];
-                    v[0] = fmaf(acc[i][j][g * 4 + 0], sc.x, bi.x);
-                    v[1] = fmaf(acc[i][j][g * 4 + 1], sc.y, bi.y);
-                    v[2] = fmaf(acc[i][j][g * 4 + 2], sc.z, bi.z);
-                    v[3] = fmaf(acc[i][j][g * 4 + 3], sc.w, bi.w);
+                    uint2* slot = reinterpret_cast<uint2*>(lane_base + (size_t)i * 32 * sstride + ng * 2);
+                    float v0 = fmaf(acc[i][j][g * 4 + 0], sc.x, bi.x);
+                    float v1 = fmaf(acc[i][j][g * 4 + 1], sc.y, bi.y);
+                    float v2 = fmaf(acc[i][j][g * 4 + 2], sc.z, bi.z);
+                    float v3 = fmaf(acc[i][j][g * 4 + 3], sc.w, bi.w);
                     if (res_in_lds) {
-                        float rv[4];
-                        load4<bf16_t>(slot, rv);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                        const uint2 u = *slot;
+                        v0 += __uint_as_float(u.x << 16); v1 += __uint_as_float(u.x & 0xffff0000u);
+                        v2 += __uint_as_float(u.y << 16); v3 += __uint_as_float(u.y & 0xffff0000u);
                     }
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    store4<bf16_t>(slot, v);
+                    v0 = __builtin_amdgcn_fmed3f(v0, lo, __builtin_inff());
+                    v1 = __builtin_amdgcn_fmed3f(v1, lo, __builtin_inff());
+                    v2 = __builtin_amdgcn_fmed3f(v2, lo, __builtin_inff());
+                    v3 = __builtin_amdgcn_fmed3f(v3, lo, __builtin_inff());
+                    uint2 o;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+                    *slot = o;
                 }
             }
         }
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     const int sb_off = (wl_off + 9 * K0 * 4 + 15) & ~15;
     const int lb = (p.lds_total - (sb_off + WN * RN * 32 * 8)) & ~15;
     unsigned char* smem = smem0 + lb;
-    const bool res_dma = p.residual != nullptr && p.Nstore <= 1024;
+    const bool res_dma = p.residual != nullptr;    // rows of up to 128 pieces: Nstore <= 1024 (launcher-checked)
     const int npre = res_dma ? lb / stage_stride<bf16_t>(p.Nstore) : 0;
 
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
@@ -445,8 +450,6 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
             __syncthreads();                       // (waits for this wave's DMA, then for everyone's)
             PSTAMP(56);
             pipe_epilogue_to_lds<MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, true);
-        } else if (p.residual) {
-            epilogue_to_lds<bf16_t, MF, RN>(p, acc, nfb, wm * MF * 32, m0, r32, h, smem0);
         } else {
             pipe_epilogue_to_lds<MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, false);
         }
@@ -470,7 +473,7 @@ int launch_pipe(const GemmParams& p, hipStream_t s) {
     lds = ((lds + 15) & ~(size_t)15) + (size_t)p.NFp * 32 * 8 + 16;      // + scale and bias
     // one workgroup per CU anyway (2 waves per SIMD): take all of LDS so a residual tile can be prefetched
     if (p.residual && WM == 1 && RN == 3 && lds <= 160 * 1024) lds = 160 * 1024;
-    if (p.NFp != WN * RN || p.K % 16 != 0 || HP * CPR > NRAW * 64 * WN * WM || lds > 160 * 1024 || p.k_off != 0)
+    if (p.NFp != WN * RN || p.K % 16 != 0 || p.Nstore % 8 != 0 || p.Nstore > 1024 || HP * CPR > NRAW * 64 * WN * WM || lds > 160 * 1024 || p.k_off != 0)
         return (int)hipErrorInvalidValue;
     static size_t lds_set = 0;
     if (lds > lds_set) {
