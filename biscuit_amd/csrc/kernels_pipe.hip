@@ -299,7 +299,19 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     const int lb = (p.lds_total - (sb_off + WN * RN * 32 * 8)) & ~15;
     unsigned char* smem = smem0 + lb;
     const bool res_dma = p.residual != nullptr;    // rows of up to 128 pieces: Nstore <= 1024 (launcher-checked)
-    const int npre = res_dma ? lb / stage_stride<bf16_t>(p.Nstore) : 0;
+    // rows [0, npre) lie below the loop's buffers; [npre, n1) also cover raw[0], free from iteration NC-2 on, and
+    // [n1, n2) raw[1], free in the last iteration (NC even: raw[0] is then the buffer nobody refills)
+    const int NCk = (p.K + KC - 1) / KC;
+    int npre = 0, n1 = 0, n2 = 0;
+    if (res_dma) {
+        const int S = stage_stride<bf16_t>(p.Nstore);
+        npre = min(min(lb / S, MT), max(NCk - 2, 0) * (NT / 64));
+        n1 = n2 = npre;
+        if (NCk % 2 == 0 && NCk >= 2) {
+            n1 = max(npre, min((lb + raw_bytes) / S, MT));
+            n2 = max(n1, min((lb + 2 * raw_bytes) / S, MT));
+        }
+    }
 
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = tile * MT;
@@ -420,9 +432,11 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         // k-blocks would wait out their HBM latency.
         const int a_base = a_off0 + cur * MT * A_STR + (wm * MF * 32 + r32) * A_STR + h * 16;
         const bool do_d = (c + 1 < NC) && !(p.dbg & 1);
+        const int dma_lo = c == NC - 2 ? npre : c == NC - 1 ? n1 : c * (NT / 64);
+        const int dma_hi = c == NC - 2 ? n1 : c == NC - 1 ? n2 : min(npre, (c + 1) * (NT / 64));
         if (first_half) {
             if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
-            if (c * (NT / 64) + wave_u < npre) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, c * (NT / 64) + wave_u);
+            for (int r = dma_lo + wave_u; r < dma_hi; r += NT / 64) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, r);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask, p.dbg);
@@ -432,7 +446,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         PSTAMP(6 + 4 * c);
         if (!first_half) {
             if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
-            if (c * (NT / 64) + wave_u < npre) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, c * (NT / 64) + wave_u);
+            for (int r = dma_lo + wave_u; r < dma_hi; r += NT / 64) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, r);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask, p.dbg);
@@ -445,7 +459,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     // output staging tile
     if (!(p.dbg & 4)) {
         if (res_dma) {
-            residual_dma<NT, MT>(p, m0, tid, smem0, min(npre, NC * (NT / 64)), MT);
+            residual_dma<NT, MT>(p, m0, tid, smem0, n2, MT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the in-loop asm copies too
             __syncthreads();                       // (waits for this wave's DMA, then for everyone's)
             PSTAMP(56);
