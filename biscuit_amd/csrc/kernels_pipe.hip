@@ -324,26 +324,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in);
     const int ldi = p.ldi;
 
-    // per-thread constants of the depthwise stage (independent of the chunk)
     const int jch = tid & (CPR - 1);               // this thread's 16-byte piece (8 channels)
-    unsigned item_mask[NITEM];                     // 9 validity bits ('same' zero padding)
-#pragma unroll
-    for (int q = 0; q < NITEM; ++q) {
-        const int r = (tid + q * NT) >> 3;
-        unsigned bits = 0;
-        if (r < MT && m0 + r < p.M) {
-            PixIt it;
-            it.init(m0 + r, H, W);
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int yy = it.y + dy - 1, xx = it.x + dx - 1;
-                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) bits |= 1u << (dy * 3 + dx);
-                }
-        }
-        item_mask[q] = bits;
-    }
 
     // ---- prologue: every global load the first stages need is issued up front (halo chunk 0, the
     // first B fragments, then the taps), so their latencies overlap instead of adding up
@@ -378,14 +359,45 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
 #pragma unroll
         for (int j = 0; j < RN; ++j) bq[d][j] = bp0[((size_t)j * p.KBtot + idx) * 64];
     }
-    // depthwise taps -> LDS as fp32 [9][K]
-    for (int i = tid * 4; i < 9 * K; i += NT * 4) {
-        const int t = i / K, k = i - t * K;
-        // stored as (w0,w2,w1,w3): the order the packed-FMA depthwise consumes them in
-        const float4 wv = *reinterpret_cast<const float4*>(p.dw + (size_t)t * ldi + k);
-        *reinterpret_cast<float4*>(smem + wl_off + i * 4) = make_float4(wv.x, wv.z, wv.y, wv.w);
+    // depthwise taps: [9][K] fp32, all loads of a thread in flight at once
+    constexpr int NTAP = (9 * 768 / 4 + NT - 1) / NT;      // float4 pieces per thread (K <= 768)
+    float4 tapv[NTAP];
+#pragma unroll
+    for (int q = 0; q < NTAP; ++q) {
+        const int i = (tid + q * NT) * 4;
+        const int ic = i < 9 * K ? i : 0;
+        int off = ic;                              // rows are contiguous when ldi == K (the usual case)
+        if (ldi != K) { const int t = ic / K; off = t * ldi + (ic - t * K); }
+        tapv[q] = *reinterpret_cast<const float4*>(p.dw + off);
+    }
+    // per-thread constants of the depthwise stage (independent of the chunk); the integer divisions run
+    // while the loads above are in flight
+    unsigned item_mask[NITEM];                     // 9 validity bits ('same' zero padding)
+#pragma unroll
+    for (int q = 0; q < NITEM; ++q) {
+        const int r = (tid + q * NT) >> 3;
+        unsigned bits = 0;
+        if (r < MT && m0 + r < p.M) {
+            PixIt it;
+            it.init(m0 + r, H, W);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int yy = it.y + dy - 1, xx = it.x + dx - 1;
+                    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) bits |= 1u << (dy * 3 + dx);
+                }
+        }
+        item_mask[q] = bits;
     }
 
+#pragma unroll
+    for (int q = 0; q < NTAP; ++q) {
+        const int i = (tid + q * NT) * 4;
+        // stored as (w0,w2,w1,w3): the order the packed-FMA depthwise consumes them in
+        if (i < 9 * K)
+            *reinterpret_cast<float4*>(smem + wl_off + i * 4) = make_float4(tapv[q].x, tapv[q].z, tapv[q].y, tapv[q].w);
+    }
     // folded-BN scale and bias -> LDS behind everything the epilogue's staging tile will overwrite (loaded at the
     // top of the prologue, unconditionally, so their latency runs under the halo loads')
     float* sb = reinterpret_cast<float*>(smem + sb_off);
@@ -487,7 +499,7 @@ int launch_pipe(const GemmParams& p, hipStream_t s) {
     lds = ((lds + 15) & ~(size_t)15) + (size_t)p.NFp * 32 * 8 + 16;      // + scale and bias
     // one workgroup per CU anyway (2 waves per SIMD): take all of LDS so a residual tile can be prefetched
     if (p.residual && WM == 1 && RN == 3 && lds <= 160 * 1024) lds = 160 * 1024;
-    if (p.NFp != WN * RN || p.K % 16 != 0 || p.Nstore % 8 != 0 || p.Nstore > 1024 || HP * CPR > NRAW * 64 * WN * WM || lds > 160 * 1024 || p.k_off != 0)
+    if (p.NFp != WN * RN || p.K % 16 != 0 || p.K > 768 || p.Nstore % 8 != 0 || p.Nstore > 1024 || HP * CPR > NRAW * 64 * WN * WM || lds > 160 * 1024 || p.k_off != 0)
         return (int)hipErrorInvalidValue;
     static size_t lds_set = 0;
     if (lds > lds_set) {
