@@ -179,8 +179,10 @@ __device__ __forceinline__ void pipe_epilogue_to_lds(const GemmParams& p, const 
                                                      int row_local0, int r32, int h, unsigned char* smem,
                                                      const float* sb, int nfp32, bool res_in_lds) {
     const int sstride = stage_stride<bf16_t>(p.Nstore);
-    // branch-free ReLU: med3(v, lo, +inf) = max(v, lo), one instruction and no canonicalising max in front
-    const float lo = p.relu ? 0.f : -__builtin_inff();
+    // branch-free ReLU on the packed result: a signed 16-bit max with 0 clears negative bf16 values (rounding is
+    // monotone and keeps the sign, so ReLU after the conversion gives the same bits as before it); with 0x8000
+    // (the smallest int16) it is a no-op
+    const unsigned lo2 = p.relu ? 0u : 0x80008000u;
     const int nfbu = __builtin_amdgcn_readfirstlane(nfb);
     unsigned char* lane_base = smem + (size_t)(row_local0 + r32) * sstride + h * 8;
     const float* sbl = sb + h * 4;
@@ -204,13 +206,11 @@ __device__ __forceinline__ void pipe_epilogue_to_lds(const GemmParams& p, const 
                         v0 += __uint_as_float(u.x << 16); v1 += __uint_as_float(u.x & 0xffff0000u);
                         v2 += __uint_as_float(u.y << 16); v3 += __uint_as_float(u.y & 0xffff0000u);
                     }
-                    v0 = __builtin_amdgcn_fmed3f(v0, lo, __builtin_inff());
-                    v1 = __builtin_amdgcn_fmed3f(v1, lo, __builtin_inff());
-                    v2 = __builtin_amdgcn_fmed3f(v2, lo, __builtin_inff());
-                    v3 = __builtin_amdgcn_fmed3f(v3, lo, __builtin_inff());
                     uint2 o;
                     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
                     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
                     *slot = o;
                 }
             }
