@@ -68,7 +68,11 @@ tile_conv_kernel(const TileParams p) {
     constexpr int SST = N * 2 + 16;                    // staging row stride
     constexpr int W_BYTES = NF * KB * 1024;
     constexpr int TAP_BYTES = MODE == MODE_SEP ? 9 * CIN * 4 : 0;
-    constexpr int BUF_OFF = W_BYTES + TAP_BYTES;       // raw halo / output staging share this region
+    // folded-BN scale | bias as fp32 [2][N] in LDS -- except for the 64->128 instance, whose three workgroups
+    // per CU leave no room for it (LDS is handed out in 1280-byte granules: +1 KB costs the third workgroup)
+    constexpr bool SB_LDS = WPE < 3;
+    constexpr int SB_OFF = W_BYTES + TAP_BYTES;
+    constexpr int BUF_OFF = SB_OFF + (SB_LDS ? 2 * N * 4 : 0);   // raw halo / output staging share this region
     static_assert(MODE == MODE_SEP || NPASS == 1, "the 3x3 conv stages all its channels at once");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -83,6 +87,13 @@ tile_conv_kernel(const TileParams p) {
             const float4 wv = *reinterpret_cast<const float4*>(p.dw + i);
             // (w0,w2,w1,w3): the order the packed-FMA depthwise consumes them in
             *reinterpret_cast<float4*>(smem + W_BYTES + i * 4) = make_float4(wv.x, wv.z, wv.y, wv.w);
+        }
+    }
+
+    if (SB_LDS) {
+        for (int i = tid; i < N; i += NT) {
+            reinterpret_cast<float*>(smem + SB_OFF)[i] = p.scale[i];
+            reinterpret_cast<float*>(smem + SB_OFF)[N + i] = p.bias[i];
         }
     }
 
@@ -189,23 +200,32 @@ tile_conv_kernel(const TileParams p) {
             }
         }
 
-        // ---- epilogue: BN + ReLU in registers -> LDS staging (aliases the halo) -> row segments
+        // ---- epilogue: BN + ReLU in registers -> LDS staging (aliases the halo) -> row segments.
+        // Scale and bias come from LDS (per tile they would be 32 KB of L1 traffic per wave, more than the
+        // tile's own pixels); ReLU is a packed int16 max on the converted pair (0x8000 = no-op).
         __syncthreads();                 // every wave is done reading the halo
+        {
+            const unsigned lo2 = p.relu ? 0u : 0x80008000u;
+            const float* sbl = (SB_LDS ? reinterpret_cast<const float*>(smem + SB_OFF) : p.scale) + h * 4;
+            const float* bbl = (SB_LDS ? reinterpret_cast<const float*>(smem + SB_OFF) + N : p.bias) + h * 4;
+            unsigned char* row = smem + BUF_OFF + (wave * 32 + r32) * SST + h * 8;
 #pragma unroll
-        for (int j = 0; j < NF; ++j)
+            for (int j = 0; j < NF; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n0 = j * 32 + g * 8 + h * 4;
-                const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
-                const float4 bi = *reinterpret_cast<const float4*>(p.bias + n0);
-                float v[4] = {fmaf(acc[j][g * 4 + 0], sc.x, bi.x), fmaf(acc[j][g * 4 + 1], sc.y, bi.y),
-                              fmaf(acc[j][g * 4 + 2], sc.z, bi.z), fmaf(acc[j][g * 4 + 3], sc.w, bi.w)};
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int g = 0; g < 4; ++g) {
+                    const int ng = j * 32 + g * 8;
+                    const float4 sc = *reinterpret_cast<const float4*>(sbl + ng);
+                    const float4 bi = *reinterpret_cast<const float4*>(bbl + ng);
+                    const float v0 = fmaf(acc[j][g * 4 + 0], sc.x, bi.x), v1 = fmaf(acc[j][g * 4 + 1], sc.y, bi.y);
+                    const float v2 = fmaf(acc[j][g * 4 + 2], sc.z, bi.z), v3 = fmaf(acc[j][g * 4 + 3], sc.w, bi.w);
+                    uint2 o;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
+                    *reinterpret_cast<uint2*>(row + ng * 2) = o;
                 }
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(smem + BUF_OFF + (wave * 32 + r32) * SST) + n0, v);
-            }
+        }
         __syncthreads();
         {
             const int img = tile / tiles_per_img;
@@ -231,7 +251,7 @@ int launch_tile(const TileParams& p, int num_cus, hipStream_t s) {
     constexpr size_t TAP_BYTES = MODE == MODE_SEP ? 9 * CIN * 4 : 0;
     constexpr size_t RAW_BYTES = (size_t)RH * ((RW * ((CIN < 64 ? CIN : 64) * 2 + 16) + 255) / 256 * 256);
     constexpr size_t STAGE_BYTES = (size_t)TH * TW * (NF * 64 + 16);
-    constexpr size_t lds = W_BYTES + TAP_BYTES + (RAW_BYTES > STAGE_BYTES ? RAW_BYTES : STAGE_BYTES);
+    constexpr size_t lds = W_BYTES + TAP_BYTES + (WPE < 3 ? (size_t)NF * 32 * 8 : 0) + (RAW_BYTES > STAGE_BYTES ? RAW_BYTES : STAGE_BYTES);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     auto kern = tile_conv_kernel<MODE, CIN, NF, RELU_IN, WPE>;
     static bool set = false;
