@@ -269,6 +269,27 @@ __device__ __forceinline__ void residual_dma_row_asm(const GemmParams& p, int m0
     }
 }
 
+// Halo rows of chunk c straight into a raw buffer by LDS-DMA (layers without a ReLU in front: the staged bytes
+// are the input bytes).  One instruction = 8 halo pixels x 128 B, contiguous in LDS; instructions k = first,
+// first + step, ... are this wave's.  Rows outside the tensor stay stale (their taps are masked to zero bytes by
+// the depthwise stage's permutes), pieces past K re-read the last valid piece, like the register path.
+__device__ __forceinline__ void halo_dma_asm(const bf16_t* __restrict__ in, int ldi, int c, int K, int p_lo, int M,
+                                             int HP, int lane, int first, int step, unsigned lds_raw) {
+    int coff = c * KC + (lane & 7) * 8;
+    coff = coff < K - 8 ? coff : K - 8;
+    for (int k = first; k * 8 < HP; k += step) {
+        const int row = k * 8 + (lane >> 3);
+        const int prow = p_lo + row;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_raw + (unsigned)k * 1024u);
+        if (row < HP && prow >= 0 && prow < M) {
+            const bf16_t* g = in + (size_t)prow * ldi + coff;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+        }
+    }
+}
+
 // diagnostic s_memtime stamps (BQ_STAMPS; p.stamps is null in production)
 #define PSTAMP(ev) do { if (stp && (tid & 63) == 0) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -328,7 +349,17 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
 
     // ---- prologue: every global load the first stages need is issued up front (halo chunk 0, the
     // first B fragments, then the taps), so their latencies overlap instead of adding up
-    Raw3 rreg = raw_load<NT, NRAW>(in, ldi, 0, K, jch, tid, p_lo, p.M);
+    // halo rows by LDS-DMA (no registers, no staging pass) where the layer has no ReLU in front.  256-wide
+    // instances only: 256->256 @74x74 0.73 -> 0.67 ms; the 728-wide ones measured 1-2 % slower with it
+    constexpr bool HDMA = !RELU && RN == 1;
+    constexpr int HSTEP = WN * WM / 2;             // issued by the D-first half of the waves only
+    Raw3 rreg;
+    if constexpr (HDMA) {
+        halo_dma_asm(in, ldi, 0, K, p_lo, p.M, HP, tid & 63, __builtin_amdgcn_readfirstlane(tid >> 6), NT / 64,
+                     (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem0 + (unsigned)lb);
+    } else {
+        rreg = raw_load<NT, NRAW>(in, ldi, 0, K, jch, tid, p_lo, p.M);
+    }
     constexpr int nfp32 = WN * RN * 32;
     constexpr int NSB = (nfp32 + NT - 1) / NT;
     float sbv[NSB][2];
@@ -350,6 +381,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     const bool first_half = __builtin_amdgcn_readfirstlane(wave) < WN * WM / 2;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem0;
+    const unsigned lds_raw0 = lds_base + (unsigned)lb;
     const uint4* __restrict__ wp = reinterpret_cast<const uint4*>(p.wp);
     const uint4* bp0 = wp + ((size_t)nfb * p.KBtot + p.kb0) * 64 + lane;
     uint4 bq[PF][RN];
@@ -411,14 +443,23 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     }
 
     // raw(0) -> LDS, D(0), raw(1) -> LDS, raw(2) in flight
-    raw_store<NT, RELU, NRAW>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
-    rreg = raw_load<NT, NRAW>(in, ldi, 1, K, jch, tid, p_lo, p.M);
+    if constexpr (HDMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of raw[0] has landed
+    } else {
+        raw_store<NT, RELU, NRAW>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
+        rreg = raw_load<NT, NRAW>(in, ldi, 1, K, jch, tid, p_lo, p.M);
+    }
     PSTAMP(1);
     __syncthreads();                               // raw[0] and the taps are visible
     PSTAMP(2);
+    if constexpr (HDMA) halo_dma_asm(in, ldi, 1, K, p_lo, p.M, HP, lane, wave_u, NT / 64, lds_raw0 + raw_bytes);
     depthwise<NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
-    raw_store<NT, RELU, NRAW>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
-    rreg = raw_load<NT, NRAW>(in, ldi, 2, K, jch, tid, p_lo, p.M);
+    if constexpr (HDMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        raw_store<NT, RELU, NRAW>(rreg, smem, raw_bytes, jch, tid, p_lo, HP, p.M);
+        rreg = raw_load<NT, NRAW>(in, ldi, 2, K, jch, tid, p_lo, p.M);
+    }
 
     f32x16 acc[MF][RN];
 #pragma unroll
@@ -435,7 +476,9 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         const int cur = c & 1, nxt = cur ^ 1;
         // L: raw chunk c+2 (loaded during the previous iteration) -> raw[cur], whose last reader D(c)
         // finished before the previous barrier
-        if (c + 2 < NC && !(p.dbg & 16)) raw_store<NT, RELU, NRAW>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
+        if constexpr (!HDMA) {
+            if (c + 2 < NC && !(p.dbg & 16)) raw_store<NT, RELU, NRAW>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
+        }
         // D (depthwise of chunk c+1, vector ALU) and G (matrix cores on chunk c) are independent.
         // Each SIMD hosts one wave of each half of the workgroup: run them in opposite order so
         // one wave's vector-ALU stage overlaps its partner's matrix-core stage.  The halo loads of
@@ -447,7 +490,14 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         const int dma_lo = c == NC - 2 ? npre : c == NC - 1 ? n1 : c * (NT / 64);
         const int dma_hi = c == NC - 2 ? n1 : c == NC - 1 ? n2 : min(npre, (c + 1) * (NT / 64));
         if (first_half) {
-            if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+            if constexpr (HDMA) {
+                // chunk c+2 -> raw[cur] (its last reader, D(c), finished before the previous barrier); only the
+                // waves that run D first issue these: in front of G they would delay the B ring (in-order vmcnt)
+                if (c + 2 < NC && !(p.dbg & 16))
+                    halo_dma_asm(in, ldi, c + 2, K, p_lo, p.M, HP, lane, wave_u, HSTEP, lds_raw0 + cur * raw_bytes);
+            } else {
+                if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+            }
             for (int r = dma_lo + wave_u; r < dma_hi; r += NT / 64) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, r);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
@@ -457,13 +507,19 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
         PSTAMP(6 + 4 * c);
         if (!first_half) {
-            if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+            if constexpr (!HDMA) {
+                if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+            }
             for (int r = dma_lo + wave_u; r < dma_hi; r += NT / 64) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, r);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask, p.dbg);
         }
         PSTAMP(7 + 4 * c);
+        if constexpr (HDMA) {
+            // the halo DMA is older than the PF*RN ring loads this wave's G stage left in flight
+            if (first_half) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PF * RN) : "memory");
+        }
         __syncthreads();
         PSTAMP(8 + 4 * c);
     }
