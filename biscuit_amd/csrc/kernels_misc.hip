@@ -178,15 +178,25 @@ __global__ void __launch_bounds__(256) stem1_kernel(const T* __restrict__ in, in
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 x[(dy * 3 + dx) * 3 + c] = to_f32<T>(base[(size_t)c * px * px + (2 * yo + dy) * px + 2 * xo + dx]);
+    // two output channels per v_pk_fma_f32 (weights as scalar-register pairs, the pixel value splat): the
+    // kernel is bound by its 864 multiply-adds per pixel, not by memory
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    f32x2s acc2[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) acc2[co] = (f32x2s){0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const f32x2s xs = {x[k], x[k]};
+#pragma unroll
+        for (int co = 0; co < 16; ++co)
+            acc2[co] = __builtin_elementwise_fma(xs, (f32x2s){w[k * 32 + 2 * co], w[k * 32 + 2 * co + 1]}, acc2[co]);
+    }
     float acc[32];
 #pragma unroll
-    for (int co = 0; co < 32; ++co) acc[co] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 27; ++k)
-#pragma unroll
-        for (int co = 0; co < 32; ++co) acc[co] = fmaf(x[k], w[k * 32 + co], acc[co]);
-#pragma unroll
-    for (int co = 0; co < 32; ++co) acc[co] = fmaxf(fmaf(acc[co], scale[co], bias[co]), 0.f);
+    for (int co = 0; co < 16; ++co) {
+        acc[2 * co] = fmaxf(fmaf(acc2[co].x, scale[2 * co], bias[2 * co]), 0.f);
+        acc[2 * co + 1] = fmaxf(fmaf(acc2[co].y, scale[2 * co + 1], bias[2 * co + 1]), 0.f);
+    }
     T* o = out + (size_t)gid * 32;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
