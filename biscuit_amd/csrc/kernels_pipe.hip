@@ -290,6 +290,36 @@ __device__ __forceinline__ void halo_dma_asm(const bf16_t* __restrict__ in, int 
     }
 }
 
+// The same stage with the A fragments of k-block d+1 read from LDS before the MFMAs of k-block d (12 more live
+// registers: only for instances that have them to spare).
+template <int MF, int RN, int PF, int KBC>
+__device__ __forceinline__ void mma_chunk_pre(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
+                                              int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot) {
+    uint4 a[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR);
+#pragma unroll
+    for (int d = 0; d < KBC; ++d) {
+        const int kb = c * KBC + d;
+        uint4 an[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+            an[i] = d + 1 < KBC ? *reinterpret_cast<const uint4*>(smem + a_base + i * 32 * A_STR + (d + 1) * 32) : a[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
+        const int nx = kb + PF;
+        const int idx = nx < KB ? nx : KB - 1;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * KBtot + idx) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MF; ++i) a[i] = an[i];
+    }
+}
+
 // diagnostic s_memtime stamps (BQ_STAMPS; p.stamps is null in production)
 #define PSTAMP(ev) do { if (stp && (tid & 63) == 0) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -351,7 +381,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     // first B fragments, then the taps), so their latencies overlap instead of adding up
     // halo rows by LDS-DMA (no registers, no staging pass) where the layer has no ReLU in front.  256-wide
     // instances only: 256->256 @74x74 0.73 -> 0.67 ms; the 728-wide ones measured 1-2 % slower with it
-    constexpr bool HDMA = !RELU && RN == 1;
+    constexpr bool HDMA = !RELU;
     constexpr int HSTEP = WN * WM / 2;             // issued by the D-first half of the waves only
     Raw3 rreg;
     if constexpr (HDMA) {
@@ -504,7 +534,11 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
                                          tid, item_mask, p.dbg);
         }
         PSTAMP(5 + 4 * c);
-        if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
+        if constexpr (HDMA && RN == 3) {
+            if (!(p.dbg & 2)) mma_chunk_pre<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+        } else {
+            if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
+        }
         PSTAMP(6 + 4 * c);
         if (!first_half) {
             if constexpr (!HDMA) {
