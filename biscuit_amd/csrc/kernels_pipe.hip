@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
                                          tid, item_mask, p.dbg);
         }
         PSTAMP(5 + 4 * c);
-        if constexpr (HDMA && RN == 3) {
+        if constexpr (RN == 3) {
             if (!(p.dbg & 2)) mma_chunk_pre<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
         } else {
             if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
