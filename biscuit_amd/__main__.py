@@ -24,7 +24,10 @@ def main(argv=None):
     src.add_argument('--tfrecords', help='directory of Slideflow *.tfrecords (one per slide)')
     src.add_argument('--synthetic', help='SxT: S synthetic slides of T tiles')
     ap.add_argument('--labels', help='CSV with slide,label[,patient]')
-    ap.add_argument('--weights', help='npz written by biscuit_amd.weights.save_npz (default: seeded random init)')
+    ap.add_argument('--weights', help='weights: .npz / .safetensors under Keras variable names, a TensorFlow checkpoint '
+                                      'prefix, or a Keras SavedModel directory (default: seeded random init)')
+    ap.add_argument('--model', help='Slideflow model directory (find_model, biscuit/utils.py:233-272): SavedModel weights '
+                                    'plus params.json (norm_fit, outcome labels); replaces --weights and --params')
     ap.add_argument('--outcome', default='cohort')
     ap.add_argument('--out', required=True)
     ap.add_argument('--mc', type=int, default=30)
@@ -44,7 +47,15 @@ def main(argv=None):
     from .synthetic import make_slides
 
     rank, world, local = D.init_from_env('cuda')
-    w = W.load_npz(args.weights) if args.weights else W.synthetic_weights(1)
+    model_params = None
+    if args.model:
+        from .keras_import import load_model_dir
+        w, model_params = load_model_dir(args.model)
+    elif args.weights:
+        from .keras_import import load_weights
+        w = load_weights(args.weights)
+    else:
+        w = W.synthetic_weights(1)
     patients = None
     if args.tfrecords:
         lab = pd.read_csv(args.labels, dtype={'slide': str}) if args.labels else pd.DataFrame(columns=['slide', 'label'])
@@ -56,7 +67,7 @@ def main(argv=None):
         s, t = (int(x) for x in args.synthetic.lower().split('x'))
         tiles, sidx, y = make_slides(s, t, seed=0)
         slides = [Slide(f'slide{i:03d}', tiles[sidx == i], t, y_true=int(y[i])) for i in range(s)]
-    norm_fit = None
+    norm_fit = model_params.get('norm_fit') if model_params else None
     if args.params:
         with open(args.params) as f:
             norm_fit = json.load(f).get('norm_fit')

@@ -1,0 +1,282 @@
+"""Weight import from a Slideflow / Keras model directory.
+
+The reference evaluates a trained model found by ``biscuit/utils.py:233-272`` (``find_model``: the directory
+``{models_dir}/NNNNN-{outcome}-{label}-HP0/{outcome}-{label}-HP0_epoch1``) through
+``Project.evaluate(model=...)`` (``biscuit/experiment.py:912-922``); Slideflow writes it as a Keras
+SavedModel (``saved_model.pb`` + ``variables/``) next to a ``params.json`` that carries the stain
+normaliser fit (``norm_fit``), the hyper-parameters (``hp``, cf. ``biscuit/hp.py:3-23``) and the outcome
+labels.  ``load_model_dir`` turns that directory into the canonical weight dict of ``biscuit_amd.weights``
+(float32 arrays under Keras variable names) without TensorFlow:
+
+  * variables are read with ``tf_bundle.BundleReader``; optimizer slots, metrics and counters are skipped;
+  * object-based checkpoints name variables by their path from the model object
+    (``layer_with_weights-0/layer_with_weights-7/depthwise_kernel/.ATTRIBUTES/VARIABLE_VALUE``), not by
+    layer name, so layers are put in order by those indices (nested models expand in place) and matched
+    to the architecture of keras.applications.Xception + Slideflow's two hidden layers by kind and shape:
+    the 3x3 convolutions are ``block1_conv1/2``, the separable convolutions are ``sepconv_plan()`` in order,
+    the 1x1 convolutions the four residual branches in order, the dense layers ``hidden_0``, ``hidden_1``,
+    ``logits``; a BatchNormalization belongs to the closest preceding convolution that has none yet
+    (Keras lists ``block2_sepconv2_bn, conv2d, block2_pool, batch_normalization``).  Every shape is checked;
+    anything unexpected is an error, never a guess.
+
+PARITY UNPINNED: no TensorFlow-written model exists in the container or the reference repository; the tests
+round-trip synthetic weights through this module's own writer in the Keras order described above.
+"""
+import json
+import os
+import re
+
+import numpy as np
+
+from . import tf_bundle, weights as W
+
+_SUFFIX = '/.ATTRIBUTES/VARIABLE_VALUE'
+_BN_VARS = ('gamma', 'beta', 'moving_mean', 'moving_variance')
+
+
+class ImportError_(ValueError):
+    """The directory does not hold the hp.nature2022 classifier (or not in a layout this importer knows)."""
+
+
+def keras_layer_order(n_hidden=2):
+    """[(canonical layer name, kind)] of the layers with weights, in the order Keras lists them
+    (``model.layers``: by depth, so a residual 1x1 conv sits between the block's last BN and its own BN)."""
+    order = [('block1_conv1', 'conv'), ('block1_conv1_bn', 'bn'), ('block1_conv2', 'conv'), ('block1_conv2_bn', 'bn')]
+
+    def sep(block, n):
+        for i in range(1, n + 1):
+            order.append((f'block{block}_sepconv{i}', 'sep'))
+            order.append((f'block{block}_sepconv{i}_bn', 'bn'))
+
+    def res(block):
+        order.append((f'block{block}_res_conv', 'conv'))
+        order.append((f'block{block}_res_bn', 'bn'))
+    for block in (2, 3, 4):
+        sep(block, 2)
+        res(block)
+    for block in range(5, 13):
+        sep(block, 3)
+    sep(13, 2)
+    res(13)
+    sep(14, 2)
+    order += [(f'hidden_{i}', 'dense') for i in range(n_hidden)] + [('logits', 'dense')]
+    return order
+
+
+def _layer_key(path):
+    """('layer_with_weights-0', 'layer_with_weights-12') -> (0, 12); None if a component is not indexed."""
+    out = []
+    for comp in path:
+        m = re.fullmatch(r'layer_with_weights-(\d+)', comp)
+        if not m:
+            return None
+        out.append(int(m.group(1)))
+    return tuple(out)
+
+
+def _collect_layers(reader):
+    layers = {}
+    skipped = []
+    for key in reader.keys():
+        if not key.endswith(_SUFFIX) or '.OPTIMIZER_SLOT' in key:
+            continue
+        path = key[:-len(_SUFFIX)].split('/')
+        if path[0] in ('optimizer', 'keras_api', 'save_counter') or len(path) < 2:
+            continue
+        lk = _layer_key(path[:-1])
+        if lk is None:
+            skipped.append(key)
+            continue
+        layers.setdefault(lk, {})[path[-1]] = key
+    if not layers:
+        raise ImportError_('no layer_with_weights-N/... variables in the checkpoint '
+                           f'(keys look like {reader.keys()[:3]}): not an object-based Keras checkpoint')
+    return [layers[k] for k in sorted(layers)], skipped
+
+
+def _kind(vars_, reader):
+    names = set(vars_)
+    if names >= set(_BN_VARS) and names <= set(_BN_VARS):
+        return 'bn'
+    if 'depthwise_kernel' in names and 'pointwise_kernel' in names and names <= {'depthwise_kernel', 'pointwise_kernel', 'bias'}:
+        return 'sep'
+    if 'kernel' in names and names <= {'kernel', 'bias'}:
+        nd = len(reader.shape(vars_['kernel']))
+        return 'conv' if nd == 4 else 'dense' if nd == 2 else None
+    return None
+
+
+def from_bundle(prefix, verify=True):
+    """Canonical weight dict from a checkpoint prefix / ``variables`` directory / SavedModel directory."""
+    reader = tf_bundle.BundleReader(prefix, verify=verify)
+    layers, _ = _collect_layers(reader)
+    kinds = []
+    for n, lv in enumerate(layers):
+        k = _kind(lv, reader)
+        if k is None:
+            raise ImportError_(f'layer {n} has variables {sorted(lv)}: not a layer of the Xception classifier')
+        kinds.append(k)
+    convs3 = [i for i, (k, lv) in enumerate(zip(kinds, layers)) if k == 'conv' and reader.shape(lv['kernel'])[:2] == (3, 3)]
+    convs1 = [i for i, (k, lv) in enumerate(zip(kinds, layers)) if k == 'conv' and reader.shape(lv['kernel'])[:2] == (1, 1)]
+    seps = [i for i, k in enumerate(kinds) if k == 'sep']
+    dense = [i for i, k in enumerate(kinds) if k == 'dense']
+    plan_s, plan_r = W.sepconv_plan(), W.residual_plan()
+    if len(convs3) != 2 or len(convs1) != len(plan_r) or len(seps) != len(plan_s) or len(convs3) + len(convs1) != kinds.count('conv'):
+        raise ImportError_(f'found {len(convs3)} 3x3 convolutions, {len(convs1)} 1x1 convolutions, {len(seps)} separable '
+                           f'convolutions; keras.applications.Xception has 2, {len(plan_r)} and {len(plan_s)}')
+    if len(dense) != 3:
+        raise ImportError_(f'found {len(dense)} dense layers; hp.nature2022 (biscuit/hp.py:13,21) has hidden_layers=2 + logits')
+    name_of = {convs3[0]: 'block1_conv1', convs3[1]: 'block1_conv2'}
+    name_of.update({i: plan_r[n][0] + '_conv' for n, i in enumerate(convs1)})
+    name_of.update({i: plan_s[n][0] for n, i in enumerate(seps)})
+    name_of.update({dense[0]: 'hidden_0', dense[1]: 'hidden_1', dense[2]: 'logits'})
+    # BatchNormalization -> the closest preceding convolution without one; two in a row cannot be told apart
+    bn_of, open_convs = {}, []
+    prev_bn = False
+    for i, k in enumerate(kinds):
+        if k in ('conv', 'sep'):
+            open_convs.append(i)
+            prev_bn = False
+        elif k == 'bn':
+            if not open_convs:
+                raise ImportError_(f'layer {i}: BatchNormalization with no convolution in front of it')
+            if prev_bn and len(open_convs) > 0:
+                raise ImportError_(f'layers {i - 1},{i}: two BatchNormalization layers in a row, ambiguous layer order')
+            bn_of[open_convs.pop()] = i
+            prev_bn = True
+        else:
+            prev_bn = False
+    if open_convs:
+        raise ImportError_(f'{name_of[open_convs[0]]}: no BatchNormalization found for it')
+
+    def bn_name(conv):
+        return conv[:-len('_conv')] + '_bn' if conv.endswith('_res_conv') else conv + '_bn'
+    w = {}
+    for i, name in name_of.items():
+        lv = layers[i]
+        for var, key in lv.items():
+            if var != 'bias' or kinds[i] == 'dense':
+                w[f'{name}/{var}'] = reader.tensor(key).astype(np.float32)
+        if kinds[i] in ('conv', 'sep'):
+            bl = layers[bn_of[i]]
+            for var in _BN_VARS:
+                w[f'{bn_name(name)}/{var}'] = reader.tensor(bl[var]).astype(np.float32)
+            if 'bias' in lv:        # y = BN(conv + b): fold the bias into the moving mean
+                w[f'{bn_name(name)}/moving_mean'] = w[f'{bn_name(name)}/moving_mean'] - reader.tensor(lv['bias']).astype(np.float32)
+    n_classes = int(w['logits/kernel'].shape[-1]) if w['logits/kernel'].ndim == 2 else -1
+    try:
+        return W.validate(w, n_classes)
+    except ValueError as e:
+        raise ImportError_(str(e)) from None
+
+
+def from_named(arrays):
+    """Canonical weight dict from arrays under Keras names (``model.get_layer(n).get_weights()`` exported to
+    npz / safetensors): residual layers may carry Keras' automatic names (``conv2d``, ``conv2d_1`` ...,
+    ``batch_normalization`` ...), variable names may end in ``:0``, the output layer may have any name."""
+    def base(k):
+        k = k.replace('__', '/')
+        return k[:-2] if k.endswith(':0') else k
+    arrays = {base(k): np.asarray(v, np.float32) for k, v in arrays.items()}
+
+    def family(prefix):
+        names = sorted({k.split('/')[0] for k in arrays if re.fullmatch(prefix + r'(_\d+)?', k.split('/')[0])},
+                       key=lambda n: int(n[len(prefix) + 1:]) if len(n) > len(prefix) else 0)
+        return names
+    ren = {}
+    plan_r = W.residual_plan()
+    convs, bns = family('conv2d'), family('batch_normalization')
+    if convs or bns:
+        if len(convs) != len(plan_r) or len(bns) != len(plan_r):
+            raise ImportError_(f'{len(convs)} conv2d* / {len(bns)} batch_normalization* layers; expected {len(plan_r)} each')
+        for (name, _, _), c, b in zip(plan_r, convs, bns):
+            ren[c], ren[b] = name + '_conv', name + '_bn'
+    known = set(k.split('/')[0] for k in W.expected_shapes())
+    others = sorted({k.split('/')[0] for k in arrays} - known - set(ren))
+    if 'logits' not in {k.split('/')[0] for k in arrays} and len(others) == 1:
+        ren[others[0]] = 'logits'
+    w = {}
+    for k, v in arrays.items():
+        layer, _, var = k.partition('/')
+        w[f'{ren.get(layer, layer)}/{var}'] = v
+    n_classes = int(w['logits/kernel'].shape[-1]) if 'logits/kernel' in w else 2
+    try:
+        return W.validate(w, n_classes)
+    except ValueError as e:
+        raise ImportError_(str(e)) from None
+
+
+def save_safetensors(path, w):
+    from safetensors.numpy import save_file
+    save_file({k: np.ascontiguousarray(v, np.float32) for k, v in W.validate(w, _ncls(w)).items()}, path)
+
+
+def load_safetensors(path):
+    from safetensors.numpy import load_file
+    return from_named(load_file(path))
+
+
+def _ncls(w):
+    return int(np.shape(w['logits/kernel'])[-1])
+
+
+def read_params(model_dir):
+    """``params.json`` of a Slideflow model directory (or of its parent): the fields this path uses.
+    Returns {'norm_fit', 'normalizer', 'outcome_labels', 'outcomes', 'hp', 'tile_px'} with None for what
+    is absent, and raises if the hyper-parameters are not the hp.nature2022 classifier (biscuit/hp.py:3-23)."""
+    for d in (model_dir, os.path.dirname(os.path.abspath(model_dir))):
+        p = os.path.join(d, 'params.json')
+        if os.path.isfile(p):
+            with open(p) as f:
+                raw = json.load(f)
+            break
+    else:
+        return None
+    hp = raw.get('hp') or {}
+    want = {'model': 'xception', 'tile_px': 299, 'hidden_layers': 2, 'hidden_layer_width': 1024}
+    bad = {k: hp[k] for k, v in want.items() if k in hp and hp[k] != v}
+    if bad:
+        raise ImportError_(f'{p}: hyper-parameters {bad} differ from hp.nature2022 {want}')
+    return {'norm_fit': raw.get('norm_fit'), 'normalizer': hp.get('normalizer', raw.get('normalizer')),
+            'outcome_labels': raw.get('outcome_labels'), 'outcomes': raw.get('outcomes'), 'hp': hp,
+            'tile_px': raw.get('tile_px', hp.get('tile_px')), 'dropout': hp.get('dropout'), 'path': p}
+
+
+def load_weights(path, verify=True):
+    """One entry point for ``--weights``: ``.npz`` (``weights.save_npz`` or Keras-named), ``.safetensors``,
+    a checkpoint prefix, a ``variables`` directory or a SavedModel / Slideflow model directory."""
+    if os.path.isfile(path) and path.endswith('.npz'):
+        with np.load(path) as z:
+            return from_named({k: z[k] for k in z.files})
+    if os.path.isfile(path) and path.endswith('.safetensors'):
+        return load_safetensors(path)
+    return from_bundle(path, verify=verify)
+
+
+def load_model_dir(model_dir, verify=True):
+    """(weights, params) of a Slideflow model directory; params is None without a params.json."""
+    return from_bundle(model_dir, verify=verify), read_params(model_dir)
+
+
+def export_bundle(prefix, w, nested=True, optimizer_slots=False):
+    """Write the canonical dict as an object-based Keras checkpoint in Keras' layer order (the inverse of
+    ``from_bundle``; ``nested`` puts the backbone under ``layer_with_weights-0`` like a base model called
+    inside the classifier).  Test fixture generator and an exit path back to TensorFlow."""
+    tensors = {'_CHECKPOINTABLE_OBJECT_GRAPH': b'', 'save_counter' + _SUFFIX: np.asarray(1, np.int64)}
+    idx_backbone = idx_top = 0
+    for name, kind in keras_layer_order():
+        if kind == 'dense' or not nested:
+            path = f'layer_with_weights-{(idx_top + 1) if nested else idx_top}'
+            idx_top += 1
+        else:
+            path = f'layer_with_weights-0/layer_with_weights-{idx_backbone}'
+            idx_backbone += 1
+        for k, v in w.items():
+            layer, _, var = k.partition('/')
+            if layer == name:
+                tensors[f'{path}/{var}{_SUFFIX}'] = np.asarray(v, np.float32)
+                if optimizer_slots and var in ('kernel', 'pointwise_kernel'):
+                    tensors[f'{path}/{var}/.OPTIMIZER_SLOT/optimizer/m{_SUFFIX}'] = np.zeros_like(v, np.float32)
+    if optimizer_slots:
+        tensors['optimizer/iter' + _SUFFIX] = np.asarray(7, np.int64)
+    tf_bundle.write_bundle(prefix, tensors)
