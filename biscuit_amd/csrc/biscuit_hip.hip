@@ -477,7 +477,12 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
         if (it == c->layers.end()) return fail(c, BQ_ERR_WEIGHTS, "head weights not loaded");
         const GemmLayer& G = it->second;
         const int K = G.kpad;                    // 2048 / 1024
-        const int nsplit = K / 1024;             // K handled per launch = 1024 (131.6 KB of LDS)
+        // K handled per launch = 1024 (131.6 KB of LDS for the 32-row A tile: one workgroup per CU, and
+        // 7 680 rows are only 240 workgroups, so the launch is one latency chain per CU).  BQ_HEAD_WAVES=4
+        // restores the 4-wave workgroup.
+        static const bool w8 = !(getenv("BQ_HEAD_WAVES") && atoi(getenv("BQ_HEAD_WAVES")) == 4);
+        const int KS = 1024;
+        const int nsplit = K / KS;
         ProfScope ps(c, s, layer == 0 ? "mc_head_dense0" : "mc_head_dense1", 2.0 * rows * (double)K * 1024,
                      4.0 * ((layer == 0 ? (double)n : (double)rows) * K + (double)rows * 1024 + (double)K * 1024));
         for (int sp = 0; sp < nsplit; ++sp) {
@@ -489,13 +494,13 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
             p.bias = last ? G.bias : nullptr;
             p.residual = sp > 0 ? hpart : nullptr;
             p.out = last ? (layer == 0 ? h0 : h1) : hpart;
-            p.M = rows; p.K = 1024; p.KBtot = K / 8; p.kb0 = sp * 128; p.k_off = sp * 1024;
+            p.M = rows; p.K = KS; p.KBtot = K / 8; p.kb0 = sp * (KS / 8); p.k_off = sp * KS;
             p.NFp = G.nfp; p.Nstore = 1024; p.ldo = 1024; p.ldi = K;
             p.relu = last ? 1 : 0;
             p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32);
             p.thresh = thresh; p.dscale = dscale; p.layer = layer; p.mc_n = mc_n; p.pass0 = pass0;
             p.in_row_is_tile = layer == 0 ? 1 : 0; p.tile0 = tile0;
-            const int e = launch_gemm(BQ_DTYPE_F32, PROD_DROPOUT, SHAPE_H, p, s);
+            const int e = launch_gemm(BQ_DTYPE_F32, PROD_DROPOUT, w8 ? SHAPE_I : SHAPE_H, p, s);
             if (e) return fail(c, BQ_ERR_HIP, std::string("head dense launch: ") + hipGetErrorString((hipError_t)e));
         }
     }

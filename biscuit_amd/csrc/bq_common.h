@@ -26,7 +26,8 @@ enum BqShape : int {       // MF, WM, WN, RN   (tile rows = 32*MF, waves = WM*WN
     SHAPE_E = 4,           // 3, 1, 8, 2   N = 512 per pass
     SHAPE_F = 5,           // 2, 1, 8, 3
     SHAPE_G = 6,           // 1, 1, 8, 4
-    SHAPE_H = 7            // 1, 1, 4, 2   fp32 fallback / MC head
+    SHAPE_H = 7,           // 1, 1, 4, 2   fp32 fallback
+    SHAPE_I = 8            // 1, 1, 8, 2   MC head: 8 waves on a 32-row tile
 };
 
 struct GemmParams {
