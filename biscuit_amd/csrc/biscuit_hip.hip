@@ -143,6 +143,10 @@ struct ProfScope {
 int pick_shape(const bq_ctx* c, int prod, int nfp) {
     if (prod == PROD_IM2COL) return SHAPE_A;
     if (c->cfg.dtype == BQ_DTYPE_BF16) {
+        static const bool s2_small = !getenv("BQ_S2_BIG");
+        // 64-row tiles halve the staging tile: four workgroups per CU instead of two for N = 256
+        // (128->256 @37x37: 0.161 -> 0.111 ms); for N = 128 they measured slower (0.194 -> 0.234 ms)
+        if (prod == PROD_S2 && s2_small && nfp == 8) return SHAPE_K;
         switch (nfp) {
             case 4: return SHAPE_B;
             case 8: return SHAPE_C;

@@ -27,7 +27,9 @@ enum BqShape : int {       // MF, WM, WN, RN   (tile rows = 32*MF, waves = WM*WN
     SHAPE_F = 5,           // 2, 1, 8, 3
     SHAPE_G = 6,           // 1, 1, 8, 4
     SHAPE_H = 7,           // 1, 1, 4, 2   fp32 fallback
-    SHAPE_I = 8            // 1, 1, 8, 2   MC head: 8 waves on a 32-row tile
+    SHAPE_I = 8,           // 1, 1, 8, 2   MC head: 8 waves on a 32-row tile
+    SHAPE_J = 9,           // 2, 1, 4, 1   N = 128, 64-row tiles (1x1/s2 residual convs: more workgroups per CU)
+    SHAPE_K = 10           // 2, 1, 4, 2   N = 256, 64-row tiles
 };
 
 struct GemmParams {

@@ -256,8 +256,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_fused_kernel(const GemmPara
 }
 
 struct ShapeDesc { int MF, WM, WN, RN; };
-constexpr ShapeDesc kShapes[9] = {{4, 2, 2, 1}, {4, 1, 4, 1}, {4, 1, 4, 2}, {3, 1, 8, 3},
-                                  {3, 1, 8, 2}, {2, 1, 8, 3}, {1, 1, 8, 4}, {1, 1, 4, 2}, {1, 1, 8, 2}};
+constexpr ShapeDesc kShapes[11] = {{4, 2, 2, 1}, {4, 1, 4, 1}, {4, 1, 4, 2}, {3, 1, 8, 3}, {3, 1, 8, 2}, {2, 1, 8, 3},
+                                   {1, 1, 8, 4}, {1, 1, 4, 2}, {1, 1, 8, 2}, {2, 1, 4, 1}, {2, 1, 4, 2}};
 
 template <typename T, int PROD, int SH>
 int launch_inst(const GemmParams& p, hipStream_t s) {
@@ -310,6 +310,7 @@ int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t
         BQ_CASE(bf16_t, PROD_S2, SHAPE_D)
         BQ_CASE(bf16_t, PROD_DW, SHAPE_E)
         BQ_CASE(bf16_t, PROD_S2, SHAPE_E)
+        BQ_CASE(bf16_t, PROD_S2, SHAPE_K)
         BQ_CASE(bf16_t, PROD_DW, SHAPE_F)
         BQ_CASE(bf16_t, PROD_DW, SHAPE_G)
     } else {
