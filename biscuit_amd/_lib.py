@@ -44,6 +44,8 @@ ABI = {
     'bq_mc_head': (_i, [_vp, _vp, _i, _i64, _i, _i, _u64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'bq_mc_infer': (_i, [_vp, _vp, _i, _i64, _i, _u64, _i, _vp, _vp, _vp, _sz, _vp]),
     'bq_slide_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    'bq_roc_workspace_bytes': (_sz, [_i64]),
+    'bq_roc_youden': (_i, [_vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp]),
     'bq_slide_finish': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     'bq_profile_enable': (_i, [_vp, _i]),
     'bq_profile_read': (_i, [_vp, C.POINTER(BqProfEntry), _i]),

@@ -824,6 +824,20 @@ int bq_slide_finish(bq_ctx* c, const int64_t* d_acc_pred, const int64_t* d_acc_u
     return BQ_OK;
 }
 
+size_t bq_roc_workspace_bytes(int64_t n) { return roc_workspace_bytes((long long)n); }
+
+int bq_roc_youden(bq_ctx* c, const double* d_score, const uint8_t* d_label, int64_t n, void* d_ws, size_t ws_bytes,
+                  double* d_out6, bq_stream_t stream) {
+    if (!c || !d_score || !d_label || !d_ws || !d_out6 || n <= 0 || n > 0x7fffffffLL)
+        return fail(c, BQ_ERR_ARG, "bq_roc_youden: bad argument");
+    if (ws_bytes < roc_workspace_bytes(n)) return fail(c, BQ_ERR_ARG, "bq_roc_youden: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(c, s, "roc_youden", 4.0 * n, 60.0 * n);
+    const int e = launch_roc_youden(d_score, d_label, (long long)n, (unsigned char*)d_ws, ws_bytes, d_out6, s);
+    if (e) return fail(c, BQ_ERR_HIP, std::string("roc_youden: ") + hipGetErrorString((hipError_t)e));
+    return BQ_OK;
+}
+
 int bq_profile_enable(bq_ctx* c, int on) {
     if (!c) return BQ_ERR_ARG;
     c->prof = on != 0;

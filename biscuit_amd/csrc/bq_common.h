@@ -94,6 +94,9 @@ int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long til
 int launch_slide_reduce(const float* mean2, const float* std2, const int32_t* slide_idx, int n,
                         int n_slides, float tile_uq, long long* acc_pred, long long* acc_unc,
                         int32_t* count, hipStream_t s);
+size_t roc_workspace_bytes(long long n);
+int launch_roc_youden(const double* score, const unsigned char* label, long long n, unsigned char* ws, size_t ws_bytes,
+                      double* out, hipStream_t s);
 int launch_slide_finish(const long long* acc_pred, const long long* acc_unc, const int32_t* count,
                         int n_slides, double* mean_pred, double* mean_unc, hipStream_t s);
 int launch_to_f32_nhwc(const void* x, long long rows, int C, int ld, float* out, int dtype,

@@ -190,6 +190,34 @@ class Engine:
                                               n_slides, _ptr(mp), _ptr(mu), self._stream()))
         return mp, mu, acc[2]
 
+    def youden(self, y_true, y_score):
+        """Youden threshold of the ROC curve of (y_true, y_score) on the device: the value the consumer gets
+        from ``thresh[argmax(tpr - fpr)]`` over ``sklearn.metrics.roc_curve`` (``threshold.py:145-155,
+        417-426``).  Arrays or tensors; labels must be 0/1 (or bool).  Raises ``ValueError`` when only one
+        class is present, like the reference's ``max()`` over NaN rates.  Returns ``(threshold, info)``."""
+        if torch.is_tensor(y_score):
+            score = y_score.to(device=self.device, dtype=torch.float64).contiguous()
+        else:
+            score = torch.from_numpy(np.ascontiguousarray(y_score, dtype=np.float64)).to(self.device)
+        if torch.is_tensor(y_true):
+            label = (y_true != 0).to(device=self.device, dtype=torch.uint8).contiguous()
+        else:
+            yt = np.asarray(y_true)
+            if yt.dtype != bool and not np.isin(yt, (0, 1)).all():
+                raise ValueError('youden: labels must be 0/1')
+            label = torch.from_numpy(np.ascontiguousarray(yt != 0).view(np.uint8)).to(self.device)
+        n = int(score.numel())
+        if n == 0 or label.numel() != n:
+            raise ValueError('youden: empty input or length mismatch')
+        ws = torch.empty(int(self._lib.bq_roc_workspace_bytes(n)), dtype=torch.uint8, device=self.device)
+        out = torch.empty(6, dtype=torch.float64, device=self.device)
+        self._check(self._lib.bq_roc_youden(self._ctx, _ptr(score), _ptr(label), n, _ptr(ws), ws.numel(), _ptr(out),
+                                            self._stream()))
+        o = out.cpu().numpy()
+        if o[4] == 0 or o[5] == 0:
+            raise ValueError('ROC undefined: only one class present')
+        return float(o[0]), {'j': float(o[1]), 'tpr': float(o[2]), 'fpr': float(o[3]), 'n_pos': int(o[4]), 'n_neg': int(o[5])}
+
     def debug_activation(self, name, staged, shape_hwc):
         n = staged.shape[0]
         ws = self._ws_for(n, 1)

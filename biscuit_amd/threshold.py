@@ -36,13 +36,43 @@ def _roc(y_true, y_score):
         return metrics.roc_curve(y_true, y_score)
 
 
+class _RocUndefined(ValueError):
+    """Only one class present: the rates are NaN (the reference's list.index() then raises ValueError)."""
+
+
+_DEVICE = {'engine': None, 'min_rows': 0}
+
+
+def use_device(engine, min_rows=100_000):
+    """Route the Youden threshold searches of tables with at least ``min_rows`` rows to
+    ``engine.youden`` (``bq_roc_youden``: sort + scan + first-maximum reduce on the GPU, the same threshold
+    value; ``tests/test_gpu_parity.py`` checks it against this module's scikit-learn path).  ``None``
+    switches back to the host.  The cohort-wide tile table is 1.6 M rows at BASELINE config 3."""
+    _DEVICE['engine'] = engine
+    _DEVICE['min_rows'] = int(min_rows)
+
+
+def _youden_threshold(y_true, y_score):
+    """``thresh[argmax(tpr - fpr)]`` of the ROC curve; ValueError when it is undefined."""
+    eng = _DEVICE['engine']
+    if eng is not None and len(y_score) >= _DEVICE['min_rows']:
+        yt = np.asarray(y_true)
+        if yt.dtype == bool or np.isin(yt, (0, 1)).all():
+            try:
+                return eng.youden(yt, np.asarray(y_score))[0]
+            except ValueError as e:
+                raise _RocUndefined(str(e)) from None
+    fpr, tpr, thresh = _roc(y_true, y_score)          # invalid labels raise here, as in the reference
+    return _youden(fpr, tpr, thresh)
+
+
 def _youden(fpr, tpr, thresh):
     """Threshold at the first maximum of tpr - fpr."""
     j = np.asarray(tpr) - np.asarray(fpr)
     if len(thresh) == 0 or np.isnan(j).any():
         # one class only: the reference's max()/list.index() pair fails on the NaN rates
         # with ValueError (threshold.py:151-152,423-424); callers rely on that.
-        raise ValueError('ROC undefined: only one class present')
+        raise _RocUndefined('ROC undefined: only one class present')
     return thresh[int(np.argmax(j))]
 
 
@@ -65,10 +95,9 @@ def process_tile_predictions(df, pred_thresh=0.5, patients=None):
     yp = df['y_pred'].to_numpy()
     if np.isnan(yp).sum():
         raise errors.PredsContainNaNError
-    fpr, tpr, thresh = _roc(df['y_true'].to_numpy(), yp)
     try:
-        opt_pred = _youden(fpr, tpr, thresh)
-    except ValueError:
+        opt_pred = _youden_threshold(df['y_true'].to_numpy(), yp)
+    except _RocUndefined:
         opt_pred = 0.5
     if isinstance(pred_thresh, str) and pred_thresh == 'detect':
         pred_thresh = opt_pred
@@ -103,11 +132,12 @@ def group_frame(levels, yp, yt, un, pred_thresh, level):
     were reduced on the GPU (``bq_slide_reduce``)."""
     if not len(yt):
         raise errors.ROCFailedError('Unable to generate ROC; preds are empty.')
-    fpr, tpr, thresh = _roc(yt, yp)
-    if isinstance(pred_thresh, str) and pred_thresh == 'detect':
+    if not (isinstance(pred_thresh, str) and pred_thresh == 'detect'):
+        _roc(yt, yp)                                   # the reference always builds the curve (threshold.py:212)
+    else:
         try:
-            pred_thresh = _youden(fpr, tpr, thresh)
-        except ValueError:
+            pred_thresh = _youden_threshold(yt, yp)
+        except _RocUndefined:
             raise errors.ROCFailedError(f'Unable to generate {level}-level ROC')
     correct = ((yp < pred_thresh) & (yt == 0)) | ((yp >= pred_thresh) & (yt == 1))
     incorrect = (((yp < pred_thresh) & (yt == 1)) | ((yp >= pred_thresh) & (yt == 0))).astype(int)
@@ -198,8 +228,7 @@ def detect(df, tile_uq='detect', slide_uq='detect', tile_pred='detect', slide_pr
     elif not (isinstance(tile_uq, str) and tile_uq == 'detect'):
         tile_uq = None
     else:
-        fpr, tpr, thresh = _roc(df['incorrect'].to_numpy(), df['uncertainty'].to_numpy())
-        tile_uq = _youden(fpr, tpr, thresh)
+        tile_uq = _youden_threshold(df['incorrect'].to_numpy(), df['uncertainty'].to_numpy())
         df = df[df['uncertainty'] < tile_uq]
 
     try:
@@ -212,8 +241,7 @@ def detect(df, tile_uq='detect', slide_uq='detect', tile_pred='detect', slide_pr
         if not s_df['incorrect'].to_numpy().sum():
             slide_uq = None
         else:
-            fpr, tpr, thresh = _roc(s_df['incorrect'], s_df['uncertainty'].to_numpy())
-            slide_uq = _youden(fpr, tpr, thresh)
+            slide_uq = _youden_threshold(s_df['incorrect'].to_numpy(), s_df['uncertainty'].to_numpy())
             s_df = s_df[s_df['uncertainty'] < slide_uq]
     else:
         slide_uq = 0.5

@@ -135,6 +135,18 @@ int bq_slide_finish(bq_ctx* ctx, const int64_t* d_acc_pred, const int64_t* d_acc
                     const int32_t* d_count, int n_slides, double* d_mean_pred,
                     double* d_mean_unc, bq_stream_t stream);
 
+/* Threshold search of the consumer on the device: Youden's J over the ROC curve of (label, score), i.e.
+ * `thresh[argmax(tpr - fpr)]` of sklearn.metrics.roc_curve as the reference uses it for the tile-level
+ * prediction threshold (threshold.py:145-155), the tile-level uncertainty threshold over every tile of the
+ * cohort (threshold.py:417-426) and the slide-level ones (threshold.py:212-218, 449-455): first maximum, curve
+ * starting at (0, 0) with threshold +inf, one point per distinct score, rates in float64 from exact counts.
+ * d_score [n] float64, d_label [n] uint8 (non-zero = positive); d_out6 = [threshold, J, tpr, fpr, n_pos,
+ * n_neg] (float64, device).  With only one class present the rates are undefined (the reference raises):
+ * callers check n_pos / n_neg.  Workspace: bq_roc_workspace_bytes(n). */
+size_t bq_roc_workspace_bytes(int64_t n);
+int bq_roc_youden(bq_ctx* ctx, const double* d_score, const uint8_t* d_label, int64_t n,
+                  void* d_ws, size_t ws_bytes, double* d_out6, bq_stream_t stream);
+
 /* Per-kernel timing with HIP events on the launch stream (bench.py roofline leg).
  * bq_profile_enable(1) brackets every subsequent launch with events;
  * bq_profile_read synchronises and returns, per kernel class, the number of launches,

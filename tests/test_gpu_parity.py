@@ -339,3 +339,71 @@ def test_heatmap_front_end(engines, oracles, tiles):
     assert mask.sum() == len(excl) and (hm.logits[mask] == -1).all()
     with pytest.raises(ValueError):
         Heatmap(engines['f32'], tiles[:2], [[0, 0]], mc_n=2)
+
+
+# ---------------------------------------------------------------- device-side ROC / Youden
+def _host_youden(y_true, y_score):
+    from biscuit_amd import threshold as T
+    fpr, tpr, thresh = T._roc(y_true, y_score)
+    return T._youden(fpr, tpr, thresh)
+
+
+@pytest.mark.gpu
+def test_device_youden_matches_sklearn_path(engines):
+    eng = engines['f32']
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (2, 3, 17, 1000, 65_537):
+        yt = rng.integers(0, 2, n)
+        yt[:2] = (0, 1)
+        cases.append((yt, rng.random(n)))                                     # distinct scores
+        cases.append((yt, np.round(rng.random(n), 1)))                        # heavy ties (11 distinct values)
+        cases.append((yt, rng.random(n).astype(np.float32).astype(np.float64)))   # fp32 values, as device outputs are
+        cases.append((yt, np.where(yt == 1, 0.2, 0.8) + 0.01 * rng.random(n)))   # anti-correlated: J <= 0 -> +inf
+        cases.append((yt, yt * 1.0))                                          # perfect separation
+        cases.append((yt, np.zeros(n)))                                       # one distinct value
+    cases.append((np.array([0, 1, 1, 0]), np.array([-0.0, 0.0, 1.0, -1.0])))  # signed zeros tie
+    cases.append((np.array([True, False, True]), np.array([0.3, 0.3, 0.9])))  # bool labels
+    for yt, ys in cases:
+        want = _host_youden(yt, ys)
+        got, info = eng.youden(yt, ys)
+        assert (got == want) or (np.isinf(got) and np.isinf(want)), (len(yt), got, want, info)
+    # one class only: the reference's max()/index() raises ValueError; so do both paths here
+    for yt in (np.zeros(50, int), np.ones(50, int)):
+        with pytest.raises(ValueError):
+            eng.youden(yt, rng.random(50))
+        with pytest.raises(ValueError):
+            _host_youden(yt, rng.random(50))
+
+
+@pytest.mark.gpu
+def test_device_youden_full_size_and_consumer_switch(engines):
+    """BASELINE config 3's cohort table: 1.6 M tile rows.  Same threshold as the scikit-learn path, and the
+    consumer gives identical results with the device search switched on."""
+    import time
+    import pandas as pd
+    from biscuit_amd import threshold as T
+    eng = engines['f32']
+    rng = np.random.default_rng(5)
+    n = 1_600_000
+    incorrect = (rng.random(n) < 0.3).astype(int)
+    unc = (rng.gamma(2.0, 0.02, n) + 0.03 * incorrect).astype(np.float32).astype(np.float64)
+    t0 = time.perf_counter()
+    want = _host_youden(incorrect, unc)
+    t1 = time.perf_counter()
+    got, info = eng.youden(incorrect, unc)
+    t2 = time.perf_counter()
+    assert got == want
+    print(f'youden over {n} rows: scikit-learn {t1 - t0:.2f} s, device {t2 - t1:.3f} s (incl. H2D), J={info["j"]:.4f}')
+    # consumer round trip on a smaller table
+    m = 40_000
+    df = pd.DataFrame({'slide': [f's{i // 400}' for i in range(m)], 'y_true': np.repeat(rng.integers(0, 2, m // 400), 400),
+                       'y_pred': rng.random(m).astype(np.float32).astype(np.float64),
+                       'uncertainty': rng.random(m).astype(np.float32).astype(np.float64) * 0.2})
+    host = T.detect(df.copy())
+    T.use_device(eng, min_rows=1000)
+    try:
+        dev = T.detect(df.copy())
+    finally:
+        T.use_device(None)
+    assert host[0] == dev[0] and (host[1] == dev[1] or (np.isnan(host[1]) and np.isnan(dev[1])))
