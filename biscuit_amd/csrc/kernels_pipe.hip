@@ -551,7 +551,10 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         }
         PSTAMP(7 + 4 * c);
         if constexpr (HDMA) {
-            // the halo DMA is older than the PF*RN ring loads this wave's G stage left in flight
+            // the halo DMA is older than the PF*RN ring loads this wave's G stage left in flight.  (A register
+            // spill reload inside that stage would be one more younger vector-memory operation and make this count
+            // wrong: `make` fails if an instance with the DMA path spills -- csrc/check_spills.sh.  vmcnt(0) here
+            // measured 3-4 % slower on the 728-wide layers.)
             if (first_half) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PF * RN) : "memory");
         }
         __syncthreads();
