@@ -6,7 +6,7 @@ for rep in 1 2 3; do
   for v in A B; do
     cp biscuit_amd/lib$v.so biscuit_amd/libbiscuit_hip.so
     echo "=== $v rep $rep" >> $L
-    timeout 100 python tools/gpu_probe.py time --dtype bf16 --n 256 2>&1 | grep -E "time dtype|sepconv_k728_n728|sepconv_k256_n256|sepconv_k128_n256|sepconv_k256_n728" >> $L
+    timeout 100 python tools/gpu_probe.py time --dtype bf16 --n 256 2>&1 | grep -E "time dtype|147x147" >> $L
   done
 done
 cat $L
