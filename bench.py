@@ -1,47 +1,98 @@
 """bench.py -- tiles/sec of the MC-dropout tile-inference hot path on MI355X.
 
-Workload (BASELINE.json config 2): synthetic slides of 1000 tiles (299x299x3 uint8,
+Default workload (BASELINE.json config 2): synthetic slides of 1000 tiles (299x299x3 uint8,
 resident in HBM before the timed region), Xception bf16 backbone + fp32 MC head, MC = 30,
 batch = 256.  A "step" is one batch of 256 tiles through
     stage (K0) -> backbone (K1-K5) -> 30 Philox-dropout head passes + Welford (K6)
     -> slide-level segmented reduce (K7).
 ``value`` = tiles processed by all ranks / max-over-ranks wall time of exactly K steps
 (barrier + synchronize on both sides; at N>1 the timed region ends with the single
-all-gather of the per-slide results).
+all-gather of the per-slide results).  Weak scaling: K x 256 tiles per GPU.
+
+``--workload cfg3`` (BASELINE.json config 3, strong scaling): S = 1600 synthetic slides x T = 1000
+tiles, longest-processing-time sharded over the ranks, streamed through the product's own
+``biscuit_amd.inference.evaluate`` (batches of 256 that span slides, global Philox tile indices), one
+all-gather of the slide (pred, sigma, n) table; ``value`` = S x T / max-over-ranks wall time.
 
 mc_mode 'head' (default, reported as ``value``): backbone once per tile, the 30 stochastic
 passes run in the head -- bit-identical to 30 full passes because every dropout layer sits
-behind the global pool and BN is in inference mode.  ``full_mode_value`` times the
-reference's loop structure (30 complete forward passes) on the same kernels, and
-``cpu_baseline`` times the fp32 CPU oracle in that same full structure on the host cores.
+behind the global pool and BN is in inference mode.  Extra keys (N = 1 only, never the headline):
+``full_mode_value`` (the reference's loop structure, 30 complete forward passes, same kernels),
+``with_reinhard_value`` (hp.py:19's stain normaliser in the timed region), ``f32_value`` (exact fp32
+kernels), ``b1_latency`` (``UncertaintyInterface`` on one tile, results.py:257), ``tfrecords``
+(``evaluate`` from self-written PNG TFRecords: decode on the host cores) and ``cpu_baseline`` (the fp32
+CPU oracle in the reference's loop structure on the host cores).
 
-usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--mc 30] [--batch 256]
+``--gpus N`` without torchrun's environment starts the N ranks itself (one child process per GPU,
+before this process has touched the GPU); under ``python -m torch.distributed.run`` it is one of them.
+
+usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--mc 30] [--batch 256] [--workload cfg2|cfg3]
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-
-from biscuit_amd import distributed as D      # noqa: E402
-from biscuit_amd.engine import EnginePool     # noqa: E402
-from biscuit_amd.weights import synthetic_weights  # noqa: E402
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 # Algorithmic work per tile (derivation SURVEY.md section 8d)
-FLOP_PER_TILE_HEAD = 16.711e9 + 30 * 6.296e6      # backbone once + 30 head passes
-FLOP_PER_TILE_FULL = 30 * (16.711e9 + 6.296e6)
+FLOP_BACKBONE = 16.711e9
+FLOP_HEAD_PASS = 6.296e6
 BYTES_PER_TILE_BF16 = 90.2e6                      # layer-boundary bf16 bytes, fused dw+pw/BN/ReLU/pool+add
 PEAK_HBM = 8.0e12                                 # B/s   (MI355X_MICROARCH.md: 8 TB/s spec)
 PEAK_BF16 = 2.5e15                                # FLOP/s dense bf16 MFMA
 PEAK_F32 = 157.3e12
 TILES_PER_SLIDE = 1000
+NORM_FIT = {'target_means': [65.0, 12.0, -8.0], 'target_stds': [14.0, 7.0, 6.0]}   # a plausible H&E fit (synthetic)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--mc', type=int, default=30)
+    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--mode', default='head', choices=['head', 'full'])
+    ap.add_argument('--workload', default='cfg2', choices=['cfg2', 'cfg3'])
+    ap.add_argument('--slides', type=int, default=1600, help='cfg3: number of synthetic slides')
+    ap.add_argument('--tiles-per-slide', type=int, default=TILES_PER_SLIDE, help='cfg3: tiles per slide')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the reinhard / f32 / B=1 / TFRecord legs')
+    ap.add_argument('--cpu-tiles', type=int, default=128, help='batch of the CPU baseline (hp.py:7: 128)')
+    ap.add_argument('--cpu-budget', type=float, default=25.0, help='seconds of CPU work in the baseline sample')
+    ap.add_argument('--streams', type=int, default=4,
+                    help='batches in flight: independent contexts on HIP streams that own disjoint groups of XCDs (2 or 4)')
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------- rank launcher
+def spawn_ranks(args):
+    """Start one child process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in its environment), relay rank 0's
+    JSON line, return the worst exit code.  The parent never touches the GPU: nothing that has initialised HIP
+    is ever exec'd or forked."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
 
 
 def usable_cores():
@@ -62,39 +113,6 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(weights, mc_n, seed, batch=8, budget_s=20.0):
-    """The CPU oracle in the reference's loop structure -- N complete forward passes per
-    batch, then mean / population std -- on this host's cores.  Bounded sample: whole
-    forward passes over one batch are timed until the budget is spent; tiles/s at MC=N is
-    batch * passes / (N * seconds)."""
-    from biscuit_amd.synthetic import make_tiles
-    from oracle.xception_ref import XceptionOracle, standardize
-    threads = usable_cores()
-    torch.set_num_threads(threads)
-    orc = XceptionOracle(weights)
-    tiles = make_tiles(batch, seed=11)
-    idx = np.arange(batch)
-    x = standardize(tiles)
-    orc.head_pass(orc.backbone(x), idx, 0, seed)              # warm-up (oneDNN primitive cache)
-    passes, t0 = 0, time.time()
-    while True:
-        orc.head_pass(orc.backbone(x), idx, passes, seed)     # one full stochastic forward pass
-        passes += 1
-        dt_full = time.time() - t0
-        if dt_full >= budget_s or passes >= mc_n:
-            break
-    full = batch * passes / (mc_n * dt_full)
-    t0 = time.time()
-    feat = orc.backbone(x)
-    for p in range(mc_n):
-        orc.head_pass(feat, idx, p, seed)
-    dt_head = time.time() - t0
-    return {'value': full, 'unit': 'tiles/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{passes} complete fp32 forward passes (PyTorch-CPU oracle, dropout on) over a batch of '
-                      f'{batch} synthetic 299x299x3 tiles in {dt_full:.1f} s, scaled to MC={mc_n} passes per tile',
-            'head_mode_value': batch / dt_head, 'cpu': _cpu_name(), 'os_cpu_count': os.cpu_count()}
-
-
 def _cpu_name():
     try:
         for line in open('/proc/cpuinfo'):
@@ -105,25 +123,55 @@ def _cpu_name():
     return 'unknown'
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mc', type=int, default=30)
-    ap.add_argument('--batch', type=int, default=256)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--mode', default='head', choices=['head', 'full'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--cpu-tiles', type=int, default=8)
-    ap.add_argument('--streams', type=int, default=4,
-                    help='batches in flight: independent contexts on HIP streams that own disjoint groups of XCDs (2 or 4)')
-    args = ap.parse_args()
+def cpu_baseline(weights, mc_n, seed, batch=128, budget_s=25.0):
+    """The CPU oracle in the reference's loop structure -- N complete forward passes per
+    batch, then mean / population std -- on this host's cores, batch 128 (hp.py:7).  Bounded sample:
+    whole forward passes over one batch are timed until the budget is spent (at least one, after a
+    warm-up pass); tiles/s at MC=N is batch * passes / (N * seconds)."""
+    import numpy as np
+    import torch
+    from biscuit_amd.synthetic import make_tiles
+    from oracle.xception_ref import XceptionOracle, standardize
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    orc = XceptionOracle(weights)
+    tiles = np.concatenate([make_tiles(min(batch, 16), seed=11)] * ((batch + 15) // 16))[:batch]
+    idx = np.arange(batch)
+    x = standardize(tiles)
+    orc.head_pass(orc.backbone(x[:min(batch, 16)]), idx[:min(batch, 16)], 0, seed)   # warm-up (oneDNN primitive cache)
+    passes, t0 = 0, time.time()
+    while True:
+        orc.head_pass(orc.backbone(x), idx, passes, seed)     # one full stochastic forward pass
+        passes += 1
+        dt_full = time.time() - t0
+        if dt_full >= budget_s or passes >= mc_n:
+            break
+    full = batch * passes / (mc_n * dt_full)
+    t0 = time.time()
+    feat = orc.backbone(x[:min(batch, 32)])
+    for p in range(mc_n):
+        orc.head_pass(feat, idx[:feat.shape[0]], p, seed)
+    dt_head = time.time() - t0
+    return {'value': full, 'unit': 'tiles/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{passes} complete fp32 forward passes (PyTorch-CPU oracle, dropout on) over a batch of '
+                      f'{batch} synthetic 299x299x3 tiles ({passes * batch} tile-passes) in {dt_full:.1f} s, scaled to '
+                      f'MC={mc_n} passes per tile',
+            'head_mode_value': feat.shape[0] / dt_head, 'cpu': _cpu_name(), 'os_cpu_count': os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------- the benchmark proper
+def run(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from biscuit_amd import distributed as D
+    from biscuit_amd.engine import EnginePool
+    from biscuit_amd.weights import synthetic_weights
 
     rank, world, local = D.init_from_env('cuda')
-    if world != args.gpus and rank == 0:
-        print(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using {world}', file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f'[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus} '
+                         f'(or without torchrun: bench.py starts its own ranks)')
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     # collectives run on the GPU (RCCL) unless a CPU backend was forced for single-GPU testing
@@ -141,6 +189,29 @@ def main():
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     pool = [torch.randint(0, 256, (B, 299, 299, 3), dtype=torch.uint8, device=dev, generator=g)
             for _ in range(4)]
+    scratch = [torch.empty_like(pool[0]) for _ in range(NS)]      # stain-normalised copy, one per stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.workload == 'cfg3':
+        out = run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     NSTEP = max(K, Wm, 8)                         # the per-kernel pass and the full-mode leg run up to 8 steps
     n_slides_local = (NSTEP * B + TILES_PER_SLIDE - 1) // TILES_PER_SLIDE + 1
     slide_of = [torch.div(torch.arange(s * B, (s + 1) * B, device=dev), TILES_PER_SLIDE,
@@ -149,59 +220,53 @@ def main():
     std = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NS)]
     tile_base = rank * K * B                      # global tile index of this rank's shard
 
-    def zero_acc():
+    def zero_acc(n=NS):
         # one fixed-point accumulator triple per stream; integer sums add exactly at the end
         return [(torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
                  torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
-                 torch.zeros(n_slides_local, dtype=torch.int32, device=dev)) for _ in range(NS)]
+                 torch.zeros(n_slides_local, dtype=torch.int32, device=dev)) for _ in range(n)]
 
-    def step(i, acc, mode):
-        k = i % len(pool_e)           # batches in flight (set by the calibration below)
+    def step(pe, i, acc, mode, stain=False):
+        k = i % len(pe)               # batches in flight (set by the calibration below)
 
         def work(e):
-            e.mc_infer(pool[i % 4], args.mc, seed, tile_idx0=tile_base + i * B, mc_mode=mode, out=(mean[k], std[k]))
+            src = pool[i % 4]
+            if stain:
+                src = e.reinhard_fast(src, NORM_FIT['target_means'], NORM_FIT['target_stds'], out=scratch[k])
+            e.mc_infer(src, args.mc, seed, tile_idx0=tile_base + i * B, mc_mode=mode, out=(mean[k], std[k]))
             e.slide_reduce(mean[k], std[k], slide_of[i], n_slides_local, acc=acc[k])
-        pool_e.run(k, work)
+        pe.run(k, work)
 
-    def finish(acc):
+    def finish(pe, acc):
         torch.cuda.synchronize()
-        tot = tuple(sum(a[j] for a in acc[1:]) + acc[0][j] if NS > 1 else acc[0][j] for j in range(3))
-        return eng.slide_finish(tot)
+        tot = tuple(sum(a[j] for a in acc[1:]) + acc[0][j] if len(acc) > 1 else acc[0][j] for j in range(3))
+        return pe.engines[0].slide_finish(tot)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(mode, steps):
+    def timed(mode, steps, pe=None, stain=False):
+        pe = pe or pool_e
         acc = zero_acc()
         for i in range(Wm):
-            step(i, acc, mode)
+            step(pe, i, acc, mode, stain)
         acc = zero_acc()
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i, acc, mode)
-        mp, mu, cnt = finish(acc)
+            step(pe, i, acc, mode, stain)
+        mp, mu, cnt = finish(pe, acc)
         if world > 1:                              # the path's one collective (RCCL over xGMI)
             ids = np.arange(rank * n_slides_local, (rank + 1) * n_slides_local)
             D.gather_slide_results(ids, mp.cpu().numpy(), mu.cpu().numpy(), cnt.cpu().numpy(),
                                    world * n_slides_local, n_slides_local, device=coll_dev)
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = max_over_ranks(time.perf_counter() - t0)
         assert int(cnt.sum()) == steps * B and bool(torch.isfinite(mp[cnt > 0]).all())
         return dt
 
     # Untimed calibration of the number of batches in flight.  Each batch in flight owns 1/n of the chip's
     # XCDs (CU-masked streams), which lets batches run out of phase (one's HBM-bound prologues and store
-    # drains under another's compute): 4 in flight measured 12.3 ms per batch, 2 12.5, one whole-chip stream
-    # 13.0.  But n in flight only pays when the K timed steps fill whole rounds of n (10 steps on 4
-    # quarter-chips are 3 rounds), and plain streams (if CU masks are unavailable) are bimodal.  So time
-    # min(K, 32) steps each way and keep the fastest; every rank adopts the same choice.
+    # drains under another's compute).  But n in flight only pays when the K timed steps fill whole rounds of n
+    # (10 steps on 4 quarter-chips are 3 rounds), and plain streams (if CU masks are unavailable) are bimodal.
+    # So time min(K, 32) steps each way and keep the fastest; every rank adopts the same choice.
     cands = sorted({n for n in (NS, NS // 2, 1) if n >= 1}, reverse=True)
     if len(cands) > 1:
         cal = min(K, 32)
@@ -229,20 +294,28 @@ def main():
                    'parallelism': f'slide-sharded dp{world}, one all-gather of slide (pred, sigma, n)'},
     }
 
+    flop_head = FLOP_BACKBONE + args.mc * FLOP_HEAD_PASS
+    flop_full = args.mc * (FLOP_BACKBONE + FLOP_HEAD_PASS)
     if rank == 0:
-        flop_tile = FLOP_PER_TILE_HEAD if args.mode == 'head' else FLOP_PER_TILE_FULL
+        flop_tile = flop_head if args.mode == 'head' else flop_full
         per_gpu = value / world
         out['path_roofline'] = {
             'hbm_frac': per_gpu * BYTES_PER_TILE_BF16 / PEAK_HBM if args.dtype == 'bf16' else None,
             'mfma_frac': per_gpu * flop_tile / (PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32),
             'bytes_per_tile': BYTES_PER_TILE_BF16, 'flop_per_tile': flop_tile}
 
+    solo = world == 1 and rank == 0
     # the other MC structure on the same kernels (N=1 only; a few steps)
-    if world == 1 and rank == 0:
+    if solo:
         other = 'full' if args.mode == 'head' else 'head'
         k2 = max(2, len(pool_e)) if other == 'full' else K     # a batch per stream keeps every XCD group busy
         dt2 = timed(other, k2)
         out[f'{other}_mode_value'] = k2 * B / dt2
+    # hp.py:19's stain normaliser inside the timed region (results.py:251-252 applies it per tile)
+    if solo and not args.no_extras:
+        dt3 = timed(args.mode, K, stain=True)
+        out['with_reinhard_value'] = K * B / dt3
+        out['with_reinhard_ms_per_step'] = dt3 / K * 1e3
 
     # per-kernel roofline: HIP events on the launch stream around every launch
     if not args.no_profile and rank == 0:
@@ -253,14 +326,14 @@ def main():
         # Engine 0 on a plain (whole-chip) stream of its own, nothing else in flight: the events bracket
         # each launch on the stream it runs on and give the kernel's own duration, the figure the
         # single-stream rocprofv3 trace under profiles/ is comparable with.  (In the timed region each
-        # batch owns a quarter of the chip and four run side by side; see `in_situ` below.)
-        solo = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(solo):
+        # batch owns a share of the chip and several run side by side; see `in_situ` below.)
+        solo_s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(solo_s):
             for i in range(psteps):
                 eng.mc_infer(pool[i % 4], args.mc, seed, tile_idx0=tile_base + i * B, mc_mode=args.mode,
                              out=(mean[0], std[0]))
                 eng.slide_reduce(mean[0], std[0], slide_of[i], n_slides_local, acc=acc[0])
-        solo.synchronize()
+        solo_s.synchronize()
         ents = eng.profile_read()
         eng.profile_enable(False)
         tot = sum(e.ms for e in ents)
@@ -299,10 +372,26 @@ def main():
         out['kernels'] = [{'name': e.name, 'launches_per_step': e.launches / psteps,
                            'ms_per_launch': e.ms / e.launches, 'share': e.ms / tot,
                            'tflops': e.flops / (e.ms / e.launches * 1e-3) / 1e12,
-                           'gbps': e.bytes / (e.ms / e.launches * 1e-3) / 1e9} for e in ents[:12]]
+                           'gbps': e.bytes / (e.ms / e.launches * 1e-3) / 1e9} for e in ents[:14]]
 
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(weights, args.mc, seed, args.cpu_tiles)
+    if solo and not args.no_extras:
+        out['b1_latency'] = b1_latency(eng, args.mc)
+        other_dt = 'f32' if args.dtype == 'bf16' else 'bf16'
+        pool_e.synchronize()
+        pe2 = EnginePool(weights, n_streams=1, dtype=other_dt, max_batch=B, max_mc=args.mc, device=local)
+        k4 = 4 if other_dt == 'f32' else K
+        dt4 = timed(args.mode, k4, pe=pe2)
+        out[f'{other_dt}_value'] = k4 * B / dt4
+        out[f'{other_dt}_mfma_frac'] = out[f'{other_dt}_value'] * flop_head / (PEAK_F32 if other_dt == 'f32' else PEAK_BF16)
+        pe2.close()
+        del pe2
+        try:
+            out['tfrecords'] = tfrecord_leg(pool_e, args)
+        except Exception as e:                                  # an extra leg never takes the headline down
+            out['tfrecords'] = {'error': f'{type(e).__name__}: {e}'}
+
+    if solo and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(weights, args.mc, seed, args.cpu_tiles, args.cpu_budget)
         out['speedup_vs_cpu_full'] = (out.get('full_mode_value') or value) / out['cpu_baseline']['value']
         out['speedup_headline_vs_cpu_full'] = value / out['cpu_baseline']['value']
 
@@ -311,6 +400,136 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks):
+    """BASELINE.json config 3: S slides x T tiles, LPT-sharded, through ``inference.evaluate``; strong scaling."""
+    import numpy as np
+    import torch
+    from biscuit_amd import distributed as D
+    from biscuit_amd.inference import Slide, evaluate
+    S, T, B = args.slides, args.tiles_per_slide, args.batch
+    allt = torch.cat(pool)                                       # the resident synthetic tiles, cycled
+    npool = allt.shape[0]
+
+    def tiles_of(i):
+        def load():
+            idx = (torch.arange(T, device=dev) + i * T) % npool
+            return allt.index_select(0, idx)
+        return load
+    slides = [Slide(f's{i:05d}', tiles_of(i), T, y_true=i % 2) for i in range(S)]
+    warm = [Slide(f'w{i}', tiles_of(i), min(T, 2 * B), y_true=0) for i in range(world * max(1, args.warmup))]
+    pool_e.set_in_flight(min(2, len(pool_e.engines)))
+    evaluate(pool_e, warm, mc_n=args.mc, seed=1234, batch=B, mc_mode=args.mode, keep_tiles=False, rank=rank, world=world)
+    barrier()
+    t0 = time.perf_counter()
+    res = evaluate(pool_e, slides, mc_n=args.mc, seed=1234, batch=B, mc_mode=args.mode, keep_tiles=False,
+                   rank=rank, world=world)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    assert int(res.slide_count.sum()) == S * T and np.isfinite(res.slide_pred).all()
+    parts = D.partition_slides([T] * S, world)
+    steps = max(-(-len(p) * T // B) for p in parts)
+    return {'metric': 'tiles/sec at MC-dropout=30, 299x299x3 (Xception, slide-level pred/sigma reduce)',
+            'value': S * T / dt, 'unit': 'tiles/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup,
+            'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic', 'seconds': dt,
+            'config': {'workload': f'BASELINE.json config 3: {S} synthetic slides x {T} tiles (299x299x3), LPT-sharded over '
+                                   f'{world} GPU(s), Xception {args.dtype} + fp32 MC head, MC={args.mc}, batch={B}, through '
+                                   f'biscuit_amd.inference.evaluate', 'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B,
+                       'slides_per_rank': [len(p) for p in parts], 'hip_streams': len(pool_e),
+                       'parallelism': f'slide-sharded dp{world}, one all-gather of slide (pred, sigma, n)'},
+            'path_roofline': {'hbm_frac': S * T / dt / world * BYTES_PER_TILE_BF16 / PEAK_HBM if args.dtype == 'bf16' else None,
+                              'mfma_frac': S * T / dt / world * (FLOP_BACKBONE + args.mc * FLOP_HEAD_PASS) /
+                              (PEAK_BF16 if args.dtype == 'bf16' else PEAK_F32)}}
+
+
+def b1_latency(eng, mc_n, calls=50):
+    """results.py:250-258 as the heatmap loop runs it: one standardised 299x299x3 float tile per call,
+    ``UncertaintyInterface(batch) -> (mean, std)`` with MC passes folded in the head; host wall time per
+    call (H2D of the tile, ~60 launches, D2H of 4 floats) and the device time between HIP events."""
+    import numpy as np
+    import torch
+    from biscuit_amd.engine import UncertaintyInterface
+    itf = UncertaintyInterface(eng, uq_n=mc_n, seed=5)
+    x = np.random.default_rng(0).normal(0, 1, (1, 299, 299, 3)).astype(np.float32)
+    for _ in range(5):
+        itf(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        itf(x)
+    wall = (time.perf_counter() - t0) / calls
+    xd = torch.from_numpy(x).to(eng.device)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(calls):
+        itf.device_call(xd)
+    b.record()
+    b.synchronize()
+    res = {'us_per_call_host_wall': wall * 1e6, 'us_per_call_device': a.elapsed_time(b) / calls * 1e3, 'mc_n': mc_n,
+           'calls': calls, 'graph': False}
+    if hasattr(itf, 'enable_graph'):
+        try:
+            itf.enable_graph()
+            for _ in range(3):
+                itf.device_call(xd)
+            a.record()
+            for _ in range(calls):
+                itf.device_call(xd)
+            b.record()
+            b.synchronize()
+            res['us_per_call_device_graph'] = a.elapsed_time(b) / calls * 1e3
+            res['graph'] = True
+        except Exception as e:
+            res['graph_error'] = f'{type(e).__name__}: {e}'
+    return res
+
+
+def tfrecord_leg(pool_e, args, n_slides=4, tiles_per_slide=256):
+    """``evaluate`` fed from self-written PNG TFRecords (configure.py:118-124: PNG tiles, one file per slide):
+    host decode (libbiscuit_io.so on the box's cores) -> pinned buffer -> H2D -> the same kernels."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from biscuit_amd import tfrecord, tfrecord_native
+    from biscuit_amd.inference import evaluate, slides_from_tfrecords
+    from biscuit_amd.synthetic import make_tiles
+    d = tempfile.mkdtemp(prefix='bq_tfr_')
+    try:
+        base = make_tiles(32, seed=21)
+        paths = []
+        for s in range(n_slides):
+            t = base[(np.arange(tiles_per_slide) + s) % 32]
+            p = os.path.join(d, f's{s}.tfrecords')
+            tfrecord.write_slide(p, f's{s}', t, np.zeros((tiles_per_slide, 2), np.int64))
+            paths.append(p)
+        nbytes = sum(os.path.getsize(p) for p in paths)
+        tfrecord_native.load()
+        t0 = time.perf_counter()
+        for p in paths:
+            tfrecord.read_slide(p, 299)
+        dec = time.perf_counter() - t0
+        slides = slides_from_tfrecords(paths, {f's{s}': s % 2 for s in range(n_slides)})
+        evaluate(pool_e, slides[:1], mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False)     # warm-up
+        t0 = time.perf_counter()
+        res = evaluate(pool_e, slides, mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=True)
+        dt = time.perf_counter() - t0
+        n = n_slides * tiles_per_slide
+        assert int(res.slide_count.sum()) == n
+        return {'tiles': n, 'value': n / dt, 'unit': 'tiles/s', 'decode_only_tiles_per_s': n / dec,
+                'host_cores': usable_cores(), 'png_bytes_per_tile': nbytes / n,
+                'note': 'end to end from PNG TFRecords incl. host decode, H2D, kernels, tile table; bound by host decode '
+                        'when decode_only is below the resident-tiles value'}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run(args)
 
 
 if __name__ == '__main__':

@@ -17,6 +17,35 @@ import numpy as np
 import pandas as pd
 
 
+def model_hp(params):
+    """(ModelParams, norm_fit) from what ``keras_import.read_params`` found in a model's params.json: the dropout
+    rate (and ``uq_n`` when stored) drive the MC statistics, so they come from the model, never from the defaults;
+    a stain normaliser other than the one this path implements (`reinhard_fast`, hp.py:19) is an error, and its fit
+    is used only when that normaliser is the model's."""
+    from .hp import ModelParams
+    hp = ModelParams()
+    if not params:
+        return hp, None
+    raw = params.get('hp') or {}
+    if raw.get('dropout') is not None:
+        hp.dropout = float(raw['dropout'])
+    if raw.get('uq_n') is not None:
+        hp.uq_n = int(raw['uq_n'])
+    normalizer = params.get('normalizer')
+    if normalizer is None and params.get('norm_fit'):
+        raise SystemExit(f"{params.get('path', 'params.json')}: a norm_fit block but no hp.normalizer: cannot tell which stain "
+                         f"normaliser the model was trained with")
+    hp.normalizer = normalizer
+    hp.validate()
+    if normalizer not in (None, 'reinhard_fast'):
+        raise SystemExit(f"{params.get('path', 'params.json')}: the model was trained with normalizer={normalizer!r}; this "
+                         f"path implements 'reinhard_fast' (biscuit/hp.py:19) or none")
+    fit = params.get('norm_fit') if normalizer == 'reinhard_fast' else None
+    if normalizer == 'reinhard_fast' and not fit:
+        raise SystemExit(f"{params.get('path', 'params.json')}: normalizer='reinhard_fast' but no norm_fit block")
+    return hp, fit
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog='python -m biscuit_amd', description=__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -30,7 +59,7 @@ def main(argv=None):
                                     'plus params.json (norm_fit, outcome labels); replaces --weights and --params')
     ap.add_argument('--outcome', default='cohort')
     ap.add_argument('--out', required=True)
-    ap.add_argument('--mc', type=int, default=30)
+    ap.add_argument('--mc', type=int, default=None, help='MC-dropout passes (default: uq_n of the model, 30)')
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
@@ -67,13 +96,17 @@ def main(argv=None):
         s, t = (int(x) for x in args.synthetic.lower().split('x'))
         tiles, sidx, y = make_slides(s, t, seed=0)
         slides = [Slide(f'slide{i:03d}', tiles[sidx == i], t, y_true=int(y[i])) for i in range(s)]
-    norm_fit = model_params.get('norm_fit') if model_params else None
+    hp, norm_fit = model_hp(model_params)
     if args.params:
         with open(args.params) as f:
-            norm_fit = json.load(f).get('norm_fit')
+            raw = json.load(f)
+        hp, norm_fit = model_hp({'hp': raw.get('hp') or {}, 'normalizer': (raw.get('hp') or {}).get('normalizer', raw.get('normalizer', 'reinhard_fast')),
+                                 'norm_fit': raw.get('norm_fit'), 'path': args.params})
         if not norm_fit:
             raise SystemExit(f'{args.params}: no norm_fit block')
-    pool = EnginePool(w, n_streams=args.streams, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local)
+    if args.mc is None:
+        args.mc = hp.uq_n
+    pool = EnginePool(w, n_streams=args.streams, hp=hp, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local)
     res = evaluate(pool, slides, outcome=args.outcome, mc_n=args.mc, seed=args.seed, batch=args.batch,
                    save_dir=args.out, rank=rank, world=world, norm_fit=norm_fit)
     if rank == 0:

@@ -141,13 +141,19 @@ class Engine:
                                           self._stream()))
         return feat
 
-    def mc_head(self, feat, mc_n, seed, tile_idx0=0):
+    def mc_head(self, feat, mc_n, seed, tile_idx0=0, out=None):
+        """GAP features [n,2048] -> (mean[n,2], std[n,2]) over mc_n dropout passes; the Philox tile counter of row i
+        is tile_idx0 + i.  ``out``: (mean, std) to write into (contiguous [n,2] fp32 views are fine)."""
         assert feat.dtype == torch.float32 and feat.is_cuda and feat.is_contiguous()
         n = feat.shape[0]
         ws = self._ws_for(n, mc_n)
         state = torch.empty((n, 5), dtype=torch.float32, device=self.device)
-        mean = torch.empty((n, 2), dtype=torch.float32, device=self.device)
-        std = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        if out is None:
+            mean = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+            std = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        else:
+            mean, std = out
+            assert mean.is_contiguous() and std.is_contiguous() and mean.shape == (n, 2) and std.shape == (n, 2)
         self._check(self._lib.bq_mc_head(self._ctx, _ptr(feat), n, int(tile_idx0), int(mc_n), 0,
                                          int(seed), 1, 1, _ptr(state), _ptr(mean), _ptr(std), _ptr(ws),
                                          ws.numel(), self._stream()))
@@ -353,13 +359,20 @@ class UncertaintyInterface:
             from .stain import ReinhardFast
             self.wsi_normalizer = ReinhardFast(engine, norm_fit['target_means'], norm_fit['target_stds'])
 
-    def __call__(self, batch):
+    def device_call(self, x):
+        """The same call with everything left on the device: x float32 [B,299,299,3] on the engine's GPU ->
+        (mean, std) device tensors, nothing synchronises."""
         eng = self.engine
-        x = torch.as_tensor(np.asarray(batch) if not torch.is_tensor(batch) else batch)
-        x = x.to(device=eng.device, dtype=torch.float32).contiguous()
         if x.ndim != 4 or tuple(x.shape[1:]) != (TILE_PX, TILE_PX, 3):
             raise ValueError(f'expected [B,{TILE_PX},{TILE_PX},3] standardised tiles, got {tuple(x.shape)}')
         feat = eng.backbone(eng.stage_f32(x))
         mean, std = eng.mc_head(feat, self.uq_n, self.seed, tile_idx0=self._calls)
         self._calls += x.shape[0]
+        return mean, std
+
+    def __call__(self, batch):
+        eng = self.engine
+        x = torch.as_tensor(np.asarray(batch) if not torch.is_tensor(batch) else batch)
+        x = x.to(device=eng.device, dtype=torch.float32).contiguous()
+        mean, std = self.device_call(x)
         return mean.cpu().numpy(), std.cpu().numpy()

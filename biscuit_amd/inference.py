@@ -141,6 +141,12 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                     cur = eng.reinhard_fast(cur, norm_fit['target_means'], norm_fit['target_stds'])
                 if len(starts) == 1:
                     eng.mc_infer(cur, mc_n, seed, tile_idx0=int(cg[0]), mc_mode=mc_mode, out=(mean, std))
+                elif mc_mode == 'head':
+                    # a batch that spans slides: the backbone does not care (one launch sequence for the whole
+                    # batch), only the head's Philox counter does -- one head call per run of consecutive indices
+                    feat = eng.backbone(eng.stage(cur))
+                    for a, b in zip(starts, ends):
+                        eng.mc_head(feat[a:b], mc_n, seed, tile_idx0=int(cg[a]), out=(mean[a:b], std[a:b]))
                 else:
                     for a, b in zip(starts, ends):
                         eng.mc_infer(cur[a:b], mc_n, seed, tile_idx0=int(cg[a]), mc_mode=mc_mode,

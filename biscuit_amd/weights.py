@@ -62,8 +62,15 @@ def _bn(rng, w, name, c, gamma=1.0):
     w[name + '/moving_variance'] = rng.uniform(0.9, 1.1, c).astype(np.float32)
 
 
-def synthetic_weights(seed=1, n_classes=2, logit_gain=0.3):
+def synthetic_weights(seed=1, n_classes=2, logit_gain=0.3, hard=False):
     """Seeded random-init weights of the hp.nature2022 architecture.
+
+    ``hard=True`` is the parity stress set: BatchNorm moving variances log-uniform in [0.25, 4] with the
+    convolution in front scaled so that its output really has that variance (as a trained network's
+    statistics do), moving means and betas far from zero, gammas in [0.8, 1.25], and -- unless
+    ``logit_gain`` is given explicitly -- an output layer with O(1) logits (gain 1.0).  A folding mistake
+    (eps, sqrt, sign of the mean) or a lost bf16 bit moves these predictions visibly; the default set
+    (variances and gammas within 10 % of one, logits within +-0.6) would hide it.
 
     Variance-preserving init so activations stay O(1) through the 36 conv layers with
     BatchNorm in inference mode (moving statistics ~ identity): conv / pointwise
@@ -107,7 +114,29 @@ def synthetic_weights(seed=1, n_classes=2, logit_gain=0.3):
     k2 = rng.normal(0, np.sqrt(1.0 / 1024), (1024, n_classes)).astype(np.float32)
     w['logits/kernel'] = (k2 - k2.mean(axis=1, keepdims=True)) * np.float32(logit_gain)
     w['logits/bias'] = np.zeros(n_classes, np.float32)
+    if hard:
+        _harden(w, seed, n_classes, logit_gain)
     return w
+
+
+def _harden(w, seed, n_classes, logit_gain):
+    """In place: the ``hard=True`` statistics of ``synthetic_weights`` (own random stream, so the default
+    set stays bit-identical)."""
+    rng = np.random.default_rng([seed, 0x4841524])
+    for name in sorted(k[:-len('/gamma')] for k in w if k.endswith('/gamma')):
+        c = w[name + '/gamma'].size
+        var = np.exp(rng.uniform(np.log(0.25), np.log(4.0), c)).astype(np.float32)
+        sd = np.sqrt(var)
+        conv = name[:-len('_bn')] if not name.endswith('_res_bn') else name[:-len('_bn')] + '_conv'
+        key = conv + ('/pointwise_kernel' if conv + '/pointwise_kernel' in w else '/kernel')
+        w[key] = (w[key] * sd).astype(np.float32)                       # output channel c now has std sd[c]
+        w[name + '/moving_variance'] = var
+        w[name + '/moving_mean'] = (rng.normal(0.0, 0.3, c) * sd).astype(np.float32)
+        w[name + '/beta'] = rng.normal(0.0, 0.2, c).astype(np.float32)
+        w[name + '/gamma'] = (w[name + '/gamma'] * rng.uniform(0.8, 1.25, c)).astype(np.float32)
+    if logit_gain == 0.3:                                                # the default was not overridden
+        w['logits/kernel'] = (w['logits/kernel'] * np.float32(1.0 / 0.3)).astype(np.float32)
+    w['logits/bias'] = rng.normal(0.0, 0.2, n_classes).astype(np.float32)
 
 
 def expected_shapes(n_classes=2):

@@ -1,0 +1,247 @@
+"""BASELINE.json configs 3, 4 and 5 and the parity stress set, on the MI355X (``-m gpu``).
+
+* config 3 (slides sharded over ranks, one gather): two ranks on ONE GPU -- the real ``Engine`` in each,
+  ``BQ_LOCAL_DEVICE=0`` + a gloo process group -- must reproduce the single-rank result exactly; and
+  ``bench.py --gpus 2`` must start its own two ranks.
+* config 4 (MC sweep N in {1,5,10,30,50}): the fused on-device Welford ('head') is bit-identical to N separate
+  complete passes ('full') at every N, and matches the CPU oracle at N <= 10.
+* config 5 (TFRecords + checkpoint + params.json -> CLI -> CSV -> threshold.apply): the harness on self-written
+  records and an exported Keras-format checkpoint (no TCGA data exists here), equal to the in-memory path.
+* stress weights (``synthetic_weights(hard=True)``): O(1) logits, BatchNorm statistics far from identity.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from biscuit_amd.synthetic import make_slides, make_tiles
+from biscuit_amd.weights import synthetic_weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+# ------------------------------------------------------------------------------------------------ config 3
+def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
+    from _rank_worker import build_slides
+    from biscuit_amd.engine import Engine
+    from biscuit_amd.inference import evaluate
+    counts = [9, 4, 0, 7, 5, 3]
+    mc_n, batch = 6, 8
+    out = str(tmp_path / 'res')
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), BQ_LOCAL_DEVICE='0', BQ_DIST_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_rank_worker.py'), out, 'bf16',
+                                       str(mc_n), str(batch), ','.join(map(str, counts))], env=env, cwd=ROOT))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    eng = Engine(synthetic_weights(1), dtype='bf16', max_batch=batch, max_mc=mc_n)
+    single = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch)
+    r0, r1 = (np.load(f'{out}.rank{r}.npz') for r in range(2))
+    # both ranks hold the whole gathered slide table, equal to the single-rank one bit for bit
+    for r in (r0, r1):
+        assert np.array_equal(r['slide_pred'], single.slide_pred, equal_nan=True)
+        assert np.array_equal(r['slide_unc'], single.slide_unc, equal_nan=True)
+        assert list(r['slide_count']) == counts
+    assert sorted(list(r0['local']) + list(r1['local'])) == list(range(len(counts)))
+    # tile rows stay rank-local; together they are the single-rank table (Philox counters are global tile indices)
+    got = pd.DataFrame({'slide': np.concatenate([r0['tile_slide'], r1['tile_slide']]),
+                        'p': np.concatenate([r0['tile_pred'], r1['tile_pred']]),
+                        'u': np.concatenate([r0['tile_unc'], r1['tile_unc']])})
+    want = single.tile_df
+    for name in set(want['slide']):
+        a = got[got['slide'] == name]; b = want[want['slide'] == name]
+        assert np.array_equal(a['p'].to_numpy(), b['cohort-y_pred1'].to_numpy())
+        assert np.array_equal(a['u'].to_numpy(), b['cohort-uncertainty1'].to_numpy())
+    eng.close()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent spawns two ranks before touching the
+    GPU and relays rank 0's JSON line (here both ranks share GPU 0 through the gloo hook)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(BQ_LOCAL_DEVICE='0', BQ_DIST_BACKEND='gloo')
+    common = ['--steps', '2', '--warmup', '1', '--batch', '16', '--mc', '5', '--streams', '1', '--no-extras',
+              '--no-cpu-baseline', '--no-profile']
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + common, env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 2
+    # the strong-scaling form of config 3 (scaled down): slides LPT-sharded through inference.evaluate
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'cfg3', '--slides', '6',
+                        '--tiles-per-slide', '40'] + common, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['config']['slides_per_rank'] == [3, 3]
+    # a WORLD_SIZE / --gpus mismatch is an error, not a silent single-rank run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + common,
+                         env=dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0'), cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
+    assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr
+
+
+# ------------------------------------------------------------------------------------------------ config 4
+@pytest.fixture(scope='module')
+def sweep_engines():
+    from biscuit_amd.engine import Engine
+    w = synthetic_weights(1)
+    e = {'f32': Engine(w, dtype='f32', max_batch=8, max_mc=50), 'bf16': Engine(w, dtype='bf16', max_batch=8, max_mc=50)}
+    yield e
+    for x in e.values():
+        x.close()
+
+
+@pytest.mark.parametrize('mc_n', [1, 5, 10, 30, 50])
+def test_mc_sweep_fused_equals_separate_passes(sweep_engines, mc_n):
+    tiles = make_tiles(5, seed=31)
+    d = dev(tiles)
+    for dtype in ('f32', 'bf16'):
+        eng = sweep_engines[dtype]
+        m_h, s_h = eng.mc_infer(d, mc_n, 1234, tile_idx0=40, mc_mode='head')
+        m_f, s_f = eng.mc_infer(d, mc_n, 1234, tile_idx0=40, mc_mode='full')
+        assert torch.equal(m_h, m_f) and torch.equal(s_h, s_f), (dtype, mc_n)
+        if mc_n == 1:
+            assert torch.all(s_h == 0)
+        else:
+            assert torch.all(s_h > 0)
+    if mc_n <= 10:
+        from oracle.xception_ref import XceptionOracle
+        rm, rs = XceptionOracle(synthetic_weights(1)).mc_predict(tiles, mc_n, 1234, tile_index0=40, mode='head')
+        m, s = sweep_engines['f32'].mc_infer(d, mc_n, 1234, tile_idx0=40)
+        assert np.abs(m.cpu().numpy() - rm).max() < 1e-5 and np.abs(s.cpu().numpy() - rs).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ config 5
+def test_config5_harness_tfrecords_checkpoint_cli_threshold(tmp_path):
+    """Self-written PNG TFRecords (configure.py:118-124) + a Keras-format checkpoint + params.json
+    -> `python -m biscuit_amd --model` -> tile_predictions_eval.csv -> threshold.apply, against the in-memory path."""
+    from biscuit_amd import keras_import as K, tfrecord as tfr, threshold
+    from biscuit_amd.engine import Engine
+    from biscuit_amd.inference import Slide, evaluate
+    from biscuit_amd.predictions import rename_cols
+    d = str(tmp_path)
+    n_slides, per = 6, 7
+    tiles, sidx, y = make_slides(n_slides, per, seed=3)
+    rows = []
+    for i in range(n_slides):
+        t = tiles[sidx == i]
+        tfr.write_slide(f'{d}/s{i}.tfrecords', f's{i}', t, np.arange(2 * len(t)).reshape(-1, 2))
+        rows.append(f's{i},{int(y[i])},p{i // 2}')
+    open(f'{d}/labels.csv', 'w').write('slide,label,patient\n' + '\n'.join(rows) + '\n')
+    fit = {'target_means': [65.0, 12.0, -8.0], 'target_stds': [14.0, 7.0, 6.0]}
+    w = synthetic_weights(1, hard=True)
+    mdir = f'{d}/00001-cohort-HP0/cohort-HP0_epoch1'
+    K.export_bundle(mdir + '/variables/variables', w, optimizer_slots=True)
+    json.dump({'norm_fit': fit, 'hp': {'model': 'xception', 'tile_px': 299, 'hidden_layers': 2, 'hidden_layer_width': 1024,
+                                        'dropout': 0.2, 'normalizer': 'reinhard_fast'}}, open(mdir + '/params.json', 'w'))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, '-m', 'biscuit_amd', '--tfrecords', d, '--labels', f'{d}/labels.csv', '--out',
+                        f'{d}/eval', '--mc', '8', '--batch', '16', '--model', mdir, '--seed', '1234'], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    summary = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+    assert summary['slides'] == n_slides and summary['tiles'] == n_slides * per
+    df = pd.read_csv(f'{d}/eval/tile_predictions_eval.csv', dtype={'slide': str})
+    assert list(df.columns[:2]) == ['slide', 'cohort-y_true0'] or 'cohort-y_pred1' in df.columns
+    # the in-memory path on the same tiles, the same model hyper-parameters (dropout 0.2 from params.json)
+    from biscuit_amd.hp import ModelParams
+    eng = Engine(w, hp=ModelParams(dropout=0.2), dtype='bf16', max_batch=16, max_mc=8)
+    slides = [Slide(f's{i}', tiles[sidx == i], per, y_true=int(y[i])) for i in range(n_slides)]
+    mem = evaluate(eng, slides, outcome='cohort', mc_n=8, seed=1234, batch=16, norm_fit=fit)
+    np.testing.assert_allclose(df['cohort-y_pred1'].to_numpy(), mem.tile_df['cohort-y_pred1'].to_numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(df['cohort-uncertainty1'].to_numpy(), mem.tile_df['cohort-uncertainty1'].to_numpy(), rtol=0, atol=1e-7)
+    assert list(df['slide']) == list(mem.tile_df['slide'])
+    # dropout 0.2 really was used: the default-rate engine gives other uncertainties
+    eng01 = Engine(w, dtype='bf16', max_batch=16, max_mc=8)
+    other = evaluate(eng01, slides, outcome='cohort', mc_n=8, seed=1234, batch=16, norm_fit=fit)
+    assert not np.allclose(other.tile_df['cohort-uncertainty1'].to_numpy(), df['cohort-uncertainty1'].to_numpy(), atol=1e-4)
+    # consumer: the CSV through the reference's surface
+    rename_cols(df, 'cohort')
+    patients = {f's{i}': f'p{i // 2}' for i in range(n_slides)}
+    metrics, _ = threshold.apply(df, tile_uq=0.0, slide_uq=0.0, patients=patients)
+    assert set(metrics) >= {'auc', 'percent_incl', 'acc', 'sensitivity', 'specificity'}
+    assert metrics['percent_incl'] == 1.0
+    for k in ('auc', 'acc'):
+        assert summary[k] is None or abs(summary[k] - float(metrics[k])) < 1e-12
+    sl = pd.read_csv(f'{d}/eval/slide_predictions_cohort_eval.csv', dtype={'slide': str})
+    np.testing.assert_allclose(sl['y_pred'].to_numpy(), mem.slide_pred, atol=1e-9)
+    eng.close(); eng01.close()
+
+
+# ------------------------------------------------------------------------------------------------ stress weights
+@pytest.fixture(scope='module')
+def hard():
+    from biscuit_amd.engine import Engine
+    from oracle.xception_ref import XceptionOracle
+    w = synthetic_weights(1, hard=True)
+    e = {'w': w, 'f32': Engine(w, dtype='f32', max_batch=64, max_mc=30), 'bf16': Engine(w, dtype='bf16', max_batch=64, max_mc=30),
+         'oracle': XceptionOracle(w)}
+    yield e
+    e['f32'].close(); e['bf16'].close()
+
+
+def test_hard_weights_fp32_kernels_against_both_oracles(hard):
+    from oracle import xception_nn as NN
+    tiles = make_tiles(4, seed=19)
+    rm, rs = hard['oracle'].mc_predict(tiles, 10, 1234, mode='head')
+    nm, ns = NN.mc_predict(NN.XceptionNN(hard['w']), tiles, 10, 1234)
+    m, s = hard['f32'].mc_infer(dev(tiles), 10, 1234)
+    m, s = m.cpu().numpy(), s.cpu().numpy()
+    print('hard weights, fp32 kernels: vs oracle 1 %.2e / %.2e, vs oracle 2 %.2e / %.2e; pred %s std %s' % (
+        np.abs(m - rm).max(), np.abs(s - rs).max(), np.abs(m - nm).max(), np.abs(s - ns).max(), m[:, 1], s[:, 1]))
+    assert np.abs(m - rm).max() < 2e-5 and np.abs(s - rs).max() < 2e-5
+    assert np.abs(m - nm).max() < 2e-5 and np.abs(s - ns).max() < 2e-5
+    assert np.abs(m[:, 1] - 0.5).max() > 0.05           # O(1) logits: predictions leave the 0.35-0.65 band of the default set
+
+
+def test_hard_weights_every_layer_fp32(hard):
+    from oracle.xception_ref import standardize
+    from test_gpu_parity import TAPS
+    t2 = make_tiles(2, seed=19)
+    taps = {}
+    hard['oracle'].backbone(standardize(t2), taps)
+    eng = hard['f32']
+    staged = eng.stage(dev(t2))
+    for name, shp in TAPS:
+        got = eng.debug_activation(name, staged, shp).cpu().numpy()
+        ref = taps[name].permute(0, 2, 3, 1).numpy()
+        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), name
+
+
+def test_hard_weights_bf16_kernels_reported(hard):
+    """bf16 kernels vs the exact fp32 kernels (= the oracle to 1e-5) on the stress set, 64 tiles, MC = 30:
+    tile- and slide-level |d| printed; the north-star tolerance (1e-3) applies at both levels."""
+    tiles, sidx, _ = make_slides(4, 16, seed=7)
+    d = dev(tiles)
+    m32, s32 = hard['f32'].mc_infer(d, 30, 1234)
+    m16, s16 = hard['bf16'].mc_infer(d, 30, 1234)
+    dm, ds = float((m32 - m16).abs().max()), float((s32 - s16).abs().max())
+    sl = dev(sidx).long()
+    def smean(x):
+        return torch.zeros(4, device='cuda', dtype=torch.float64).index_add_(0, sl, x.double()) / 16
+    dsp = float((smean(m32[:, 1]) - smean(m16[:, 1])).abs().max())
+    dsu = float((smean(s32[:, 1]) - smean(s16[:, 1])).abs().max())
+    print(f'hard weights, bf16 vs fp32 kernels: tile max|dmean|={dm:.3e} max|dstd|={ds:.3e}; slide pred {dsp:.3e} unc {dsu:.3e}')
+    assert dm < BF16_HARD_TOL and ds < BF16_HARD_TOL and dsp < 1e-3 and dsu < 1e-3
+
+
+BF16_HARD_TOL = 1e-3

@@ -160,3 +160,23 @@ def test_weight_file_roundtrip_and_validation(tmp_path):
     bad = dict(w); bad['logits/bias'] = np.array([np.nan, 0], np.float32)
     with pytest.raises(ValueError):
         W.validate(bad)
+
+
+def test_cli_model_hp_comes_from_params_json():
+    """dropout / uq_n / normalizer of a model's params.json drive the run, never the defaults."""
+    from biscuit_amd.__main__ import model_hp
+    hp, fit = model_hp(None)
+    assert (hp.dropout, hp.uq_n, fit) == (0.1, 30, None)
+    nf = {'target_means': [1, 2, 3], 'target_stds': [4, 5, 6]}
+    hp, fit = model_hp({'hp': {'dropout': 0.25, 'uq_n': 12}, 'normalizer': 'reinhard_fast', 'norm_fit': nf, 'path': 'p'})
+    assert (hp.dropout, hp.uq_n, hp.normalizer) == (0.25, 12, 'reinhard_fast') and fit == nf
+    hp, fit = model_hp({'hp': {'dropout': 0.5}, 'normalizer': None, 'norm_fit': None})
+    assert hp.dropout == 0.5 and hp.normalizer is None and fit is None
+    for bad in ({'hp': {}, 'normalizer': 'macenko', 'norm_fit': nf},          # another normaliser: refuse, do not mis-normalise
+                {'hp': {}, 'normalizer': 'reinhard', 'norm_fit': nf},
+                {'hp': {}, 'normalizer': None, 'norm_fit': nf},               # a fit but no method named
+                {'hp': {}, 'normalizer': 'reinhard_fast', 'norm_fit': None}): # the method but no fit
+        with pytest.raises(SystemExit):
+            model_hp(bad)
+    with pytest.raises(ValueError):
+        model_hp({'hp': {'dropout': 1.5}, 'normalizer': None})

@@ -26,7 +26,7 @@ from biscuit_amd import keras_import as K, weights as W
 d = sys.argv[1] + '/00001-cohort-HP0/cohort-HP0_epoch1'
 K.export_bundle(d + '/variables/variables', W.synthetic_weights(1), optimizer_slots=True)
 json.dump({'norm_fit': {'target_means': [65.0, 12.0, -8.0], 'target_stds': [14.0, 7.0, 6.0]},
-           'hp': {'model': 'xception', 'tile_px': 299, 'hidden_layers': 2, 'hidden_layer_width': 1024, 'dropout': 0.1}},
+           'hp': {'model': 'xception', 'tile_px': 299, 'hidden_layers': 2, 'hidden_layer_width': 1024, 'dropout': 0.1, 'normalizer': 'reinhard_fast'}},
           open(d + '/params.json', 'w'))
 PY
 python -m biscuit_amd --tfrecords $D --labels $D/labels.csv --out $D/eval3 --mc 4 --batch 8 --model $D/00001-cohort-HP0/cohort-HP0_epoch1 2>&1 | grep -v amdgpu | tail -1
