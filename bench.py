@@ -412,13 +412,14 @@ def run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks):
     allt = torch.cat(pool)                                       # the resident synthetic tiles, cycled
     npool = allt.shape[0]
 
-    def tiles_of(i):
+    def tiles_of(i, count):
         def load():
-            idx = (torch.arange(T, device=dev) + i * T) % npool
+            idx = (torch.arange(count, device=dev) + i * T) % npool
             return allt.index_select(0, idx)
         return load
-    slides = [Slide(f's{i:05d}', tiles_of(i), T, y_true=i % 2) for i in range(S)]
-    warm = [Slide(f'w{i}', tiles_of(i), min(T, 2 * B), y_true=0) for i in range(world * max(1, args.warmup))]
+    slides = [Slide(f's{i:05d}', tiles_of(i, T), T, y_true=i % 2) for i in range(S)]
+    wt = min(T, 2 * B)
+    warm = [Slide(f'w{i}', tiles_of(i, wt), wt, y_true=0) for i in range(world * max(1, args.warmup))]
     pool_e.set_in_flight(min(2, len(pool_e.engines)))
     evaluate(pool_e, warm, mc_n=args.mc, seed=1234, batch=B, mc_mode=args.mode, keep_tiles=False, rank=rank, world=world)
     barrier()

@@ -71,6 +71,12 @@ int fail(bq_ctx* c, int code, const std::string& msg) {
             return fail((c), BQ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int pad16(int c) { return (c + 15) / 16 * 16; }
 inline size_t esize(const bq_ctx* c) { return c->cfg.dtype == BQ_DTYPE_BF16 ? 2 : 4; }
@@ -143,7 +149,7 @@ struct ProfScope {
 int pick_shape(const bq_ctx* c, int prod, int nfp) {
     if (prod == PROD_IM2COL) return SHAPE_A;
     if (c->cfg.dtype == BQ_DTYPE_BF16) {
-        static const bool s2_small = !getenv("BQ_S2_BIG");
+        static const bool s2_small = !bq_exp_env("BQ_S2_BIG");
         // 64-row tiles halve the staging tile: four workgroups per CU instead of two for N = 256
         // (128->256 @37x37: 0.161 -> 0.111 ms); for N = 128 they measured slower (0.194 -> 0.234 ms)
         if (prod == PROD_S2 && s2_small && nfp == 8) return SHAPE_K;
@@ -211,13 +217,13 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     // Two-kernel form (depthwise kernel + 128x128-tile GEMM): always for the wide exit-flow layers
     // (K >= 1024: the fused kernel can only hold 32-64 rows of A in LDS there and re-streams the
     // 3-6 MB weight matrix per 32-64 rows); BQ_SPLIT=1 forces it for every separable conv.
-    static const bool split_env = getenv("BQ_SPLIT") != nullptr;
-    static const bool no_split = getenv("BQ_NO_SPLIT") != nullptr;
+    static const bool split_env = bq_exp_env("BQ_SPLIT") != nullptr;
+    static const bool no_split = bq_exp_env("BQ_NO_SPLIT") != nullptr;
     const bool will_split = !no_split && (split_env || L.kpad >= 1024) && dtype == BQ_DTYPE_BF16 && dwp &&
                             L.nfp % 4 == 0 && a.dwtmp && nsplit == 1;
     ProfScope ps(c, s, will_split ? std::string("split_") + cls : std::string(cls), will_split ? 0.0 : flops, will_split ? 0.0 : bytes);
-    static const bool no_tile = getenv("BQ_NO_TILE") != nullptr;
-    static const int tile_mask = getenv("BQ_TILE_MASK") ? atoi(getenv("BQ_TILE_MASK")) : 7;   // kinds enabled (bit k)
+    static const bool no_tile = bq_exp_env("BQ_NO_TILE") != nullptr;
+    static const int tile_mask = bq_exp_env("BQ_TILE_MASK") ? atoi(bq_exp_env("BQ_TILE_MASK")) : 7;   // kinds enabled (bit k)
     if (!no_tile && dtype == BQ_DTYPE_BF16 && !a.residual) {
         int kind = -1;
         if (a.prod == PROD_IM2COL && L.cin == 32 && L.cout == 64) kind = 0;
@@ -247,60 +253,11 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;
     }
-    static const bool no_pipe = getenv("BQ_NO_PIPE") != nullptr;
-    static const bool no_mid = getenv("BQ_MID") == nullptr;   // experimental persistent 19x19 kernel: opt-in
-    static const int dbg = getenv("BQ_DBG") ? atoi(getenv("BQ_DBG")) : 0;
-    p.dbg = dbg;
-    if (!no_mid && nsplit == 1 && a.H == a.Hi && a.W == a.Wi &&
-        mid_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, p.M, a.ldo)) {
-        p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
-        p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
-        // diagnostic: BQ_STAMPS=<file> records in-kernel s_memtime stamps of the first such launch
-        static const char* stamp_file = getenv("BQ_STAMPS");
-        static int stamp_state = 0;
-        static unsigned long long* d_stamps = nullptr;
-        if (stamp_file && stamp_state == 0 && a.residual) {
-            if (hipMalloc(&d_stamps, 64 * 8 * 128 * 8) == hipSuccess) {
-                hipMemsetAsync(d_stamps, 0, 64 * 8 * 128 * 8, s);
-                p.stamps = d_stamps;
-                stamp_state = 1;
-            }
-        }
-        const int e = launch_sepconv_mid(a.prod, p, c->num_cus, s);
-        if (stamp_state == 1) {
-            std::vector<unsigned long long> h(64 * 8 * 128);
-            hipStreamSynchronize(s);
-            hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
-            if (FILE* f = fopen(stamp_file, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-            stamp_state = 2;
-        }
-        if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(mid) ") + a.layer + ": " +
-                                                   hipGetErrorString((hipError_t)e));
-        return BQ_OK;
-    }
+    static const bool no_pipe = bq_exp_env("BQ_NO_PIPE") != nullptr;
     if (!no_pipe && nsplit == 1 && pipe_supported(dtype, a.prod, L.nfp, a.W, L.kpad)) {
         p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
-        static const char* pstamp_file = getenv("BQ_STAMPS_PIPE");
-        static int pstamp_state = 0;
-        static unsigned long long* d_pstamps = nullptr;
-        static const bool pstamp_res = getenv("BQ_STAMPS_NORES") == nullptr;
-        if (pstamp_file && pstamp_state == 0 && a.W == 19 && (a.residual != nullptr) == pstamp_res) {
-            if (hipMalloc(&d_pstamps, 64 * 8 * 128 * 8) == hipSuccess) {
-                (void)hipMemsetAsync(d_pstamps, 0, 64 * 8 * 128 * 8, s);
-                p.stamps = d_pstamps;
-                pstamp_state = 1;
-            }
-        }
         const int e = launch_sepconv_pipe(a.prod, p, s);
-        if (pstamp_state == 1) {
-            std::vector<unsigned long long> hbuf(64 * 8 * 128);
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(hbuf.data(), d_pstamps, hbuf.size() * 8, hipMemcpyDeviceToHost);
-            if (FILE* f = fopen(pstamp_file, "wb")) { fwrite(hbuf.data(), 8, hbuf.size(), f); fclose(f); }
-            pstamp_state = 2;
-            p.stamps = nullptr;
-        }
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(pipe) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;
@@ -411,7 +368,7 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     // with a small sub-batch every intermediate buffer is re-used at the same addresses and stays in
     // the 256 MiB Infinity Cache instead of round-tripping through HBM.  The block-4 outputs of all
     // sub-batches are gathered in the upper half of buffer B (the sub-batches only touch the front).
-    static const int env_sub = getenv("BQ_SUB") ? atoi(getenv("BQ_SUB")) : 0;
+    static const int env_sub = bq_exp_env("BQ_SUB") ? atoi(bq_exp_env("BQ_SUB")) : 0;
     int sub = (tap && tap->want) ? n : env_sub;
     if (sub <= 0 || sub > n / 2) sub = n;
     const size_t tile4 = (size_t)361 * 736 * esize(c);
@@ -484,7 +441,7 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
         // K handled per launch = 1024 (131.6 KB of LDS for the 32-row A tile: one workgroup per CU, and
         // 7 680 rows are only 240 workgroups, so the launch is one latency chain per CU).  BQ_HEAD_WAVES=4
         // restores the 4-wave workgroup.
-        static const bool w8 = !(getenv("BQ_HEAD_WAVES") && atoi(getenv("BQ_HEAD_WAVES")) == 4);
+        static const bool w8 = !(bq_exp_env("BQ_HEAD_WAVES") && atoi(bq_exp_env("BQ_HEAD_WAVES")) == 4);
         const int KS = 1024;
         const int nsplit = K / KS;
         ProfScope ps(c, s, layer == 0 ? "mc_head_dense0" : "mc_head_dense1", 2.0 * rows * (double)K * 1024,
@@ -536,9 +493,13 @@ int register_gemm_layer(bq_ctx* c, const std::string& name, int cin, int cout, i
     L.scale = entry_f32(c, name + "/scale");
     L.bias = entry_f32(c, name + "/bias");
     if (!L.scale || !L.bias) return fail(c, BQ_ERR_WEIGHTS, "missing scale/bias for " + name);
+    if (c->entries[name + "/scale"].n < (size_t)cout * 4 || c->entries[name + "/bias"].n < (size_t)cout * 4)
+        return fail(c, BQ_ERR_WEIGHTS, "scale/bias of " + name + " shorter than its output channels");
     if (has_dw) {
         L.dw = entry_f32(c, name + "/dw");
         if (!L.dw) return fail(c, BQ_ERR_WEIGHTS, "missing " + name + "/dw");
+        if (c->entries[name + "/dw"].n < (size_t)9 * kpad * 4)
+            return fail(c, BQ_ERR_WEIGHTS, "depthwise taps of " + name + " shorter than 9 x its padded input channels");
     }
     c->layers[name] = L;
     return BQ_OK;
@@ -570,10 +531,12 @@ bq_ctx* bq_create(int device_id, const bq_config* cfg) {
     }
     bq_ctx* c = new (std::nothrow) bq_ctx();
     if (!c) { g_create_error = "out of host memory"; return nullptr; }
+    DeviceGuard guard(device_id);            // allocations below go to the context's device; the caller's stays current
+    if (!guard.ok) { g_create_error = "hipSetDevice failed"; delete c; return nullptr; }
     c->cfg = *cfg;
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* e = getenv("BQ_NUM_CUS")) { const int v = atoi(e); if (v > 0) c->num_cus = v; }   // persistent-grid sizing (experiments)
+    if (const char* e = bq_exp_env("BQ_NUM_CUS")) { const int v = atoi(e); if (v > 0) c->num_cus = v; }   // persistent-grid sizing (experiments)
     {   // tables of the Reinhard normaliser (oracle/stain.py states the same arithmetic):
         // [0,256)   sRGB -> linear, float64 evaluation rounded to float32
         // [256,511) linear -> 8-bit sRGB as 255 switching points: entry v-1 is the smallest float32 c for which
@@ -604,7 +567,7 @@ bq_ctx* bq_create(int device_id, const bq_config* cfg) {
             memcpy(&lut[256 + v - 1], &lo, 4);
         }
         lut[511] = 0.f;
-        if (hipSetDevice(device_id) != hipSuccess || hipMalloc(&c->d_srgb_lut, sizeof lut) != hipSuccess ||
+        if (hipMalloc(&c->d_srgb_lut, sizeof lut) != hipSuccess ||
             hipMemcpy(c->d_srgb_lut, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) {
             g_create_error = "cannot allocate the sRGB tables";
             delete c;
@@ -644,20 +607,24 @@ int bq_load_weights(bq_ctx* c, const void* host_blob, size_t nbytes) {
     memcpy(&ver, hb + 4, 4); memcpy(&cnt, hb + 8, 4); memcpy(&dt, hb + 12, 4);
     if (ver != 1 || (size_t)16 + (size_t)cnt * 64 > nbytes) return fail(c, BQ_ERR_WEIGHTS, "bad header");
     if ((int)dt != c->cfg.dtype) return fail(c, BQ_ERR_WEIGHTS, "blob dtype does not match context dtype");
-    int prev = 0;
-    HIPCHK(c, hipGetDevice(&prev));
-    HIPCHK(c, hipSetDevice(c->device));
+    // validate the directory before anything is allocated (wrap-free bounds: off and len are untrusted 64-bit values)
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const unsigned char* e = hb + 16 + (size_t)i * 64;
+        char name[49]; memcpy(name, e, 48); name[48] = 0;
+        uint64_t off, len; memcpy(&off, e + 48, 8); memcpy(&len, e + 56, 8);
+        if (off > nbytes || len > nbytes - off || (off & 255)) return fail(c, BQ_ERR_WEIGHTS, std::string("bad entry ") + name);
+    }
+    DeviceGuard guard(c->device);            // restores the caller's current device on every exit path
+    if (!guard.ok) return fail(c, BQ_ERR_HIP, "hipSetDevice failed");
     if (c->d_blob) { (void)hipFree(c->d_blob); c->d_blob = nullptr; }
     c->entries.clear(); c->layers.clear(); c->loaded = false;
     HIPCHK(c, hipMalloc((void**)&c->d_blob, nbytes));
     HIPCHK(c, hipMemcpy(c->d_blob, hb, nbytes, hipMemcpyHostToDevice));
-    (void)hipSetDevice(prev);
     c->blob_bytes = nbytes;
     for (uint32_t i = 0; i < cnt; ++i) {
         const unsigned char* e = hb + 16 + (size_t)i * 64;
         char name[49]; memcpy(name, e, 48); name[48] = 0;
         uint64_t off, len; memcpy(&off, e + 48, 8); memcpy(&len, e + 56, 8);
-        if (off + len > nbytes || (off & 255)) return fail(c, BQ_ERR_WEIGHTS, std::string("bad entry ") + name);
         c->entries[name] = Blob{c->d_blob + off, (size_t)len};
     }
     const int vec = c->cfg.dtype == BQ_DTYPE_BF16 ? 8 : 4;
@@ -692,7 +659,7 @@ int bq_stage(bq_ctx* c, const uint8_t* d_tiles, int n, void* d_out, bq_stream_t 
     if (!c || !d_tiles || !d_out || n < 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_stage: bad argument");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(c, s, "stage_u8_standardize", 4.0 * n * kStaged, (double)n * kStaged * (1.0 + esize(c)));
-    static const bool one_kernel = getenv("BQ_STAGE_1K") != nullptr;
+    static const bool one_kernel = bq_exp_env("BQ_STAGE_1K") != nullptr;
     if (launch_stage_u8(d_tiles, n, 299, d_out, c->cfg.dtype, one_kernel ? nullptr : c->d_stage_stats, s))
         return fail(c, BQ_ERR_HIP, "stage launch failed");
     return BQ_OK;
@@ -734,7 +701,8 @@ int bq_stain_lab_stats(bq_ctx* c, const uint8_t* d_tiles, int n, float* d_stats6
 int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, bq_stream_t* out) {
     if (!c || !cu_mask || mask_words <= 0 || !out) return fail(c, BQ_ERR_ARG, "bq_stream_create_masked: bad argument");
     hipStream_t s = nullptr;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(c, BQ_ERR_HIP, "hipSetDevice failed");
     HIPCHK(c, hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask));
     *out = (bq_stream_t)s;
     return BQ_OK;

@@ -4,6 +4,32 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <stdlib.h>
+
+// Experiment switches (ablations, alternative tilings, in-kernel stamps) exist only in -DBQ_EXPERIMENTS builds
+// (`make EXPERIMENTS=1`); the product library reads no environment variable and carries no debug branch.
+#ifdef BQ_EXPERIMENTS
+inline const char* bq_exp_env(const char* name) { return getenv(name); }
+#else
+inline const char* bq_exp_env(const char*) { return nullptr; }
+#endif
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device only: remember, per device, the
+// largest size already set for one kernel (one `BqLdsAttr` object per kernel instantiation).
+struct BqLdsAttr {
+    static constexpr int kMaxDev = 64;
+    size_t set[kMaxDev] = {};
+    int ensure(const void* kern, size_t lds) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = -1;
+        if (dev >= 0 && lds <= set[dev]) return 0;
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) set[dev] = lds;
+        return 0;
+    }
+};
+
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,8 +84,6 @@ struct GemmParams {
     int layer, mc_n, pass0, in_row_is_tile;
     long long tile0;
     int lds_total;         // dynamic LDS bytes of the launch (set by the pipe launcher)
-    int dbg;               // ablation flags for timing experiments (0 in production)
-    unsigned long long* stamps;   // diagnostic builds: s_memtime stamps [wg][wave][64] (null in production)
 };
 
 size_t gemm_lds_bytes(int dtype, int shape, int K);
@@ -68,8 +92,6 @@ int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t
 int gemm_tile_rows(int shape);
 bool pipe_supported(int dtype, int prod, int nfp, int W, int K);
 int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s);
-bool mid_supported(int dtype, int prod, int nfp, int H, int W, int K, int M, int Nstore);
-int launch_sepconv_mid(int prod, const GemmParams& p, int num_cus, hipStream_t s);
 int launch_dw3x3(const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
 int launch_gemm_tile(const GemmParams& p, hipStream_t s);
 int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, const float* scale,

@@ -270,13 +270,8 @@ int launch_inst(const GemmParams& p, hipStream_t s) {
         const size_t stage = (size_t)(32 * d.MF) * (p.Nstore * sizeof(T) + 16);
         if (stage > lds) lds = stage;
     }
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        lds_set = lds;
-    }
+    static BqLdsAttr attr;
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     if (p.NFp % (d.WN * d.RN) != 0 || p.K % (2 * vec) != 0 || lds > 160 * 1024)
         return (int)hipErrorInvalidValue;
     const int mt = 32 * d.MF;

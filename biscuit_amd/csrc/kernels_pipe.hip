@@ -16,7 +16,6 @@
 // in the same iteration.  Depthwise taps live in LDS as fp32 (26 KB for 736 channels).
 #include "gemm_common.h"
 
-#include <stdlib.h>
 
 namespace {
 using namespace bqk;
@@ -91,7 +90,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT, int MT, int NITEM>
 __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, int wl_off, int c, int K,
-                                          int W, int jch, int tid, const unsigned (&item_mask)[NITEM], int dbg = 0) {
+                                          int W, int jch, int tid, const unsigned (&item_mask)[NITEM]) {
     if (c * KC + jch * 8 >= K) {                   // padded channel tail of the last chunk: A = 0 (the matrix
 #pragma unroll                                     // stage always runs whole chunks)
         for (int q = 0; q < NITEM; ++q) {
@@ -110,7 +109,7 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
             // one tap row at a time (outer loop not unrolled): keeps the live set small, the
             // accumulators of the matrix-core stage leave few spare registers
 #pragma unroll 1
-            for (int dy = (dbg & 64) ? 1 : 0; dy < ((dbg & 64) ? 2 : 3); ++dy) {
+            for (int dy = 0; dy < 3; ++dy) {
                 const int rowoff = base + (dy - 1) * W * RAW_ROW;
                 const int woff = wbase + dy * 3 * K * 4;
                 const unsigned mrow = item_mask[q] >> (dy * 3);
@@ -148,8 +147,7 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
 // path-dependent, and the compiler then waits vmcnt(0) - the whole ring - before every k-block.
 template <int MF, int RN, int PF, int KBC>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
-                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot,
-                                          int dbg = 0) {
+                                          int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot) {
 #pragma unroll
     for (int d = 0; d < KBC; ++d) {
         const int kb = c * KBC + d;
@@ -162,7 +160,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF]
 #pragma unroll
             for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
         const int nx = kb + PF;
-        const int idx = (dbg & 128) ? 0 : (nx < KB ? nx : KB - 1);   // 128: timing probe, B stays L1-resident
+        const int idx = nx < KB ? nx : KB - 1;
 #pragma unroll
         for (int j = 0; j < RN; ++j) bq[d & (PF - 1)][j] = bp0[((size_t)j * KBtot + idx) * 64];
     }
@@ -320,9 +318,6 @@ __device__ __forceinline__ void mma_chunk_pre(f32x16 (&acc)[MF][RN], uint4 (&bq)
     }
 }
 
-// diagnostic s_memtime stamps (BQ_STAMPS; p.stamps is null in production)
-#define PSTAMP(ev) do { if (stp && (tid & 63) == 0) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
-
 // WM groups of WN waves: group g owns rows [32*MF*g, 32*MF*(g+1)) of the tile, every group all output columns.
 // WM = 2 (16 waves, 192-row tiles) is for the 256-wide layers on large maps: a 74-wide map needs 150 halo
 // pixels around ANY flattened tile, so twice the rows per tile means 30 % less halo traffic per pixel, the
@@ -366,8 +361,6 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
 
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = tile * MT;
-    unsigned long long* stp = (p.stamps && blockIdx.x < 64) ? p.stamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 128 : nullptr;
-    PSTAMP(0);
     const int p_lo = m0 - (W + 1);
     const int K = p.K;                             // padded input channels (multiple of 16)
     const int KB = K / 16;
@@ -479,9 +472,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         raw_store<NT, RELU, NRAW>(rreg, smem, 0, jch, tid, p_lo, HP, p.M);
         rreg = raw_load<NT, NRAW>(in, ldi, 1, K, jch, tid, p_lo, p.M);
     }
-    PSTAMP(1);
     __syncthreads();                               // raw[0] and the taps are visible
-    PSTAMP(2);
     if constexpr (HDMA) halo_dma_asm(in, ldi, 1, K, p_lo, p.M, HP, lane, wave_u, NT / 64, lds_raw0 + raw_bytes);
     depthwise<NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
     if constexpr (HDMA) {
@@ -498,16 +489,14 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         for (int j = 0; j < RN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    PSTAMP(3);
     __syncthreads();                               // A(0) and raw[1] visible
-    PSTAMP(4);
 
     for (int c = 0; c < NC; ++c) {
         const int cur = c & 1, nxt = cur ^ 1;
         // L: raw chunk c+2 (loaded during the previous iteration) -> raw[cur], whose last reader D(c)
         // finished before the previous barrier
         if constexpr (!HDMA) {
-            if (c + 2 < NC && !(p.dbg & 16)) raw_store<NT, RELU, NRAW>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
+            if (c + 2 < NC) raw_store<NT, RELU, NRAW>(rreg, smem, cur * raw_bytes, jch, tid, p_lo, HP, p.M);
         }
         // D (depthwise of chunk c+1, vector ALU) and G (matrix cores on chunk c) are independent.
         // Each SIMD hosts one wave of each half of the workgroup: run them in opposite order so
@@ -516,40 +505,37 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
         // of G they would sit ahead of the B ring's loads in the in-order vmcnt queue and the first
         // k-blocks would wait out their HBM latency.
         const int a_base = a_off0 + cur * MT * A_STR + (wm * MF * 32 + r32) * A_STR + h * 16;
-        const bool do_d = (c + 1 < NC) && !(p.dbg & 1);
+        const bool do_d = c + 1 < NC;
         const int dma_lo = c == NC - 2 ? npre : c == NC - 1 ? n1 : c * (NT / 64);
         const int dma_hi = c == NC - 2 ? n1 : c == NC - 1 ? n2 : min(npre, (c + 1) * (NT / 64));
         if (first_half) {
             if constexpr (HDMA) {
                 // chunk c+2 -> raw[cur] (its last reader, D(c), finished before the previous barrier); only the
                 // waves that run D first issue these: in front of G they would delay the B ring (in-order vmcnt)
-                if (c + 2 < NC && !(p.dbg & 16))
+                if (c + 2 < NC)
                     halo_dma_asm(in, ldi, c + 2, K, p_lo, p.M, HP, lane, wave_u, HSTEP, lds_raw0 + cur * raw_bytes);
             } else {
-                if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+                rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
             }
             for (int r = dma_lo + wave_u; r < dma_hi; r += NT / 64) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, r);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
-                                         tid, item_mask, p.dbg);
+                                         tid, item_mask);
         }
-        PSTAMP(5 + 4 * c);
         if constexpr (RN == 3) {
-            if (!(p.dbg & 2)) mma_chunk_pre<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+            mma_chunk_pre<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
         } else {
-            if (!(p.dbg & 2)) mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot, p.dbg);
+            mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
         }
-        PSTAMP(6 + 4 * c);
         if (!first_half) {
             if constexpr (!HDMA) {
-                if (!(p.dbg & 16)) rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
+                rreg = raw_load<NT, NRAW>(in, ldi, c + 3, K, jch, tid, p_lo, p.M);
             }
             for (int r = dma_lo + wave_u; r < dma_hi; r += NT / 64) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, r);
             if (do_d)
                 depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
-                                         tid, item_mask, p.dbg);
+                                         tid, item_mask);
         }
-        PSTAMP(7 + 4 * c);
         if constexpr (HDMA) {
             // the halo DMA is older than the PF*RN ring loads this wave's G stage left in flight.  (A register
             // spill reload inside that stage would be one more younger vector-memory operation and make this count
@@ -558,25 +544,20 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
             if (first_half) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PF * RN) : "memory");
         }
         __syncthreads();
-        PSTAMP(8 + 4 * c);
     }
     // every wave is past its last LDS read (the loop's closing barrier): reuse LDS as the
     // output staging tile
-    if (!(p.dbg & 4)) {
+    {
         if (res_dma) {
             residual_dma<NT, MT>(p, m0, tid, smem0, n2, MT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the in-loop asm copies too
             __syncthreads();                       // (waits for this wave's DMA, then for everyone's)
-            PSTAMP(56);
             pipe_epilogue_to_lds<MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, true);
         } else {
             pipe_epilogue_to_lds<MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, false);
         }
-        PSTAMP(57);
         __syncthreads();
-        PSTAMP(58);
         lds_rows_to_global<bf16_t, NT, MT>(p, m0, tid, smem0);
-        PSTAMP(59);
     }
 }
 
@@ -594,13 +575,8 @@ int launch_pipe(const GemmParams& p, hipStream_t s) {
     if (p.residual && WM == 1 && RN == 3 && lds <= 160 * 1024) lds = 160 * 1024;
     if (p.NFp != WN * RN || p.K % 16 != 0 || p.K > 768 || p.Nstore % 8 != 0 || p.Nstore > 1024 || HP * CPR > NRAW * 64 * WN * WM || lds > 160 * 1024 || p.k_off != 0)
         return (int)hipErrorInvalidValue;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        lds_set = lds;
-    }
+    static BqLdsAttr attr;
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     const int grid = (p.M + MT - 1) / MT;
     GemmParams q = p;
     q.lds_total = (int)lds;
@@ -632,7 +608,7 @@ int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s) {
     const bool relu = prod == PROD_DW_RELU;
     if (pipe_variant(p.NFp, p.W) == 0) return relu ? launch_pipe<true, 3, 3, 1>(p, s) : launch_pipe<false, 3, 3, 1>(p, s);
     // 256-wide: 192-row tiles on 16 waves where the halo of a 96-row tile is larger than the tile itself
-    static const bool no_wide = getenv("BQ_PIPE_NO_WM2") != nullptr;
+    static const bool no_wide = bq_exp_env("BQ_PIPE_NO_WM2") != nullptr;
     const size_t lds2 = (size_t)2 * (192 + 2 * (p.W + 1)) * RAW_ROW + 2 * 192 * A_STR + (size_t)9 * p.K * 4;
     if (!no_wide && p.W >= 48 && lds2 + (size_t)p.NFp * 32 * 8 + 16 <= 160 * 1024 && (192 + 2 * (p.W + 1)) * CPR <= 3 * 1024)
         return relu ? launch_pipe<true, 1, 3, 2>(p, s) : launch_pipe<false, 1, 3, 2>(p, s);

@@ -254,15 +254,10 @@ int launch_tile(const TileParams& p, int num_cus, hipStream_t s) {
     constexpr size_t lds = W_BYTES + TAP_BYTES + (WPE < 3 ? (size_t)NF * 32 * 8 : 0) + (RAW_BYTES > STAGE_BYTES ? RAW_BYTES : STAGE_BYTES);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     auto kern = tile_conv_kernel<MODE, CIN, NF, RELU_IN, WPE>;
-    static bool set = false;
-    if (!set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        set = true;
-    }
+    static BqLdsAttr attr;
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
-    static const int env_wgs = getenv("BQ_TILE_WGS") ? atoi(getenv("BQ_TILE_WGS")) : 0;
+    static const int env_wgs = bq_exp_env("BQ_TILE_WGS") ? atoi(bq_exp_env("BQ_TILE_WGS")) : 0;
     int wgs = per_cu > WPE ? WPE : per_cu;     // persistent workgroups per CU = waves per SIMD
     if (env_wgs > 0 && env_wgs < wgs) wgs = env_wgs;
     const int ntiles = p.n * p.tyn * p.txn;
@@ -683,13 +678,8 @@ int launch_tile_sep2(TileParams p, int num_cus, hipStream_t s) {
                            (size_t)8 * 32 * (N * 2 + 16);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
     auto kern = CIN > 64 ? tile_sep2p_kernel<CIN, NF, RELU_IN> : tile_sep2_kernel<CIN, NF, RELU_IN>;
-    static bool set = false;
-    if (!set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        set = true;
-    }
+    static BqLdsAttr attr;
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     p.tyn = (p.H + T2 - 1) / T2;
     p.txn = (p.W + T2 - 1) / T2;
     const int ntiles = p.n * p.tyn * p.txn;
@@ -714,7 +704,7 @@ int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, 
     p.n = n; p.H = H; p.W = W; p.Hi = Hi; p.Wi = Wi;
     p.tyn = (H + TH - 1) / TH; p.txn = (W + TW - 1) / TW;
     p.relu = relu;
-    static const bool sep2 = getenv("BQ_TILE_SEP1") == nullptr;   // the lane = channel-pair form (default)
+    static const bool sep2 = bq_exp_env("BQ_TILE_SEP1") == nullptr;   // the lane = channel-pair form (default)
     if (sep2 && kind == 1) return launch_tile_sep2<64, 4, false>(p, num_cus, s);
     if (sep2 && kind == 2) return launch_tile_sep2<128, 4, false>(p, num_cus, s);
     switch (kind) {
