@@ -19,30 +19,53 @@ EVAL_NAME = 'tile_predictions_eval.csv'            # experiment.py:690
 VAL_NAME = 'tile_predictions_val_epoch1.csv'       # experiment.py:926, utils.py:216
 
 
+# The column contract as a table (the data of ``biscuit/utils.py:19-53``): consumer name -> Slideflow header
+# suffixes in order of preference.  Every suffix is looked up with an underscore separator first, then with a
+# dash (``utils.py:34-49`` checks ``underscore=True in df.columns``); a missing column falls through to the
+# dash form of the LAST candidate, which is what the reference ends up asking pandas to rename.
+CONTRACT = {
+    'y_true': ('y_true0', 'y_true'),        # utils.py:22-23, fallback utils.py:38-39
+    'y_pred': ('y_pred1',),                 # utils.py:26-27: the class-1 mean over the MC passes
+    'uncertainty': ('uncertainty1',),       # utils.py:19-20: the class-1 standard deviation
+}
+
+
+def _header(name, outcome, underscore=False):
+    return f"{outcome}{'_' if underscore else '-'}{CONTRACT[name][0]}"
+
+
 def uncertainty_header(outcome, underscore=False):
-    return str(outcome) + ('_' if underscore else '-') + 'uncertainty1'
+    return _header('uncertainty', outcome, underscore)
 
 
 def y_true_header(outcome, underscore=False):
-    return str(outcome) + ('_' if underscore else '-') + 'y_true0'
+    return _header('y_true', outcome, underscore)
 
 
 def y_pred_header(outcome, underscore=False):
-    return str(outcome) + ('_' if underscore else '-') + 'y_pred1'
+    return _header('y_pred', outcome, underscore)
+
+
+def resolve_cols(columns, outcome, **given):
+    """{header present in ``columns``: consumer name} for the three contract columns; ``given`` overrides a lookup."""
+    have = set(columns)
+    found = {}
+    for name, suffixes in CONTRACT.items():
+        pick = given.get(name)
+        if pick is None:
+            first = suffixes[0]
+            pick = f'{outcome}_{first}' if f'{outcome}_{first}' in have else f'{outcome}-{first}'
+            for alt in suffixes[1:]:                      # only the dash form of a fallback exists in the reference
+                if pick not in have:
+                    pick = f'{outcome}-{alt}'
+        found[pick] = name
+    return found
 
 
 def rename_cols(df, outcome, *, y_true=None, y_pred=None, uncertainty=None):
-    """In-place rename to ``y_true / y_pred / uncertainty`` (``utils.py:31-53``): accepts
-    dash or underscore headers and the ``{outcome}-y_true`` fallback."""
-    if y_true is None:
-        y_true = y_true_header(outcome, underscore=(y_true_header(outcome, True) in df.columns))
-        if y_true not in df.columns:
-            y_true = str(outcome) + '-y_true'
-    if y_pred is None:
-        y_pred = y_pred_header(outcome, underscore=(y_pred_header(outcome, True) in df.columns))
-    if uncertainty is None:
-        uncertainty = uncertainty_header(outcome, underscore=(uncertainty_header(outcome, True) in df.columns))
-    df.rename(columns={y_true: 'y_true', y_pred: 'y_pred', uncertainty: 'uncertainty'}, inplace=True)
+    """In-place rename to ``y_true / y_pred / uncertainty``; same accepted headers and the same result as
+    ``biscuit/utils.py:31-53`` (a header that is absent is simply not renamed, as with ``DataFrame.rename``)."""
+    df.rename(columns=resolve_cols(df.columns, outcome, y_true=y_true, y_pred=y_pred, uncertainty=uncertainty), inplace=True)
 
 
 def tile_frame(outcome, slides, y_true, mean2, std2, loc=None):
