@@ -20,6 +20,7 @@ struct Blob { const unsigned char* p = nullptr; size_t n = 0; };
 struct GemmLayer {
     std::string name;
     const void* wp = nullptr;
+    const void* wp16 = nullptr;   // the same weights in 16x16x32 fragment order (728-wide 19x19 layers, kernels_wide.hip)
     const float* scale = nullptr;
     const float* bias = nullptr;
     const float* dw = nullptr;
@@ -250,6 +251,16 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
         const int e = launch_gemm_tile(p, s);
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(gemm_tile) ") + a.layer + ": " +
+                                                   hipGetErrorString((hipError_t)e));
+        return BQ_OK;
+    }
+    static const bool no_wide = bq_exp_env("BQ_NO_WIDE") != nullptr;
+    if (!no_wide && nsplit == 1 && L.wp16 && a.H == a.Hi && a.W == a.Wi &&
+        wide_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, a.ldo, a.ldi, a.ldo) && p.M % (a.H * a.W) == 0) {
+        p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
+        p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
+        const int e = launch_sepconv_wide(a.prod, p, L.wp16, s);
+        if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(wide) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;
     }
@@ -490,6 +501,12 @@ int register_gemm_layer(bq_ctx* c, const std::string& name, int cin, int cout, i
     L.nfp = (int)(w->second.n / per_nf);
     if (L.nfp * 32 < cout) return fail(c, BQ_ERR_WEIGHTS, "too few output fragments in " + name);
     L.wp = w->second.p;
+    auto w16 = c->entries.find(name + "/wp16");
+    if (w16 != c->entries.end()) {
+        if (w16->second.n != (size_t)(kpad / 32) * ((size_t)L.nfp * 2) * 1024)
+            return fail(c, BQ_ERR_WEIGHTS, "bad size for " + name + "/wp16");
+        L.wp16 = w16->second.p;
+    }
     L.scale = entry_f32(c, name + "/scale");
     L.bias = entry_f32(c, name + "/bias");
     if (!L.scale || !L.bias) return fail(c, BQ_ERR_WEIGHTS, "missing scale/bias for " + name);

@@ -1,0 +1,535 @@
+// SeparableConv2D 728 -> 728 on 19x19 maps (25 of the 34 separable convolutions, ~75 % of the network's FLOPs), bf16.
+//
+// One workgroup = 8 waves (two per SIMD, 256 registers each): it owns an image-aligned tile of 4 map rows (76 pixels,
+// padded to 80 MFMA rows; the 5th tile of an image has 3 rows: 1 280 tiles per batch of 256 = five whole rounds of the
+// 256 CUs) and ALL 768 (padded) output channels; wave w keeps the 80 x 96 fp32 accumulator block of channels
+// [96w, 96w+96) in the accumulator file for the whole kernel: 5 x 6 tiles of v_mfma_f32_16x16x32_bf16 = 120 registers.
+// The contraction is walked in 64-channel chunks, one workgroup barrier per chunk, and inside a chunk EVERY wave runs
+// one instruction stream that carries all three stages, interleaved instruction by instruction (a wave issues in
+// order: five MFMAs in a row hold it for 80 cycles with the vector ALU idle, 25 vector instructions in a row leave the
+// matrix pipe idle for 100), and the SIMD's second wave fills what one stream leaves open:
+//     G(c)    60 MFMAs: A fragments from the LDS chunk buffer, B fragments (weights, host-packed in 16x16x32
+//             fragment order) reloaded for the next k-step as soon as its 5 MFMAs are issued
+//     D(c+1)  the depthwise 3x3 of the NEXT chunk on the vector ALU: lane = (channel pair, run of 6 slots of the
+//             zero-padded halo image), a 3x3 sliding window in registers, per slot 3 ds_read_b32 + 6 unpack +
+//             18 v_fma_f32 + 1 v_cvt_pk_bf16_f32 + 1 ds_write_b32 -- no per-tap masks (the halo image in LDS has
+//             zero columns left and right of every row and zero rows outside the map), no packed-f32 arithmetic
+//     L(c+2)  the halo image of chunk c+2 by LDS-DMA (global_load_lds_dwordx4: no registers, no staging pass)
+// which is what the round-1 kernel (8 waves, 2 per SIMD, stage D and stage G back to back in every wave) could not
+// do: there the vector ALU work of one wave was NOT issued into the shadow of its SIMD partner's MFMAs, and the
+// depthwise stage cost 14 vector instructions per MFMA-equivalent; here it is under 5.
+// Tap order and fp32 accumulation of the depthwise stage are those of every other producer in this library.
+#include "gemm_common.h"
+
+#include <stdio.h>
+
+#include <type_traits>
+#include <vector>
+
+#ifndef WIDE_ABLATE
+#define WIDE_ABLATE 0
+#endif
+
+namespace {
+using namespace bqk;
+
+constexpr int KP = 736;                 // padded input channels (46 k-blocks of 16)
+constexpr int KST = KP / 32;             // 23 k-steps of 32 (one v_mfma_f32_16x16x32_bf16 deep)
+constexpr int KC = 64;                  // channels per chunk
+constexpr int NCH = (KP + KC - 1) / KC; // 12 chunks: 11 whole ones and one of 32 channels
+constexpr int IW = 19, IH = 19;         // map size
+constexpr int TR = 4;                   // map rows per tile
+constexpr int TPI = (IH + TR - 1) / TR; // tiles per image (5)
+constexpr int PW = IW + 2;              // slots per row of the padded halo image
+constexpr int NSLOT = (TR + 2) * PW;    // 126 slots of 128 B (64 channels of one pixel)
+constexpr int NDMA = 16;                // LDS-DMA instructions (1 KiB each) that cover the halo image: 2 per wave
+constexpr int RAW_BYTES = NDMA * 1024;
+constexpr int MT = 80;                  // MFMA rows per tile
+constexpr int A_STR = KC * 2 + 32;      // 160 B = 10 slots of 16 B: the 16x16x32 fragment read (lane -> row l&15, 16-byte
+                                        // k-group l>>4) is conflict-free for ds_read_b128's lane groups iff slots/row = 2 (mod 4)
+constexpr int A_BYTES = (MT + 1) * A_STR;   // row 80 takes the results of pad slots
+constexpr int NSTEP = 6;                // slots per lane: 16 lane groups x 6 >= 4 x 21 centre slots
+constexpr int WN = 8, RN = 6, MF = 5;   // waves, 16-wide n-fragments per wave, 16-row m-fragments
+constexpr int NFT = WN * RN;            // 48 n-fragments of 16 output channels
+constexpr int CPW = RN * 16;            // 96 output channels per wave
+
+// LDS map.  Loop buffers first, the folded-BN table at the very top; the epilogue's staging tile (per wave 80 rows of
+// its 192 channels) aliases the loop buffers.
+constexpr int OFF_RAW = 0;
+constexpr int OFF_A = OFF_RAW + 2 * RAW_BYTES;
+constexpr int OFF_TAPS = OFF_A + 2 * A_BYTES;
+constexpr int TAPS_BYTES = 9 * KP * 4;
+constexpr int LOOP_END = OFF_TAPS + TAPS_BYTES;
+constexpr int STG_ROW = CPW * 2 + 16;    // 13 pieces of 16 B: odd
+constexpr int STG_PPR = STG_ROW / 16;
+constexpr int STG_WAVE = MT * STG_ROW;  // 16 640 B
+constexpr int NRES = (MT * STG_PPR + 63) / 64;   // LDS-DMA instructions per wave for its residual slice (17)
+constexpr int SB_BYTES = 2 * 768 * 4;
+constexpr int LDS_TOTAL = 160 * 1024;
+constexpr int OFF_SB = LDS_TOTAL - SB_BYTES;
+static_assert(LOOP_END <= OFF_SB && WN * STG_WAVE <= OFF_SB, "LDS budget");
+static_assert(2 * WN * NSTEP >= TR * PW, "lane groups do not cover the centre slots");
+static_assert(NDMA * 1024 >= NSLOT * 128 && NDMA == 2 * WN, "halo DMA cover");
+
+struct WideParams {
+    const bf16_t* in;       // [n*361][736]
+    const uint4* wp;        // pointwise weights in 16x16x32 fragment order [23 k-steps][48][64] x 16 B
+    const float* dw;        // [9][736] depthwise taps
+    const float* scale;     // [768] folded BN
+    const float* bias;      // [768]
+    const bf16_t* residual; // [n*361][736] or null
+    bf16_t* out;            // [n*361][736]
+    int n;                  // images
+    int relu;               // ReLU in the epilogue
+#ifdef BQ_EXPERIMENTS
+    unsigned long long* stamps;   // s_memtime stamps [64 blocks from stamp_b0][wave][32] (diagnostic builds only)
+    unsigned stamp_b0;
+#endif
+};
+
+#ifdef BQ_EXPERIMENTS
+#define WSTAMP(ev) do { if (stp) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(ev) do { } while (0)
+#endif
+
+// One LDS-DMA instruction: lanes in `mask` copy 16 bytes each from sbase + voff to LDS at lds_dst + 16*lane.
+// Inline asm on purpose: a DMA the compiler can see makes it wait vmcnt(0) in front of every later LDS read.
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst, unsigned long long mask) {
+    unsigned long long keep_exec;
+    unsigned keep_m0;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_mov_b32 %1, m0\n\t"
+        "s_and_b64 exec, exec, %5\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(keep_exec), "=&s"(keep_m0)
+        : "s"(sbase), "v"(voff), "s"(lds_dst), "s"(mask)
+        : "memory", "scc");
+}
+
+__device__ __forceinline__ unsigned relu2(unsigned x) {      // ReLU on two packed bf16: signed 16-bit max with 0
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), z));
+}
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// ---- the depthwise stage as a list of micro-operations ---------------------------------------------------------------
+// A wave is ONE in-order instruction stream: five MFMAs back to back hold it for 80 cycles with the vector ALU idle, and
+// 25 vector instructions in a row leave the matrix pipe idle for 100.  So the stage is cut into micro-operations of two
+// vector instructions (or three LDS reads) and the K loop issues them BETWEEN consecutive MFMAs, 1.5 per MFMA.
+// Micro-operations of one chunk, in issue order (NOPS of them):
+//     0..2            taps: 3 x 3 ds_read_b64
+//     3, 4, 5         packed dwords of window columns -1, 0, +1 (3 ds_read_b32 each)
+//     6, 7            unpack columns -1, 0
+//     8 + 16 s + k    step s = 0..10 (one slot of the padded halo image):
+//                       k = 0..2    dword of column s+2, row k        (consumed by step s+1)
+//                       k = 3..5    unpack row k-3 of column s+1
+//                       k = 6..14   tap t = k-6 (row t/3, column t%3): two v_fma_f32, accumulation from zero in the
+//                                   tap order of every other depthwise producer of this library
+//                       k = 15      v_cvt_pk_bf16_f32 + ds_write_b32 into the A chunk
+constexpr int NPRIME = 8;
+constexpr int NOPS = NPRIME + 16 * NSTEP;
+
+struct DwState {
+    float2 tw[9];
+    float c[3][3][2];       // [window column slot][row][channel of the pair]; column j of the lane's run lives in slot (j+1) % 3
+    unsigned d[2][3];       // dwords of the column being brought in: column j in d[j & 1]
+    unsigned x[2][3];       // dwords of columns -1 and 0 (prime only)
+    float o0, o1;
+};
+
+template <bool RELU>
+__device__ __forceinline__ void unpack2(unsigned d, float& lo, float& hi) {
+    if (RELU) d = relu2(d);
+    lo = __uint_as_float(d << 16);
+    hi = __uint_as_float(d & 0xffff0000u);
+}
+
+__device__ __forceinline__ unsigned raw_dword(const unsigned char* smem, int raw_addr, int j, int r) {
+    return *reinterpret_cast<const unsigned*>(smem + raw_addr + ((j + 1) + r * PW) * 128);
+}
+
+template <bool RELU, int M>
+__device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, int a_off,
+                                      const int (&aw)[NSTEP]) {
+    if constexpr (M < 3) {
+#pragma unroll
+        for (int t = 3 * M; t < 3 * M + 3; ++t) st.tw[t] = *reinterpret_cast<const float2*>(smem + tap_addr + t * KP * 4);
+    } else if constexpr (M < 5) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) st.x[M - 3][r] = raw_dword(smem, raw_addr, M - 4, r);
+    } else if constexpr (M == 5) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) st.d[1][r] = raw_dword(smem, raw_addr, 1, r);
+    } else if constexpr (M < NPRIME) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) unpack2<RELU>(st.x[M - 6][r], st.c[M - 6][r][0], st.c[M - 6][r][1]);
+    } else {
+        constexpr int S = (M - NPRIME) / 16, K = (M - NPRIME) % 16;
+        if constexpr (K < 3) {
+            if constexpr (S + 1 < NSTEP) st.d[S & 1][K] = raw_dword(smem, raw_addr, S + 2, K);
+        } else if constexpr (K < 6) {
+            unpack2<RELU>(st.d[(S + 1) & 1][K - 3], st.c[(S + 2) % 3][K - 3][0], st.c[(S + 2) % 3][K - 3][1]);
+        } else if constexpr (K < 15) {
+            constexpr int T = K - 6, R = T / 3, DX = T % 3;
+            st.o0 = fmaf(st.tw[T].x, st.c[(S + DX) % 3][R][0], T == 0 ? 0.f : st.o0);
+            st.o1 = fmaf(st.tw[T].y, st.c[(S + DX) % 3][R][1], T == 0 ? 0.f : st.o1);
+        } else {
+            unsigned pk;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(st.o0), "v"(st.o1));
+            *reinterpret_cast<unsigned*>(smem + a_off + aw[S]) = pk;
+        }
+    }
+}
+
+template <bool RELU, int LO, int HI>
+__device__ __forceinline__ void dw_ops(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, int a_off,
+                                       const int (&aw)[NSTEP]) {
+    if constexpr (LO < HI) {
+        dw_op<RELU, LO>(st, smem, raw_addr, tap_addr, a_off, aw);
+        dw_ops<RELU, LO + 1, HI>(st, smem, raw_addr, tap_addr, a_off, aw);
+    }
+}
+
+// Micro-operations issued before MFMA slot q of a chunk (NSLOTQ = 60 MFMAs per wave): the prime loads go out with the
+// first MFMAs, their unpacking waits a few slots (an LDS round trip), the steps are spread evenly over the rest.
+constexpr int NSLOTQ = 2 * MF * RN;
+constexpr int ops_before(int q) {
+    if (q <= 0) return 0;
+    if (q < 4) return 2 * q > 6 ? 6 : 2 * q;
+    if (q < 8) return 6;
+    if (q < 10) return 6 + (q - 7);
+    const int done = NPRIME + ((q - 9) * (NOPS - NPRIME) + (NSLOTQ - 11)) / (NSLOTQ - 10);
+    return done > NOPS ? NOPS : done;
+}
+static_assert(ops_before(NSLOTQ) == NOPS && ops_before(9) == NPRIME, "depthwise schedule");
+
+// The MFMA as inline asm with the accumulator tied in place in the accumulator file ("+a"): written through the builtin,
+// hipcc gives every v_mfma_f32_16x16x32_bf16 of this loop a destination other than its C operand and pays for it with
+// ~450 v_accvgpr_read/write/mov per chunk pair.  `volatile` keeps the MFMAs in source order, which IS the schedule (the
+// micro-operations above are written between them).  What hipcc then no longer does for us (it cannot see an MFMA in
+// the string): (1) the wait states between the last MFMAs and the epilogue's first accumulator read -- explicit s_nops
+// after the loop; (2) the wait states between a VALU write of an A/B operand register and the MFMA reading it -- the
+// operands here come straight from ds_read / global_load, and `make` runs check_wide.py over the generated assembly
+// to prove that no VALU instruction writes an operand within two instructions of its MFMA.
+__device__ __forceinline__ void mfma16(f32x4v& acc, const uint4& b, const uint4& a) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                 : "+a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
+}
+
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (LO < HI) {
+        f(std::integral_constant<int, LO>{});
+        static_for<LO + 1, HI>(f);
+    }
+}
+
+template <bool RELU>
+__global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int img = tile / TPI, part = tile - img * TPI;
+    const int r0 = part * TR;                                   // first map row of the tile
+    const int npix = (IH - r0 < TR ? IH - r0 : TR) * IW;        // valid output pixels (76 or 57)
+    const int m0 = img * (IH * IW) + r0 * IW;                   // their first global pixel index
+
+#ifdef BQ_EXPERIMENTS
+    unsigned long long* stp = (p.stamps && blockIdx.x >= p.stamp_b0 && blockIdx.x < p.stamp_b0 + 64 && lane == 0)
+                                  ? p.stamps + ((blockIdx.x - p.stamp_b0) * WN + wave) * 32 : nullptr;
+#endif
+    WSTAMP(0);
+    // ---- per-lane constants -------------------------------------------------------------------------------
+    // halo DMA: instruction j = wave + 8t covers pieces [64j, 64j+64) of the padded image (piece = slot*8 + 16-byte part)
+    unsigned halo_off[2];
+    unsigned long long halo_mask[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int P = (wave + WN * t) * 64 + lane;
+        const int slot = P >> 3, piece = P & 7;
+        const int sy = slot / PW, sx = slot - sy * PW;
+        const int row = r0 + sy - 1, x = sx - 1;
+        const bool ok = slot < NSLOT && (unsigned)x < (unsigned)IW && (unsigned)row < (unsigned)IH;
+        halo_off[t] = ok ? (unsigned)(((img * IH + row) * IW + x) * KP + piece * 8) * 2u : 0u;
+        halo_mask[t] = __builtin_amdgcn_ballot_w64(ok);
+    }
+    const unsigned long long tail_lanes = 0x0F0F0F0F0F0F0F0Full;    // pieces 0..3: the 32 channels of the last chunk
+
+    // depthwise: channel pair cp, lane group grp (0..15) -> centre slots [PW + 6 grp, PW + 6 grp + 6)
+    const int cp = lane & 31;
+    const int grp = wave * 2 + (lane >> 5);
+    const int s0 = PW + NSTEP * grp;
+    const int raw_lane = (s0 - 1 - PW) * 128 + cp * 4;          // column -1, row -1 of the lane's window
+    int aw[NSTEP];                                              // A-chunk address of each step's result
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int slot = s0 + s;
+        const int sy = slot / PW, sx = slot - sy * PW;
+        const bool ok = sy >= 1 && sy <= TR && sx >= 1 && sx <= IW;
+        aw[s] = (ok ? (sy - 1) * IW + (sx - 1) : MT) * A_STR + cp * 4;
+    }
+    const int tap_lane = OFF_TAPS + cp * 8;
+
+    // matrix stage: lane -> (row l&15 of a 16-row fragment, 16-byte k-group l>>4)
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nfb = wave * RN;
+    // weights [k-step][48 n-fragments][64 lanes] x 16 B: a wave's 6 fragments of one k-step are 6 KiB in a row;
+    // uniform base per k-step + two per-lane offsets (the immediate reaches 4 KiB)
+    const unsigned char* __restrict__ wbase = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)nfb * 1024;
+    unsigned voff[(RN + 3) / 4];
+#pragma unroll
+    for (int g = 0; g < (RN + 3) / 4; ++g) voff[g] = lane * 16 + g * 4096;
+    auto load_b = [&](int ks, int j) {
+        return *reinterpret_cast<const uint4*>(wbase + (size_t)ks * (NFT * 1024) + voff[j >> 2] + (j & 3) * 1024);
+    };
+    const int a_lane = r16 * A_STR + kg * 16;
+
+    // ---- prologue: every load the first stages need goes out before anything waits ---------------------------
+    const unsigned char* inb = reinterpret_cast<const unsigned char*>(p.in);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dma16(inb, halo_off[t], lds0 + OFF_RAW + (wave + WN * t) * 1024, halo_mask[t]);
+    {   // depthwise taps (26 496 B) and folded BN (2 x 3 072 B): plain copies, wave w takes instructions w, w+8, ...
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = wave + WN * t;
+            const int byte = j * 1024 + lane * 16;
+            dma16(p.dw, (unsigned)byte, lds0 + OFF_TAPS + j * 1024, __builtin_amdgcn_ballot_w64(byte < TAPS_BYTES));
+        }
+        const int k3 = wave < 3 ? wave : wave - 3;              // waves 0..2: 1 KiB of scale each, waves 3..5: of bias
+        dma16(wave < 3 ? p.scale : p.bias, (unsigned)(k3 * 1024 + lane * 16), lds0 + OFF_SB + (wave < 3 ? 0 : 3072) + k3 * 1024,
+              __builtin_amdgcn_ballot_w64(wave < 6));
+    }
+    uint4 bq[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) bq[j] = load_b(0, j);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        dma16(inb + KC * 2, halo_off[t], lds0 + OFF_RAW + RAW_BYTES + (wave + WN * t) * 1024, halo_mask[t]);
+    // zero the slots the DMA never writes (pad columns, rows outside the map) in both halo buffers
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int P = t * 512 + tid;
+        const int slot = P >> 3;
+        const int sy = slot / PW, sx = slot - sy * PW;
+        const int row = r0 + sy - 1, x = sx - 1;
+        const bool ok = slot < NSLOT && (unsigned)x < (unsigned)IW && (unsigned)row < (unsigned)IH;
+        if (!ok) {
+            *reinterpret_cast<uint4*>(smem + OFF_RAW + P * 16) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(smem + OFF_RAW + RAW_BYTES + P * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    f32x4v acc[MF][RN];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    WSTAMP(1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // all but the two DMAs of halo chunk 1 have landed
+    WSTAMP(2);
+    __syncthreads();
+    WSTAMP(3);
+    {   // D(0): the first A chunk, nothing to overlap it with
+        DwState st;
+        dw_ops<RELU, 0, NOPS>(st, smem, OFF_RAW + raw_lane, tap_lane, OFF_A, aw);
+    }
+    WSTAMP(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // halo chunk 1
+    __syncthreads();
+    WSTAMP(5);
+
+    // ---- K loop ------------------------------------------------------------------------------------------------
+    // iteration c: G(c) on A[c & 1], D(c+1) from raw[(c+1) & 1] into A[(c+1) & 1], DMA of halo chunk c+2 into raw[c & 1]
+    auto chunk = [&](auto cur_c, auto ksc_c, auto do_d_c, int c) {
+        constexpr int CUR = decltype(cur_c)::value;             // c & 1
+        constexpr int KSC = decltype(ksc_c)::value;             // k-steps of chunk c (2, or 1 for the last)
+        constexpr bool DO_D = decltype(do_d_c)::value;
+        constexpr int NXT = CUR ^ 1;
+        if (c + 2 < NCH) {
+            const unsigned long long tl = c + 2 == NCH - 1 ? tail_lanes : ~0ull;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                dma16(inb + (c + 2) * (KC * 2), halo_off[t], lds0 + OFF_RAW + CUR * RAW_BYTES + (wave + WN * t) * 1024,
+                      halo_mask[t] & tl);
+        }
+        const int a_cur = OFF_A + CUR * A_BYTES + a_lane;
+        const int raw_addr = OFF_RAW + NXT * RAW_BYTES + raw_lane;
+        const int a_nxt = OFF_A + NXT * A_BYTES;
+        // taps of chunk c+1; the last chunk has 32 channels: pairs 16..31 read a clamped (valid, unused) address
+        const int tap_addr = ((c + 1 == NCH - 1 && cp >= 16) ? tap_lane - 128 : tap_lane) + (c + 1) * (KC * 4);
+        DwState st;
+        uint4 a[MF];
+        const int ks0 = c * (KC / 32);
+        static_for<0, KSC * MF * RN>([&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            constexpr int D = Q / (MF * RN), J = (Q % (MF * RN)) / MF, I = Q % MF;
+            if constexpr (Q % (MF * RN) == 0) {                 // A fragments of this k-step
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+                    a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR + D * 64);
+            }
+#if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
+            if constexpr (DO_D) dw_ops<RELU, ops_before(Q), ops_before(Q + 1)>(st, smem, raw_addr, tap_addr, a_nxt, aw);
+#endif
+#if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
+            mfma16(acc[I][J], bq[J], a[I]);
+#endif
+#if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 1))          // 1 = weights stay in registers
+            if constexpr (I == MF - 1) {                        // the fragment is dead: fetch it for the next k-step
+                const int nx = ks0 + D + 1;
+                bq[J] = load_b(nx < KST ? nx : KST - 1, J);     // branch-free: past the end re-load a valid, unused step
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);                  // the source order of this loop IS the schedule
+        });
+        WSTAMP(6 + c);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RN) : "memory");
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K1 = std::integral_constant<int, 1>;
+    for (int c = 0; c < NCH - 2; c += 2) {
+        chunk(I0{}, K2{}, std::true_type{}, c);
+        chunk(I1{}, K2{}, std::true_type{}, c + 1);
+    }
+    chunk(I0{}, K2{}, std::true_type{}, NCH - 2);
+    chunk(I1{}, K1{}, std::false_type{}, NCH - 1);
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs have written their accumulators (see mfma16)
+    // ---- epilogue: folded BN (+ residual) (+ ReLU), bf16, whole 384-byte row pieces to HBM ----------------------
+    // per wave a private staging tile of 80 rows x 192 channels (the loop's buffers are free: every wave is past the
+    // closing barrier); the residual tile is copied into it by LDS-DMA, every lane adds its accumulator crumbs in
+    // place, then the wave streams the rows out
+    const int ch0 = wave * CPW;
+    const unsigned char* resb = reinterpret_cast<const unsigned char*>(p.residual);
+    const bool has_res = p.residual != nullptr;
+    const int stg_off = wave * STG_WAVE;
+    if (has_res) {
+        // instruction j covers pieces [64j, 64j+64); piece P = row * 13 + col, col 12 is padding
+        int row = lane / STG_PPR, col = lane - (lane / STG_PPR) * STG_PPR;
+#pragma unroll
+        for (int j = 0; j < NRES; ++j) {
+            const bool ok = col < STG_PPR - 1 && ch0 + col * 8 < KP && row < npix;
+            const unsigned off = ok ? (unsigned)((m0 + row) * KP + ch0 + col * 8) * 2u : 0u;
+            dma16(resb, off, lds0 + stg_off + j * 1024, __builtin_amdgcn_ballot_w64(ok));
+            col += 64 - 4 * STG_PPR; row += 4;
+            if (col >= STG_PPR) { col -= STG_PPR; row += 1; }
+        }
+        WSTAMP(19);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    WSTAMP(20);
+    const float* sb = reinterpret_cast<const float*>(smem + OFF_SB);
+    const unsigned lo2 = p.relu ? 0u : 0x80008000u;             // packed int16 max with 0 = ReLU, with -32768 = no-op
+    unsigned char* outb = reinterpret_cast<unsigned char*>(p.out);
+    unsigned char* stg = smem + stg_off;
+    float4 sc[RN], bi[RN];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {                               // 4 consecutive channels per lane and n-fragment
+        sc[j] = *reinterpret_cast<const float4*>(sb + ch0 + j * 16 + kg * 4);
+        bi[j] = *reinterpret_cast<const float4*>(sb + 768 + ch0 + j * 16 + kg * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        unsigned char* rowp = stg + (i * 16 + r16) * STG_ROW + kg * 8;
+        uint2 u[RN];
+        if (has_res) {                                          // all reads of a row before its writes: one LDS round trip
+#pragma unroll
+            for (int j = 0; j < RN; ++j) u[j] = *reinterpret_cast<const uint2*>(rowp + j * 32);
+        }
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            float v0 = fmaf(acc[i][j][0], sc[j].x, bi[j].x);
+            float v1 = fmaf(acc[i][j][1], sc[j].y, bi[j].y);
+            float v2 = fmaf(acc[i][j][2], sc[j].z, bi[j].z);
+            float v3 = fmaf(acc[i][j][3], sc[j].w, bi[j].w);
+            if (has_res) {
+                v0 += __uint_as_float(u[j].x << 16); v1 += __uint_as_float(u[j].x & 0xffff0000u);
+                v2 += __uint_as_float(u[j].y << 16); v3 += __uint_as_float(u[j].y & 0xffff0000u);
+            }
+            uint2 o;
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
+            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+            asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
+            asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
+            *reinterpret_cast<uint2*>(rowp + j * 32) = o;
+        }
+    }
+    WSTAMP(21);
+    // rows out: 80 rows x 12 pieces of 16 B, 15 per lane; a row's 192 bytes are contiguous in HBM
+    {
+        int row = lane / 12, col = lane - (lane / 12) * 12;
+#pragma unroll 5
+        for (int t = 0; t < MT * 12 / 64; ++t) {
+            if (row < npix && ch0 + col * 8 < KP)
+                *reinterpret_cast<uint4*>(outb + ((size_t)(m0 + row) * KP + ch0 + col * 8) * 2) =
+                    *reinterpret_cast<const uint4*>(stg + row * STG_ROW + col * 16);
+            col += 4; row += 5;                                   // 64 = 5 * 12 + 4
+            if (col >= 12) { col -= 12; row += 1; }
+        }
+    }
+    WSTAMP(22);
+}
+
+}  // namespace
+
+bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo) {
+    return dtype == 1 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == IH && W == IW && K == KP &&
+           Nstore == KP && ldi == KP && ldo == KP;
+}
+
+// wp16: the layer's pointwise weights in 16x16x32 fragment order (blob entry "<layer>/wp16")
+int launch_sepconv_wide(int prod, const GemmParams& g, const void* wp16, hipStream_t s) {
+    if (g.M % (IH * IW) != 0 || g.k_off != 0 || !g.scale || !g.bias || !wp16) return (int)hipErrorInvalidValue;
+    WideParams p;
+    p.in = reinterpret_cast<const bf16_t*>(g.in);
+    p.wp = reinterpret_cast<const uint4*>(wp16);
+    p.dw = g.dw; p.scale = g.scale; p.bias = g.bias;
+    p.residual = reinterpret_cast<const bf16_t*>(g.residual);
+    p.out = reinterpret_cast<bf16_t*>(g.out);
+    p.n = g.M / (IH * IW);
+    p.relu = g.relu;
+    const bool relu_in = prod == PROD_DW_RELU;
+    auto kern = relu_in ? sepconv_wide_kernel<true> : sepconv_wide_kernel<false>;
+    static BqLdsAttr attr[2];
+    if (const int e = attr[relu_in].ensure(reinterpret_cast<const void*>(kern), LDS_TOTAL)) return e;
+#ifdef BQ_EXPERIMENTS
+    // BQ_STAMPS_WIDE=<file>: in-kernel s_memtime stamps of the first launch with (BQ_STAMPS_NORES: without) a residual
+    static const char* stamp_file = bq_exp_env("BQ_STAMPS_WIDE");
+    static const bool want_res = bq_exp_env("BQ_STAMPS_NORES") == nullptr;
+    static int state = 0;
+    static unsigned long long* d_stamps = nullptr;
+    p.stamps = nullptr;
+    p.stamp_b0 = bq_exp_env("BQ_STAMPS_B0") ? (unsigned)atoi(bq_exp_env("BQ_STAMPS_B0")) : 0u;
+    if (stamp_file && state == 0 && (p.residual != nullptr) == want_res && p.n >= 64 &&
+        hipMalloc(&d_stamps, 64 * WN * 32 * 8) == hipSuccess) {
+        (void)hipMemsetAsync(d_stamps, 0, 64 * WN * 32 * 8, s);
+        p.stamps = d_stamps;
+        state = 1;
+    }
+#endif
+    hipLaunchKernelGGL(kern, dim3(p.n * TPI), dim3(64 * WN), LDS_TOTAL, s, p);
+#ifdef BQ_EXPERIMENTS
+    if (state == 1) {
+        std::vector<unsigned long long> h(64 * WN * 32);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stamp_file, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        state = 2;
+    }
+#endif
+    return (int)hipGetLastError();
+}

@@ -220,6 +220,24 @@ def pack_fragments(wkn, kpad, vec):
     return np.ascontiguousarray(t).reshape(nfp, kb, 64, vec)
 
 
+def pack_fragments16(wkn, kpad, npad):
+    """W[K][N] -> v_mfma_f32_16x16x32 fragment order [KS][NF16][64][8] float32 (zero padded): k-step ks, 16-wide
+    n-fragment nf, lane = kg*16 + r holds W[k = ks*32 + kg*8 + v][n = nf*16 + r] in element v.  All fragments of one
+    k-step are contiguous (48 KiB for 768 outputs), so a wave's 12 fragments are one 12 KiB run."""
+    k, n = wkn.shape
+    assert kpad % 32 == 0 and kpad >= k and npad % 16 == 0 and npad >= n
+    full = np.zeros((kpad, npad), np.float32)
+    full[:k, :n] = wkn
+    t = full.reshape(kpad // 32, 4, 8, npad // 16, 16)      # [ks][kg][v][nf][r]
+    t = t.transpose(0, 3, 1, 4, 2)                          # [ks][nf][kg][r][v]
+    return np.ascontiguousarray(t).reshape(kpad // 32, npad // 16, 64, 8)
+
+
+def wide_layers():
+    """The 25 separable convolutions 728 -> 728 on 19x19 maps (blocks 5-12 and block13_sepconv1): kernels_wide.hip."""
+    return [f'block{b}_sepconv{i}' for b in range(5, 13) for i in (1, 2, 3)] + ['block13_sepconv1']
+
+
 def fold_bn(w, name):
     s = w[name + '/gamma'] / np.sqrt(w[name + '/moving_variance'] + np.float32(BN_EPS))
     b = w[name + '/beta'] - w[name + '/moving_mean'] * s
@@ -262,12 +280,15 @@ def pack_blob(w, dtype='bf16'):
         npad = add_mat(name, w[name + '_conv/kernel'].reshape(cin, cout), pad_channels(cin))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)
+    wide = set(wide_layers())
     for name, cin, cout in sepconv_plan():
         cp = pad_channels(cin)
         dw = np.zeros((9, cp), np.float32)
         dw[:, :cin] = w[name + '/depthwise_kernel'].reshape(9, cin)
         add(name + '/dw', dw)
         npad = add_mat(name, w[name + '/pointwise_kernel'].reshape(cin, cout), cp)
+        if dtype == 'bf16' and name in wide and cp % 32 == 0:
+            add(name + '/wp16', f32_to_bf16_bits(pack_fragments16(w[name + '/pointwise_kernel'].reshape(cin, cout), cp, npad)))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)
     # head stays fp32 regardless of the backbone dtype (MC std ~1e-2 must not be
