@@ -10,11 +10,15 @@
 // matrix pipe idle for 100), and the SIMD's second wave fills what one stream leaves open:
 //     G(c)    60 MFMAs: A fragments from the LDS chunk buffer, B fragments (weights, host-packed in 16x16x32
 //             fragment order) reloaded for the next k-step as soon as its 5 MFMAs are issued
-//     D(c+1)  the depthwise 3x3 of the NEXT chunk on the vector ALU: lane = (channel pair, run of 6 slots of the
-//             zero-padded halo image), a 3x3 sliding window in registers, per slot 3 ds_read_b32 + 6 unpack +
-//             18 v_fma_f32 + 1 v_cvt_pk_bf16_f32 + 1 ds_write_b32 -- no per-tap masks (the halo image in LDS has
-//             zero columns left and right of every row and zero rows outside the map), no packed-f32 arithmetic
-//     L(c+2)  the halo image of chunk c+2 by LDS-DMA (global_load_lds_dwordx4: no registers, no staging pass)
+//     D(c+1)  the depthwise 3x3 of the NEXT chunk on the vector ALU: lane = (channel pair, run of 5 pixels of a tile
+//             row), a 3x3 sliding window in registers, per pixel 3 ds_read_b32 + 6 unpack + 18 v_fma_f32 +
+//             1 v_cvt_pk_bf16_f32 + 1 ds_write_b32 -- no per-tap masks (the halo image in LDS has zero columns left
+//             and right of every row and zero rows outside the map), no packed-f32 arithmetic
+//     L(c+2)  the halo image of chunk c+2 by LDS-DMA (global_load_lds_dwordx4: no registers)
+// Measured (stamps, ablation builds): a SIMD issues about one instruction of ANY kind per 4 cycles from its
+// two waves and an MFMA holds the port for 8 of its 16, so a chunk costs ~4 cycles per non-MFMA instruction on top of
+// 8 per MFMA; an fp32 copy of the halo image (no unpacking per use) traded 50 vector for as many LDS instructions and
+// a third pipeline stage, and measured the same.
 // which is what the round-1 kernel (8 waves, 2 per SIMD, stage D and stage G back to back in every wave) could not
 // do: there the vector ALU work of one wave was NOT issued into the shadow of its SIMD partner's MFMAs, and the
 // depthwise stage cost 14 vector instructions per MFMA-equivalent; here it is under 5.
@@ -48,27 +52,32 @@ constexpr int MT = 80;                  // MFMA rows per tile
 constexpr int A_STR = KC * 2 + 32;      // 160 B = 10 slots of 16 B: the 16x16x32 fragment read (lane -> row l&15, 16-byte
                                         // k-group l>>4) is conflict-free for ds_read_b128's lane groups iff slots/row = 2 (mod 4)
 constexpr int A_BYTES = (MT + 1) * A_STR;   // row 80 takes the results of pad slots
-constexpr int NSTEP = 6;                // slots per lane: 16 lane groups x 6 >= 4 x 21 centre slots
+constexpr int NSTEP = 5;                // pixels per lane: 16 lane groups = 4 tile rows x 4 segments of 5 (5, 5, 5, 4) pixels
 constexpr int WN = 8, RN = 6, MF = 5;   // waves, 16-wide n-fragments per wave, 16-row m-fragments
 constexpr int NFT = WN * RN;            // 48 n-fragments of 16 output channels
 constexpr int CPW = RN * 16;            // 96 output channels per wave
 
 // LDS map.  Loop buffers first, the folded-BN table at the very top; the epilogue's staging tile (per wave 80 rows of
 // its 192 channels) aliases the loop buffers.
-constexpr int OFF_RAW = 0;
+constexpr int OFF_RAW = 0;                       // 2 halo images (bf16, as they arrive)
 constexpr int OFF_A = OFF_RAW + 2 * RAW_BYTES;
 constexpr int OFF_TAPS = OFF_A + 2 * A_BYTES;
 constexpr int TAPS_BYTES = 9 * KP * 4;
 constexpr int LOOP_END = OFF_TAPS + TAPS_BYTES;
 constexpr int STG_ROW = CPW * 2 + 16;    // 13 pieces of 16 B: odd
 constexpr int STG_PPR = STG_ROW / 16;
-constexpr int STG_WAVE = MT * STG_ROW;  // 16 640 B
-constexpr int NRES = (MT * STG_PPR + 63) / 64;   // LDS-DMA instructions per wave for its residual slice (17)
+// a wave's staging rows live in two pieces: rows [0, STG_R1) above the loop's buffers (free while the loop runs: the
+// residual tile's first rows are copied there under the loop), rows [STG_R1, 80) over the loop's buffers
+constexpr int STG_R1 = 43;
+constexpr int STG_W1 = STG_R1 * STG_ROW, STG_W2 = (MT - STG_R1) * STG_ROW;
+constexpr int NRES1 = (STG_R1 * STG_PPR + 63) / 64;          // LDS-DMA instructions per wave and piece (9 and 8)
+constexpr int NRES2 = ((MT - STG_R1) * STG_PPR + 63) / 64;
 constexpr int SB_BYTES = 2 * 768 * 4;
 constexpr int LDS_TOTAL = 160 * 1024;
 constexpr int OFF_SB = LDS_TOTAL - SB_BYTES;
-static_assert(LOOP_END <= OFF_SB && WN * STG_WAVE <= OFF_SB, "LDS budget");
-static_assert(2 * WN * NSTEP >= TR * PW, "lane groups do not cover the centre slots");
+constexpr int OFF_STG1 = LOOP_END, OFF_STG2 = 0;
+static_assert(OFF_STG1 + WN * STG_W1 <= OFF_SB && OFF_STG2 + WN * STG_W2 <= LOOP_END, "LDS budget");
+static_assert(4 * NSTEP >= IW && 2 * WN == 4 * TR, "lane groups do not cover the tile");
 static_assert(NDMA * 1024 >= NSLOT * 128 && NDMA == 2 * WN, "halo DMA cover");
 
 struct WideParams {
@@ -120,36 +129,34 @@ __device__ __forceinline__ unsigned relu2(unsigned x) {      // ReLU on two pack
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// ---- the depthwise stage as a list of micro-operations ---------------------------------------------------------------
-// A wave is ONE in-order instruction stream: five MFMAs back to back hold it for 80 cycles with the vector ALU idle, and
-// 25 vector instructions in a row leave the matrix pipe idle for 100.  So the stage is cut into micro-operations of two
-// vector instructions (or three LDS reads) and the K loop issues them BETWEEN consecutive MFMAs, 1.5 per MFMA.
-// Micro-operations of one chunk, in issue order (NOPS of them):
-//     0..2            taps: 3 x 3 ds_read_b64
-//     3, 4, 5         packed dwords of window columns -1, 0, +1 (3 ds_read_b32 each)
-//     6, 7            unpack columns -1, 0
-//     8 + 16 s + k    step s = 0..10 (one slot of the padded halo image):
-//                       k = 0..2    dword of column s+2, row k        (consumed by step s+1)
-//                       k = 3..5    unpack row k-3 of column s+1
-//                       k = 6..14   tap t = k-6 (row t/3, column t%3): two v_fma_f32, accumulation from zero in the
-//                                   tap order of every other depthwise producer of this library
-//                       k = 15      v_cvt_pk_bf16_f32 + ds_write_b32 into the A chunk
-constexpr int NPRIME = 8;
-constexpr int NOPS = NPRIME + 16 * NSTEP;
+// ---- the depthwise stage as a list of micro-operations -----------------------------------------------------------------
+// A wave issues in order, so the stage is cut into micro-operations of two or three vector instructions (or three LDS
+// reads) that the K loop issues BETWEEN consecutive MFMAs.  Per chunk (NDW micro-operations):
+//     0..2              taps: 3 x 3 ds_read_b64
+//     3, 4, 5           packed dwords (the lane's two channels) of window columns -1, 0, +1: 3 ds_read_b32 each
+//     6, 7, 8           unpack them
+//     9 + 14 s + k      pixel s = 0..4 of the lane's run:
+//                         k = 0..6    tap t = k (row t/3, column t%3): two v_fma_f32, accumulation from zero in the
+//                                     tap order of every other depthwise producer of this library
+//                         k = 7       dwords of column s+2 (for pixel s+1)
+//                         k = 8, 9    taps 7, 8
+//                         k = 10      v_cvt_pk_bf16_f32 + ds_write_b32 into the A chunk
+//                         k = 11..13  unpack column s+2, row k-11, into the registers of column s-1 (dead after tap 6)
+constexpr int NPRIME = 9;
+constexpr int NDW = NPRIME + 14 * NSTEP;
 
 struct DwState {
     float2 tw[9];
-    float c[3][3][2];       // [window column slot][row][channel of the pair]; column j of the lane's run lives in slot (j+1) % 3
-    unsigned d[2][3];       // dwords of the column being brought in: column j in d[j & 1]
-    unsigned x[2][3];       // dwords of columns -1 and 0 (prime only)
+    float2 c[3][3];         // [window column slot][row]: column j of the lane's run lives in slot (j + 1) % 3
+    unsigned d[3];          // dwords of the column being brought in
+    unsigned x[2][3];       // dwords of columns -1, 0 (prime only)
     float o0, o1;
 };
 
 template <bool RELU>
-__device__ __forceinline__ void unpack2(unsigned d, float& lo, float& hi) {
+__device__ __forceinline__ float2 unpack2(unsigned d) {
     if (RELU) d = relu2(d);
-    lo = __uint_as_float(d << 16);
-    hi = __uint_as_float(d & 0xffff0000u);
+    return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u));
 }
 
 __device__ __forceinline__ unsigned raw_dword(const unsigned char* smem, int raw_addr, int j, int r) {
@@ -157,8 +164,7 @@ __device__ __forceinline__ unsigned raw_dword(const unsigned char* smem, int raw
 }
 
 template <bool RELU, int M>
-__device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, int a_off,
-                                      const int (&aw)[NSTEP]) {
+__device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[2]) {
     if constexpr (M < 3) {
 #pragma unroll
         for (int t = 3 * M; t < 3 * M + 3; ++t) st.tw[t] = *reinterpret_cast<const float2*>(smem + tap_addr + t * KP * 4);
@@ -167,49 +173,54 @@ __device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_
         for (int r = 0; r < 3; ++r) st.x[M - 3][r] = raw_dword(smem, raw_addr, M - 4, r);
     } else if constexpr (M == 5) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) st.d[1][r] = raw_dword(smem, raw_addr, 1, r);
-    } else if constexpr (M < NPRIME) {
+        for (int r = 0; r < 3; ++r) st.d[r] = raw_dword(smem, raw_addr, 1, r);
+    } else if constexpr (M < 8) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) unpack2<RELU>(st.x[M - 6][r], st.c[M - 6][r][0], st.c[M - 6][r][1]);
+        for (int r = 0; r < 3; ++r) st.c[M - 6][r] = unpack2<RELU>(st.x[M - 6][r]);
+    } else if constexpr (M == 8) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) st.c[2][r] = unpack2<RELU>(st.d[r]);
     } else {
-        constexpr int S = (M - NPRIME) / 16, K = (M - NPRIME) % 16;
-        if constexpr (K < 3) {
-            if constexpr (S + 1 < NSTEP) st.d[S & 1][K] = raw_dword(smem, raw_addr, S + 2, K);
-        } else if constexpr (K < 6) {
-            unpack2<RELU>(st.d[(S + 1) & 1][K - 3], st.c[(S + 2) % 3][K - 3][0], st.c[(S + 2) % 3][K - 3][1]);
-        } else if constexpr (K < 15) {
-            constexpr int T = K - 6, R = T / 3, DX = T % 3;
-            st.o0 = fmaf(st.tw[T].x, st.c[(S + DX) % 3][R][0], T == 0 ? 0.f : st.o0);
-            st.o1 = fmaf(st.tw[T].y, st.c[(S + DX) % 3][R][1], T == 0 ? 0.f : st.o1);
-        } else {
+        constexpr int S = (M - NPRIME) / 14, K = (M - NPRIME) % 14;
+        if constexpr (K == 7) {
+            if constexpr (S + 1 < NSTEP) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) st.d[r] = raw_dword(smem, raw_addr, S + 2, r);
+            }
+        } else if constexpr (K < 10) {
+            constexpr int T = K < 7 ? K : K - 1, R = T / 3, DX = T % 3;
+            st.o0 = fmaf(st.tw[T].x, st.c[(S + DX) % 3][R].x, T == 0 ? 0.f : st.o0);
+            st.o1 = fmaf(st.tw[T].y, st.c[(S + DX) % 3][R].y, T == 0 ? 0.f : st.o1);
+        } else if constexpr (K == 10) {
             unsigned pk;
             asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(st.o0), "v"(st.o1));
-            *reinterpret_cast<unsigned*>(smem + a_off + aw[S]) = pk;
+            *reinterpret_cast<unsigned*>(smem + (S + 1 < NSTEP ? aw[0] + S * A_STR : aw[1])) = pk;
+        } else {
+            if constexpr (S + 1 < NSTEP) st.c[S % 3][K - 11] = unpack2<RELU>(st.d[K - 11]);
         }
     }
 }
 
 template <bool RELU, int LO, int HI>
-__device__ __forceinline__ void dw_ops(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, int a_off,
-                                       const int (&aw)[NSTEP]) {
+__device__ __forceinline__ void dw_ops(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[2]) {
     if constexpr (LO < HI) {
-        dw_op<RELU, LO>(st, smem, raw_addr, tap_addr, a_off, aw);
-        dw_ops<RELU, LO + 1, HI>(st, smem, raw_addr, tap_addr, a_off, aw);
+        dw_op<RELU, LO>(st, smem, raw_addr, tap_addr, aw);
+        dw_ops<RELU, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
     }
 }
 
-// Micro-operations issued before MFMA slot q of a chunk (NSLOTQ = 60 MFMAs per wave): the prime loads go out with the
-// first MFMAs, their unpacking waits a few slots (an LDS round trip), the steps are spread evenly over the rest.
+// Micro-operations issued before MFMA slot q of a chunk (NSLOTQ = 60 MFMAs per wave): the taps and the first columns go
+// out with the first MFMAs, their unpacking waits a few slots (an LDS round trip), the pixels are spread over the rest.
 constexpr int NSLOTQ = 2 * MF * RN;
-constexpr int ops_before(int q) {
+constexpr int dw_before(int q) {
     if (q <= 0) return 0;
     if (q < 4) return 2 * q > 6 ? 6 : 2 * q;
-    if (q < 8) return 6;
-    if (q < 10) return 6 + (q - 7);
-    const int done = NPRIME + ((q - 9) * (NOPS - NPRIME) + (NSLOTQ - 11)) / (NSLOTQ - 10);
-    return done > NOPS ? NOPS : done;
+    if (q < 7) return 6;
+    if (q < 9) return 6 + 2 * (q - 6) > NPRIME ? NPRIME : 6 + 2 * (q - 6);
+    const int done = NPRIME + ((q - 8) * (NDW - NPRIME) + (NSLOTQ - 10)) / (NSLOTQ - 9);
+    return done > NDW ? NDW : done;
 }
-static_assert(ops_before(NSLOTQ) == NOPS && ops_before(9) == NPRIME, "depthwise schedule");
+static_assert(dw_before(NSLOTQ) == NDW && dw_before(8) == NPRIME, "micro-operation schedule");
 
 // The MFMA as inline asm with the accumulator tied in place in the accumulator file ("+a"): written through the builtin,
 // hipcc gives every v_mfma_f32_16x16x32_bf16 of this loop a destination other than its C operand and pays for it with
@@ -223,6 +234,13 @@ __device__ __forceinline__ void mfma16(f32x4v& acc, const uint4& b, const uint4&
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
                  : "+a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
+}
+
+// An LDS base address the compiler must take as it is: offsets beyond the 16-bit immediate of ds_* would otherwise be
+// re-associated into one base register per distinct offset (a dozen registers this kernel does not have).
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
 
 template <int LO, int HI, typename F>
@@ -268,32 +286,25 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     }
     const unsigned long long tail_lanes = 0x0F0F0F0F0F0F0F0Full;    // pieces 0..3: the 32 channels of the last chunk
 
-    // depthwise: channel pair cp, lane group grp (0..15) -> centre slots [PW + 6 grp, PW + 6 grp + 6)
+    // depthwise: channel pair cp, lane group grp (0..15) = tile row grp >> 2, pixels [5 (grp & 3), 5 (grp & 3) + 5) of it
     const int cp = lane & 31;
     const int grp = wave * 2 + (lane >> 5);
-    const int s0 = PW + NSTEP * grp;
-    const int raw_lane = (s0 - 1 - PW) * 128 + cp * 4;          // column -1, row -1 of the lane's window
-    int aw[NSTEP];                                              // A-chunk address of each step's result
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-        const int slot = s0 + s;
-        const int sy = slot / PW, sx = slot - sy * PW;
-        const bool ok = sy >= 1 && sy <= TR && sx >= 1 && sx <= IW;
-        aw[s] = (ok ? (sy - 1) * IW + (sx - 1) : MT) * A_STR + cp * 4;
-    }
+    const int drow = grp >> 2, dx0 = (grp & 3) * NSTEP;
+    const int raw_lane = (drow * PW + dx0) * 128 + cp * 4;      // slot (row - 1, x0 - 1) of the padded image: column -1, row -1
+    // A-chunk address of the run's first pixel (the next three follow at A_STR) and of its fifth, which the last
+    // segment of a row does not have (row 80 of the chunk takes the result)
+    const int aw[2] = {(drow * IW + dx0) * A_STR + cp * 4, (dx0 + 4 < IW ? drow * IW + dx0 + 4 : MT) * A_STR + cp * 4};
     const int tap_lane = OFF_TAPS + cp * 8;
 
     // matrix stage: lane -> (row l&15 of a 16-row fragment, 16-byte k-group l>>4)
     const int r16 = lane & 15, kg = lane >> 4;
     const int nfb = wave * RN;
     // weights [k-step][48 n-fragments][64 lanes] x 16 B: a wave's 6 fragments of one k-step are 6 KiB in a row;
-    // uniform base per k-step + two per-lane offsets (the immediate reaches 4 KiB)
+    // uniform base per k-step and 4 KiB (the immediate reaches 4 KiB) + one per-lane offset
     const unsigned char* __restrict__ wbase = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)nfb * 1024;
-    unsigned voff[(RN + 3) / 4];
-#pragma unroll
-    for (int g = 0; g < (RN + 3) / 4; ++g) voff[g] = lane * 16 + g * 4096;
+    const unsigned voff = lane * 16;
     auto load_b = [&](int ks, int j) {
-        return *reinterpret_cast<const uint4*>(wbase + (size_t)ks * (NFT * 1024) + voff[j >> 2] + (j & 3) * 1024);
+        return *reinterpret_cast<const uint4*>(wbase + (size_t)ks * (NFT * 1024) + (j >> 2) * 4096 + voff + (j & 3) * 1024);
     };
     const int a_lane = r16 * A_STR + kg * 16;
 
@@ -344,7 +355,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     WSTAMP(3);
     {   // D(0): the first A chunk, nothing to overlap it with
         DwState st;
-        dw_ops<RELU, 0, NOPS>(st, smem, OFF_RAW + raw_lane, tap_lane, OFF_A, aw);
+        const int aw0[2] = {opaque(OFF_A + aw[0]), opaque(OFF_A + aw[1])};
+        dw_ops<RELU, 0, NDW>(st, smem, OFF_RAW + raw_lane, opaque(tap_lane), aw0);
     }
     WSTAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // halo chunk 1
@@ -353,6 +365,18 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
 
     // ---- K loop ------------------------------------------------------------------------------------------------
     // iteration c: G(c) on A[c & 1], D(c+1) from raw[(c+1) & 1] into A[(c+1) & 1], DMA of halo chunk c+2 into raw[c & 1]
+    // and, in a layer with a residual input, one instruction of its copy into the staging rows above the loop's buffers
+    const int ch0 = wave * CPW;
+    const unsigned char* resb = reinterpret_cast<const unsigned char*>(p.residual);
+    const bool has_res = p.residual != nullptr;
+    // residual DMA, piece 1: instruction j covers linear pieces [64j, 64j+64) of rows [0, STG_R1); P = row * 13 + col, col 12 pads
+    auto res_dma = [&](int j, int row0, int rows, unsigned lds_base) {
+        const int P = j * 64 + lane;
+        const int row = P / STG_PPR, col = P - row * STG_PPR;
+        const bool ok = row < rows && col < STG_PPR - 1 && ch0 + col * 8 < KP && row0 + row < npix;
+        const unsigned off = ok ? (unsigned)((m0 + row0 + row) * KP + ch0 + col * 8) * 2u : 0u;
+        dma16(resb, off, lds_base + j * 1024, __builtin_amdgcn_ballot_w64(ok));
+    };
     auto chunk = [&](auto cur_c, auto ksc_c, auto do_d_c, int c) {
         constexpr int CUR = decltype(cur_c)::value;             // c & 1
         constexpr int KSC = decltype(ksc_c)::value;             // k-steps of chunk c (2, or 1 for the last)
@@ -365,11 +389,12 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                 dma16(inb + (c + 2) * (KC * 2), halo_off[t], lds0 + OFF_RAW + CUR * RAW_BYTES + (wave + WN * t) * 1024,
                       halo_mask[t] & tl);
         }
-        const int a_cur = OFF_A + CUR * A_BYTES + a_lane;
+        if (has_res && c < NRES1) res_dma(c, 0, STG_R1, lds0 + OFF_STG1 + wave * STG_W1);
+        const int a_cur = opaque(OFF_A + CUR * A_BYTES + a_lane);
         const int raw_addr = OFF_RAW + NXT * RAW_BYTES + raw_lane;
-        const int a_nxt = OFF_A + NXT * A_BYTES;
+        const int awn[2] = {opaque(OFF_A + NXT * A_BYTES + aw[0]), opaque(OFF_A + NXT * A_BYTES + aw[1])};
         // taps of chunk c+1; the last chunk has 32 channels: pairs 16..31 read a clamped (valid, unused) address
-        const int tap_addr = ((c + 1 == NCH - 1 && cp >= 16) ? tap_lane - 128 : tap_lane) + (c + 1) * (KC * 4);
+        const int tap_addr = opaque(((c + 1 == NCH - 1 && cp >= 16) ? tap_lane - 128 : tap_lane) + (c + 1) * (KC * 4));
         DwState st;
         uint4 a[MF];
         const int ks0 = c * (KC / 32);
@@ -382,7 +407,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                     a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR + D * 64);
             }
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
-            if constexpr (DO_D) dw_ops<RELU, ops_before(Q), ops_before(Q + 1)>(st, smem, raw_addr, tap_addr, a_nxt, aw);
+            if constexpr (DO_D) dw_ops<RELU, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
             mfma16(acc[I][J], bq[J], a[I]);
@@ -413,38 +438,31 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     // per wave a private staging tile of 80 rows x 192 channels (the loop's buffers are free: every wave is past the
     // closing barrier); the residual tile is copied into it by LDS-DMA, every lane adds its accumulator crumbs in
     // place, then the wave streams the rows out
-    const int ch0 = wave * CPW;
-    const unsigned char* resb = reinterpret_cast<const unsigned char*>(p.residual);
-    const bool has_res = p.residual != nullptr;
-    const int stg_off = wave * STG_WAVE;
+    // per wave a private staging tile of 80 rows x 96 channels in two pieces (see STG_R1); the residual tile's first rows
+    // were copied into piece 1 while the loop ran, the rest is copied into piece 2 now (the loop's buffers are free: every
+    // wave is past the closing barrier) and lands while the first two row fragments are finished
+    const int stg1 = OFF_STG1 + wave * STG_W1, stg2 = OFF_STG2 + wave * STG_W2;
     if (has_res) {
-        // instruction j covers pieces [64j, 64j+64); piece P = row * 13 + col, col 12 is padding
-        int row = lane / STG_PPR, col = lane - (lane / STG_PPR) * STG_PPR;
 #pragma unroll
-        for (int j = 0; j < NRES; ++j) {
-            const bool ok = col < STG_PPR - 1 && ch0 + col * 8 < KP && row < npix;
-            const unsigned off = ok ? (unsigned)((m0 + row) * KP + ch0 + col * 8) * 2u : 0u;
-            dma16(resb, off, lds0 + stg_off + j * 1024, __builtin_amdgcn_ballot_w64(ok));
-            col += 64 - 4 * STG_PPR; row += 4;
-            if (col >= STG_PPR) { col -= STG_PPR; row += 1; }
-        }
+        for (int j = 0; j < NRES2; ++j) res_dma(j, STG_R1, MT - STG_R1, lds0 + stg2);
         WSTAMP(19);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRES2) : "memory");    // piece 1 (issued under the loop) has landed
     }
     WSTAMP(20);
     const float* sb = reinterpret_cast<const float*>(smem + OFF_SB);
     const unsigned lo2 = p.relu ? 0u : 0x80008000u;             // packed int16 max with 0 = ReLU, with -32768 = no-op
     unsigned char* outb = reinterpret_cast<unsigned char*>(p.out);
-    unsigned char* stg = smem + stg_off;
     float4 sc[RN], bi[RN];
 #pragma unroll
     for (int j = 0; j < RN; ++j) {                               // 4 consecutive channels per lane and n-fragment
         sc[j] = *reinterpret_cast<const float4*>(sb + ch0 + j * 16 + kg * 4);
         bi[j] = *reinterpret_cast<const float4*>(sb + 768 + ch0 + j * 16 + kg * 4);
     }
+    auto row_addr = [&](int row) { return row < STG_R1 ? stg1 + row * STG_ROW : stg2 + (row - STG_R1) * STG_ROW; };
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        unsigned char* rowp = stg + (i * 16 + r16) * STG_ROW + kg * 8;
+        if (i == 2 && has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // piece 2 (rows 43..79)
+        unsigned char* rowp = smem + row_addr(i * 16 + r16) + kg * 8;
         uint2 u[RN];
         if (has_res) {                                          // all reads of a row before its writes: one LDS round trip
 #pragma unroll
@@ -476,7 +494,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         for (int t = 0; t < MT * 12 / 64; ++t) {
             if (row < npix && ch0 + col * 8 < KP)
                 *reinterpret_cast<uint4*>(outb + ((size_t)(m0 + row) * KP + ch0 + col * 8) * 2) =
-                    *reinterpret_cast<const uint4*>(stg + row * STG_ROW + col * 16);
+                    *reinterpret_cast<const uint4*>(smem + row_addr(row) + col * 16);
             col += 4; row += 5;                                   // 64 = 5 * 12 + 4
             if (col >= 12) { col -= 12; row += 1; }
         }

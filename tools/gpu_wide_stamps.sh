@@ -1,10 +1,12 @@
 #!/bin/bash
-# experiments build on the box (the product .so travels; rebuild with EXPERIMENTS=1 into a side directory is avoided:
-# build in place, it is a scratch copy), stamps of the wide kernel
-make -C biscuit_amd/csrc clean >/dev/null 2>&1
-make -C biscuit_amd/csrc -j16 EXPERIMENTS=1 2>&1 | grep -E "error|check_" | head
+# experiments build on the box, steady-state stamps (5th round of tiles) of the wide kernel + per-kernel time
 mkdir -p gpurun_out
-BQ_STAMPS_WIDE=gpurun_out/stamps_wide.bin timeout 600 python bench.py --no-extras --no-cpu-baseline --no-profile --steps 4 --streams 1 2>&1 | tail -1 | cut -c1-200
+make -C biscuit_amd/csrc clean >/dev/null 2>&1
+make -C biscuit_amd/csrc -j16 EXPERIMENTS=1 EXPFLAGS=-DWIDE_ABLATE=${1:-0} 2>&1 | grep -E "error" | head -3
+BQ_STAMPS_B0=1100 BQ_STAMPS_WIDE=gpurun_out/stamps_wide.bin timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 4 --streams 1 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+for k in d['kernels']:
+    if '728_n728_19' in k['name']: print('   ', k['name'], round(k['ms_per_launch'],4))
+"
 python tools/stamps_wide.py gpurun_out/stamps_wide.bin
-BQ_STAMPS_NORES=1 BQ_STAMPS_WIDE=gpurun_out/stamps_wide_nores.bin timeout 600 python bench.py --no-extras --no-cpu-baseline --no-profile --steps 4 --streams 1 2>&1 | tail -1 | cut -c1-100
-python tools/stamps_wide.py gpurun_out/stamps_wide_nores.bin
