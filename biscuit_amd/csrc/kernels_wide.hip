@@ -304,7 +304,15 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     const unsigned char* __restrict__ wbase = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)nfb * 1024;
     const unsigned voff = lane * 16;
     auto load_b = [&](int ks, int j) {
-        return *reinterpret_cast<const uint4*>(wbase + (size_t)ks * (NFT * 1024) + (j >> 2) * 4096 + voff + (j & 3) * 1024);
+        // the base is uniform: hand it to the compiler as scalars so that the load takes the scalar-base form (no
+        // 64-bit vector address arithmetic per fragment)
+        const unsigned long long b = (unsigned long long)(wbase + (size_t)ks * (NFT * 1024) + (j >> 2) * 4096);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        typedef const __attribute__((address_space(1))) unsigned char* gptr_t;
+        gptr_t sb = (gptr_t)(((unsigned long long)hi << 32) | lo);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = *(const __attribute__((address_space(1))) u32x4*)(sb + voff + (j & 3) * 1024);
+        return make_uint4(v.x, v.y, v.z, v.w);
     };
     const int a_lane = r16 * A_STR + kg * 16;
 
@@ -401,10 +409,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         static_for<0, KSC * MF * RN>([&](auto qc) {
             constexpr int Q = decltype(qc)::value;
             constexpr int D = Q / (MF * RN), J = (Q % (MF * RN)) / MF, I = Q % MF;
-            if constexpr (Q % (MF * RN) == 0) {                 // A fragments of this k-step
+            if constexpr (Q == 0) {                             // A fragments of the chunk's first k-step
 #pragma unroll
-                for (int i = 0; i < MF; ++i)
-                    a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR + D * 64);
+                for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR);
             }
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
             if constexpr (DO_D) dw_ops<RELU, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
@@ -418,6 +425,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                 bq[J] = load_b(nx < KST ? nx : KST - 1, J);     // branch-free: past the end re-load a valid, unused step
             }
 #endif
+            if constexpr (J == RN - 1 && D + 1 < KSC)           // last use of this A fragment: fetch the next k-step's
+                a[I] = *reinterpret_cast<const uint4*>(smem + a_cur + I * 16 * A_STR + (D + 1) * 64);
             __builtin_amdgcn_sched_barrier(0);                  // the source order of this loop IS the schedule
         });
         WSTAMP(6 + c);
