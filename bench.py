@@ -481,6 +481,11 @@ def b1_latency(eng, mc_n, calls=50):
             b.record()
             b.synchronize()
             res['us_per_call_device_graph'] = a.elapsed_time(b) / calls * 1e3
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                itf(x)
+            res['us_per_call_host_wall_graph'] = (time.perf_counter() - t0) / calls * 1e6
             res['graph'] = True
         except Exception as e:
             res['graph_error'] = f'{type(e).__name__}: {e}'

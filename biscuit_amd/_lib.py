@@ -42,6 +42,7 @@ ABI = {
     'bq_stain_lab_stats': (_i, [_vp, _vp, _i, _vp, _vp]),
     'bq_backbone': (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     'bq_mc_head': (_i, [_vp, _vp, _i, _i64, _i, _i, _u64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'bq_set_tile_index_ptr': (_i, [_vp, _vp]),
     'bq_mc_infer': (_i, [_vp, _vp, _i, _i64, _i, _u64, _i, _vp, _vp, _vp, _sz, _vp]),
     'bq_slide_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'bq_roc_workspace_bytes': (_sz, [_i64]),

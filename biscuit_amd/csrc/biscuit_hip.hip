@@ -46,6 +46,7 @@ struct bq_ctx {
     bool loaded = false;
     int num_cus = 256;
     float* d_srgb_lut = nullptr;   // tables of the Reinhard normaliser
+    const long long* d_tile0 = nullptr;   // bq_set_tile_index_ptr
     double* d_stage_stats = nullptr;   // 2 x 64-bit integer sums per tile for the staging kernel pair
     // profiling
     bool prof = false;
@@ -471,14 +472,14 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
             p.relu = last ? 1 : 0;
             p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32);
             p.thresh = thresh; p.dscale = dscale; p.layer = layer; p.mc_n = mc_n; p.pass0 = pass0;
-            p.in_row_is_tile = layer == 0 ? 1 : 0; p.tile0 = tile0;
+            p.in_row_is_tile = layer == 0 ? 1 : 0; p.tile0 = tile0; p.tile0_dev = c->d_tile0;
             const int e = launch_gemm(BQ_DTYPE_F32, PROD_DROPOUT, w8 ? SHAPE_I : SHAPE_H, p, s);
             if (e) return fail(c, BQ_ERR_HIP, std::string("head dense launch: ") + hipGetErrorString((hipError_t)e));
         }
     }
     {
         ProfScope ps(c, s, "mc_head_softmax_welford", 2.0 * rows * 1024 * 2, 4.0 * rows * 1024);
-        if (launch_head_final(h1, n, mc_n, pass0, tile0, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32),
+        if (launch_head_final(h1, n, mc_n, pass0, tile0, c->d_tile0, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32),
                               thresh, dscale, c->logits_w, c->logits_b, init, finalize, state, mean2, std2, s))
             return fail(c, BQ_ERR_HIP, "head_final launch failed");
     }
@@ -757,6 +758,12 @@ int bq_mc_head(bq_ctx* c, const float* d_feat, int n, int64_t tile_idx0, int mc_
     if (ws_bytes < ws_layout(c, n, mc_n).total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
     return head_impl(c, d_feat, n, tile_idx0, mc_n, pass0, seed, init, finalize, d_state, d_mean2, d_std2,
                      (unsigned char*)d_ws, (hipStream_t)stream);
+}
+
+int bq_set_tile_index_ptr(bq_ctx* c, const int64_t* d_tile_idx0) {
+    if (!c) return BQ_ERR_ARG;
+    c->d_tile0 = reinterpret_cast<const long long*>(d_tile_idx0);
+    return BQ_OK;
 }
 
 int bq_mc_infer(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int mc_n, uint64_t seed,

@@ -83,6 +83,7 @@ struct GemmParams {
     float dscale;
     int layer, mc_n, pass0, in_row_is_tile;
     long long tile0;
+    const long long* tile0_dev;   // optional device-side addend to tile0 (graph replay: the index changes between replays)
     int lds_total;         // dynamic LDS bytes of the launch (set by the pipe launcher)
 };
 
@@ -111,7 +112,7 @@ int launch_stem1(const void* in_nchw, int n, const float* w27x32, const float* s
 int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, int Wi, int C,
                     int dtype, hipStream_t s);
 int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s);
-int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0,
+int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, const long long* tile0_dev,
                       unsigned seed_lo, unsigned seed_hi, unsigned thresh, float dscale,
                       const float* w2, const float* b2, int init, int finalize, float* state,
                       float* mean2, float* std2, hipStream_t s);

@@ -148,8 +148,9 @@ __device__ __forceinline__ void produce(const GemmParams& p, unsigned char* smem
                     const size_t row = p.in_row_is_tile ? (size_t)tile : (size_t)m;
                     const uint4 vv = *reinterpret_cast<const uint4*>(in + row * ldi + ch0);
                     unsigned rnd[4];
+                    const long long t0 = p.tile0 + (p.tile0_dev ? *p.tile0_dev : 0);
                     philox4x32_10((unsigned)(ch0 >> 2), (unsigned)p.layer, (unsigned)pass,
-                                  (unsigned)(p.tile0 + tile), p.seed_lo, p.seed_hi, rnd);
+                                  (unsigned)(t0 + tile), p.seed_lo, p.seed_hi, rnd);
                     float f[4];
                     f[0] = __uint_as_float(vv.x); f[1] = __uint_as_float(vv.y);
                     f[2] = __uint_as_float(vv.z); f[3] = __uint_as_float(vv.w);

@@ -274,7 +274,8 @@ __global__ void __launch_bounds__(256) gap_kernel(const T* __restrict__ x, int n
 // softmax -> Welford update (count, mean[2], M2[2]) carried in registers; W2 lives in
 // registers (16 k per lane x 2 classes).  state layout [n][5] fp32.
 __global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict__ h1, int n, int mc_n,
-                                                         int pass0, long long tile0, unsigned seed_lo,
+                                                         int pass0, long long tile0_imm,
+                                                         const long long* __restrict__ tile0_dev, unsigned seed_lo,
                                                          unsigned seed_hi, unsigned thresh, float dscale,
                                                          const float* __restrict__ w2,
                                                          const float* __restrict__ b2, int init,
@@ -284,6 +285,7 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tile >= n) return;
+    const long long tile0 = tile0_imm + (tile0_dev ? *tile0_dev : 0);
     float wa[16], wb[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -485,11 +487,12 @@ int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dty
     return (int)hipGetLastError();
 }
 
-int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, unsigned seed_lo,
+int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, const long long* tile0_dev,
+                      unsigned seed_lo,
                       unsigned seed_hi, unsigned thresh, float dscale, const float* w2, const float* b2,
                       int init, int finalize, float* state, float* mean2, float* std2, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(head_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, h1, n, mc_n, pass0, tile0,
+    hipLaunchKernelGGL(head_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, h1, n, mc_n, pass0, tile0, tile0_dev,
                        seed_lo, seed_hi, thresh, dscale, w2, b2, init, finalize, state, mean2, std2);
     return (int)hipGetLastError();
 }

@@ -159,6 +159,14 @@ class Engine:
                                          ws.numel(), self._stream()))
         return mean, std
 
+    def set_tile_index_ptr(self, idx_tensor):
+        """Device-side addend to ``tile_idx0`` of the head kernels (``bq_set_tile_index_ptr``): an int64 tensor of one
+        element on this device, or None.  Kernels read it when they run, so a captured HIP graph can be replayed with
+        another Philox tile counter by writing 8 bytes."""
+        if idx_tensor is not None:
+            assert idx_tensor.dtype == torch.int64 and idx_tensor.is_cuda and idx_tensor.numel() == 1
+        self._check(self._lib.bq_set_tile_index_ptr(self._ctx, _ptr(idx_tensor)))
+
     def mc_infer(self, tiles_u8, mc_n, seed, tile_idx0=0, mc_mode='head', out=None):
         """uint8 NHWC tiles (device) -> (mean[n,2], std[n,2]) on device."""
         assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
@@ -359,12 +367,46 @@ class UncertaintyInterface:
             from .stain import ReinhardFast
             self.wsi_normalizer = ReinhardFast(engine, norm_fit['target_means'], norm_fit['target_stds'])
 
+    def enable_graph(self):
+        """Capture the one-tile call (stage -> ~60 backbone launches -> MC head) in a HIP graph: the heatmap loop of
+        results.py:250-258 calls the interface once per tile, and at B = 1 every kernel is a few microseconds long, so
+        the launch sequence itself is what a call costs.  The Philox tile counter stays the call index: it is read from
+        device memory by the head kernels (``Engine.set_tile_index_ptr``), results are bit-identical to the eager path."""
+        eng = self.engine
+        self._gx = torch.zeros((1, TILE_PX, TILE_PX, 3), dtype=torch.float32, device=eng.device)
+        self._gidx = torch.zeros(1, dtype=torch.int64, device=eng.device)
+        eng._ws_for(1, self.uq_n)                               # the workspace must exist before capture
+
+        def body():
+            feat = eng.backbone(eng.stage_f32(self._gx))
+            return eng.mc_head(feat, self.uq_n, self.seed, tile_idx0=0)
+        side = torch.cuda.Stream(device=eng.device)
+        side.wait_stream(torch.cuda.current_stream(eng.device))
+        eng.set_tile_index_ptr(self._gidx)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(2):                              # warm-up: kernel attributes, allocator
+                    body()
+            torch.cuda.current_stream(eng.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._gmean, self._gstd = body()
+        finally:
+            eng.set_tile_index_ptr(None)
+        self._graph = graph
+
     def device_call(self, x):
         """The same call with everything left on the device: x float32 [B,299,299,3] on the engine's GPU ->
         (mean, std) device tensors, nothing synchronises."""
         eng = self.engine
         if x.ndim != 4 or tuple(x.shape[1:]) != (TILE_PX, TILE_PX, 3):
             raise ValueError(f'expected [B,{TILE_PX},{TILE_PX},3] standardised tiles, got {tuple(x.shape)}')
+        if getattr(self, '_graph', None) is not None and x.shape[0] == 1:
+            self._gx.copy_(x)
+            self._gidx.fill_(self._calls)
+            self._graph.replay()
+            self._calls += 1
+            return self._gmean.clone(), self._gstd.clone()
         feat = eng.backbone(eng.stage_f32(x))
         mean, std = eng.mc_head(feat, self.uq_n, self.seed, tile_idx0=self._calls)
         self._calls += x.shape[0]

@@ -18,6 +18,28 @@ import torch
 MASKED = -1.0
 
 
+def tile_grid(region, tile_px=299, stride_div=1):
+    """The tile grid ``sf.Heatmap(slide, model, stride_div=...)`` walks (results.py:217), over a slide region that is
+    already in memory: tiles of ``tile_px`` at stride ``tile_px // stride_div``, row-major, border remainders dropped.
+    region: uint8 [H, W, 3] (numpy or torch, host or device).  Returns (tiles [T, tile_px, tile_px, 3] -- a torch
+    tensor on the region's device -- and grid int64 [T, 2] of (gx, gy) cells)."""
+    r = region if torch.is_tensor(region) else torch.from_numpy(np.ascontiguousarray(region))
+    if r.dim() != 3 or r.shape[2] != 3 or r.dtype != torch.uint8:
+        raise ValueError('region must be uint8 [H, W, 3]')
+    if stride_div < 1 or tile_px % stride_div:
+        raise ValueError('stride_div must divide tile_px')
+    stride = tile_px // stride_div
+    gy = (r.shape[0] - tile_px) // stride + 1 if r.shape[0] >= tile_px else 0
+    gx = (r.shape[1] - tile_px) // stride + 1 if r.shape[1] >= tile_px else 0
+    if gy == 0 or gx == 0:
+        return r.new_zeros((0, tile_px, tile_px, 3)), np.zeros((0, 2), np.int64)
+    # [gy, gx, 3, tile_px, tile_px] view -> NHWC tiles
+    t = r.unfold(0, tile_px, stride).unfold(1, tile_px, stride)
+    tiles = t.permute(0, 1, 3, 4, 2).reshape(gy * gx, tile_px, tile_px, 3).contiguous()
+    ys, xs = np.divmod(np.arange(gy * gx, dtype=np.int64), gx)
+    return tiles, np.stack([xs, ys], 1)
+
+
 class Heatmap:
     def __init__(self, engine, tiles, grid, grid_shape=None, mc_n=30, seed=0, batch=256, norm_fit=None):
         """tiles: uint8 [T,299,299,3] (host or device); grid: int [T,2] (gx, gy) cell of each tile."""
@@ -45,6 +67,14 @@ class Heatmap:
             g = grid[s:s + batch]
             self.logits[g[:, 1], g[:, 0]] = mean.cpu().numpy()
             self.uncertainty[g[:, 1], g[:, 0]] = std.cpu().numpy()
+
+    @classmethod
+    def from_region(cls, engine, region, tile_px=299, stride_div=1, **kw):
+        """Heatmap of a slide region in memory: the stride-``tile_px // stride_div`` grid of ``tile_grid``."""
+        tiles, grid = tile_grid(region, tile_px, stride_div)
+        stride = tile_px // stride_div
+        shape = ((region.shape[0] - tile_px) // stride + 1, (region.shape[1] - tile_px) // stride + 1)
+        return cls(engine, tiles, grid, grid_shape=shape, **kw)
 
     def mask_uncertain(self, tile_uq_thresh):
         """results.py:224-225: ``uq_mask = hm.uncertainty[:, :, 0] > thresh; hm.logits[uq_mask, :] = [-1, -1]``.

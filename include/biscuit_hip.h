@@ -115,6 +115,12 @@ int bq_mc_head(bq_ctx* ctx, const float* d_feat, int n, int64_t tile_idx0, int m
                float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes,
                bq_stream_t stream);
 
+/* Optional device-side addend to tile_idx0 of bq_mc_head / bq_mc_infer (NULL: none; the pointer must stay valid while
+ * launches that were enqueued with it are in flight).  The Philox tile counter of row i becomes
+ * tile_idx0 + *d_tile_idx0 + i, read by the kernels when they RUN: a captured HIP graph of the path (the one-tile
+ * loop of results.py:250-258) can then be replayed for tile after tile by updating 8 bytes of device memory. */
+int bq_set_tile_index_ptr(bq_ctx* ctx, const int64_t* d_tile_idx0);
+
 /* Fused convenience: uint8 tiles -> (mean[n,2], std[n,2]).  mc_mode BQ_MC_HEAD runs
  * the backbone once and the head mc_n times; BQ_MC_FULL re-runs the whole network per
  * pass like the reference loop.  Results are bit-identical between the two. */

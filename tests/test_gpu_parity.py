@@ -407,3 +407,38 @@ def test_device_youden_full_size_and_consumer_switch(engines):
     finally:
         T.use_device(None)
     assert host[0] == dev[0] and (host[1] == dev[1] or (np.isnan(host[1]) and np.isnan(dev[1])))
+
+
+@pytest.mark.gpu
+def test_heatmap_from_region_equals_explicit_tiles(engines):
+    """The stride grid over a slide region in memory (results.py:217 `sf.Heatmap(slide, model, stride_div=1)`)
+    gives the same grids as handing over the same tiles one by one."""
+    from biscuit_amd.heatmap import Heatmap, tile_grid
+    rng = np.random.default_rng(8)
+    region = rng.integers(0, 256, (299 * 2 + 11, 299 * 2 + 5, 3), dtype=np.uint8)
+    hm = Heatmap.from_region(engines['bf16'], torch.from_numpy(region).cuda(), mc_n=4, seed=3, batch=3)
+    tiles, grid = tile_grid(region)
+    ref = Heatmap(engines['bf16'], tiles, grid, grid_shape=(2, 2), mc_n=4, seed=3, batch=4)
+    assert hm.logits.shape == (2, 2, 2)
+    assert np.array_equal(hm.logits, ref.logits) and np.array_equal(hm.uncertainty, ref.uncertainty)
+    assert (hm.uncertainty[:, :, 0] > 0).all()
+
+
+@pytest.mark.gpu
+def test_uncertainty_interface_graph_replay_bit_identical(engines):
+    """B = 1 latency path (results.py:250-258): the captured HIP graph replays the eager launch sequence; the Philox tile
+    counter follows the call index through device memory, so results are bit-identical call by call."""
+    from biscuit_amd.engine import UncertaintyInterface
+    rng = np.random.default_rng(2)
+    xs = [torch.from_numpy(rng.normal(0, 1, (1, 299, 299, 3)).astype(np.float32)).cuda() for _ in range(4)]
+    for dtype in ('bf16', 'f32'):
+        eager = UncertaintyInterface(engines[dtype], uq_n=30, seed=5)
+        want = [eager.device_call(x) for x in xs]
+        itf = UncertaintyInterface(engines[dtype], uq_n=30, seed=5)
+        itf.enable_graph()
+        got = [itf.device_call(x) for x in xs]
+        for (m, s), (gm, gs) in zip(want, got):
+            assert torch.equal(m, gm) and torch.equal(s, gs)
+        assert not torch.equal(got[0][1], got[1][1])
+        m2, s2 = itf.device_call(torch.cat([xs[0], xs[1]]))    # other batch sizes fall back to the eager path
+        assert m2.shape == (2, 2)

@@ -182,3 +182,30 @@ def test_cli_model_hp_comes_from_params_json():
             model_hp(bad)
     with pytest.raises(ValueError):
         model_hp({'hp': {'dropout': 1.5}, 'normalizer': None})
+
+
+def test_heatmap_tile_grid_and_mask_golden():
+    """the stride grid of sf.Heatmap(slide, model, stride_div=1) (results.py:217) over a region in
+    memory, and the uncertainty mask of results.py:224-225 on a fixed array (golden values written out)."""
+    import torch
+    from biscuit_amd.heatmap import Heatmap, tile_grid, MASKED
+    rng = np.random.default_rng(4)
+    region = rng.integers(0, 256, (299 * 2 + 40, 299 * 3 + 7, 3), dtype=np.uint8)
+    tiles, grid = tile_grid(region, 299, 1)
+    assert tiles.shape == (6, 299, 299, 3) and grid.tolist() == [[0, 0], [1, 0], [2, 0], [0, 1], [1, 1], [2, 1]]
+    assert np.array_equal(tiles[4].numpy(), region[299:598, 299:598])          # cell (gx=1, gy=1)
+    t2, g2 = tile_grid(torch.from_numpy(region), 299, 13)                       # stride 23: overlapping tiles
+    assert t2.shape[0] == ((638 - 299) // 23 + 1) * ((904 - 299) // 23 + 1) and g2[-1].tolist() == [26, 14]
+    assert np.array_equal(t2[27 + 2].numpy(), region[23:322, 46:345])           # cell (gx=2, gy=1)
+    assert tile_grid(region[:100], 299)[0].shape[0] == 0
+    with pytest.raises(ValueError):
+        tile_grid(region, 299, 2)                                               # 2 does not divide 299
+    # the mask: `uq_mask = hm.uncertainty[:, :, 0] > thresh; hm.logits[uq_mask, :] = [-1, -1]` (strict >)
+    hm = Heatmap.__new__(Heatmap)
+    hm.uncertainty = np.array([[[0.010, 0.010], [0.030, 0.030], [0.020, 0.020]],
+                               [[0.0201, 0.0201], [-1, -1], [0.5, 0.5]]], np.float32)
+    hm.logits = np.array([[[0.9, 0.1], [0.2, 0.8], [0.6, 0.4]], [[0.3, 0.7], [-1, -1], [0.5, 0.5]]], np.float32)
+    mask = hm.mask_uncertain(0.02)
+    assert mask.tolist() == [[False, True, False], [True, False, True]]        # 0.020 is NOT masked (strict), the empty cell neither
+    want = np.array([[[0.9, 0.1], [MASKED, MASKED], [0.6, 0.4]], [[MASKED, MASKED], [-1, -1], [MASKED, MASKED]]], np.float32)
+    assert np.array_equal(hm.logits, want)

@@ -271,3 +271,77 @@ def test_keras_layer_order_matches_the_architecture():
     i = names.index('block2_sepconv2_bn')
     assert names[i + 1:i + 3] == ['block2_res_conv', 'block2_res_bn']       # Keras: ..., conv2d, batch_normalization
     assert names[-3:] == ['hidden_0', 'hidden_1', 'logits']
+
+
+def _pb(field, wt, payload):
+    """One protobuf field, assembled by hand (wire types 0 varint, 2 length-delimited, 5 fixed32)."""
+    tag = B._put_varint((field << 3) | wt)
+    if wt == 0:
+        return tag + B._put_varint(payload)
+    if wt == 2:
+        return tag + B._put_varint(len(payload)) + payload
+    return tag + payload
+
+
+def _entry_proto(dtype, shape, shard, offset, raw, sliced=False):
+    """BundleEntryProto from tensorflow/core/protobuf/tensor_bundle.proto: dtype=1, shape=2, shard_id=3, offset=4,
+    size=5, crc32c=6 (fixed32, masked), slices=7 -- written here field by field, not through write_bundle."""
+    dims = b''.join(_pb(2, 2, _pb(1, 0, d)) for d in shape)
+    e = _pb(1, 0, dtype) + _pb(2, 2, dims) + _pb(3, 0, shard) + _pb(4, 0, offset) + _pb(5, 0, len(raw)) + \
+        _pb(6, 5, struct.pack('<I', B._mask(crc32c(raw))))
+    if sliced:
+        e += _pb(7, 2, b'\x0a\x00')
+    return e
+
+
+def test_hand_assembled_multi_shard_bundle(tmp_path):
+    """A checkpoint as tf.train.Saver writes it from several devices: `.data-00000-of-00002`, `.data-00001-of-00002`,
+    BundleHeaderProto{num_shards=2}, entries that point into either shard at non-zero offsets.  Every byte of the
+    index entries is assembled from the .proto field numbers, nothing goes through this module's writer."""
+    prefix = str(tmp_path / 'ckpt')
+    a = np.arange(12, dtype='<f4').reshape(3, 4)
+    b = (np.arange(5, dtype='<f4') - 2).astype('<f4')
+    c = np.asarray([7, -9], '<i8')
+    shard0 = b'\xee' * 24 + a.tobytes()                          # tensor at offset 24 of shard 0
+    shard1 = b.tobytes() + b'\x00' * 3 + c.tobytes()             # two tensors in shard 1, the second unaligned
+    open(prefix + '.data-00000-of-00002', 'wb').write(shard0)
+    open(prefix + '.data-00001-of-00002', 'wb').write(shard1)
+    header = _pb(1, 0, 2) + _pb(2, 0, 0) + _pb(3, 2, _pb(1, 0, 1))   # num_shards=2, LITTLE endian, version{producer=1}
+    table = {B.HEADER_KEY: header,
+             b'layer/a': _entry_proto(1, (3, 4), 0, 24, a.tobytes()),            # DT_FLOAT = 1
+             b'layer/b': _entry_proto(1, (5,), 1, 0, b.tobytes()),
+             b'layer/c': _entry_proto(9, (2,), 1, len(b.tobytes()) + 3, c.tobytes())}   # DT_INT64 = 9
+    B.write_table(prefix + '.index', table, block_size=48)       # several blocks: shared-prefix keys across restarts
+    r = B.BundleReader(prefix)
+    assert r.header['num_shards'] == 2 and sorted(r.keys()) == ['layer/a', 'layer/b', 'layer/c']
+    assert np.array_equal(r.tensor('layer/a'), a) and np.array_equal(r.tensor('layer/b'), b)
+    assert np.array_equal(r.tensor('layer/c'), c) and r.tensor('layer/c').dtype == np.int64
+    # a missing shard is an error that names the file, never an empty tensor
+    os.remove(prefix + '.data-00001-of-00002')
+    with pytest.raises(B.BundleError, match='data-00001-of-00002'):
+        B.BundleReader(prefix).tensor('layer/b')
+    assert np.array_equal(B.BundleReader(prefix).tensor('layer/a'), a)   # the other shard still reads
+    # a truncated shard
+    open(prefix + '.data-00001-of-00002', 'wb').write(shard1[:10])
+    with pytest.raises(B.BundleError, match='truncated'):
+        B.BundleReader(prefix).tensor('layer/c')
+
+
+def test_big_endian_and_sliced_entries_are_refused(tmp_path):
+    prefix = str(tmp_path / 'be')
+    x = np.arange(4, dtype='>f4')
+    open(prefix + '.data-00000-of-00001', 'wb').write(x.tobytes())
+    # BundleHeaderProto.endianness = BIG (1): tensors would be byte-swapped; refuse instead of mis-reading
+    B.write_table(prefix + '.index', {B.HEADER_KEY: _pb(1, 0, 1) + _pb(2, 0, 1), b'x': _entry_proto(1, (4,), 0, 0, x.tobytes())})
+    with pytest.raises(B.BundleError, match='big-endian'):
+        B.BundleReader(prefix)
+    # a partitioned variable (BundleEntryProto.slices present) has no bytes of its own under that key
+    B.write_table(prefix + '.index', {B.HEADER_KEY: _pb(1, 0, 1), b'x': _entry_proto(1, (4,), 0, 0, x.tobytes(), sliced=True)})
+    with pytest.raises(B.BundleError, match='sliced'):
+        B.BundleReader(prefix).tensor('x')
+    # varints longer than one byte in the entry (offset 300 = 0xAC 0x02, little-endian base-128 groups)
+    assert B._put_varint(300) == b'\xac\x02'
+    big = b'\x00' * 300 + x.astype('<f4').tobytes()
+    open(prefix + '.data-00000-of-00001', 'wb').write(big)
+    B.write_table(prefix + '.index', {B.HEADER_KEY: _pb(1, 0, 1), b'x': _entry_proto(1, (4,), 0, 300, x.astype('<f4').tobytes())})
+    assert np.array_equal(B.BundleReader(prefix).tensor('x'), np.arange(4, dtype=np.float32))

@@ -10,7 +10,8 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
-    m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+)I(.*)EEv10GemmParams', name)
+    m = re.match(r'_ZN12_GLOBAL__N_1\d+(sepconv_wide_kernel)I(.*)EEvNS_10WideParamsE', name) or \
+        re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+)I(.*)EEv10GemmParams', name)
     if m:
         args = m.group(2).replace('DF16b', 'bf16,').replace('Li', '').replace('E', ',').replace('Lb', 'b')
         return f'{m.group(1)}<{args.strip(",")}>'
@@ -21,7 +22,7 @@ def main():
     src, out = sys.argv[1], sys.argv[2]
     lines = [f'# rocprofv3 summary ({os.path.basename(src)})', '',
              'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 8 '
-             '--warmup 2 --no-cpu-baseline --no-profile` (the default: 4 batches in flight), the same with '
+             '--warmup 2 --no-cpu-baseline --no-profile --no-extras` (the default: up to 4 batches in flight), the same with '
              '`--streams 1`, plus two separate `--pmc` passes, FETCH_SIZE and WRITE_SIZE, which do not fit one pass on gfx950.', '']
     def newest(pattern):
         f = sorted(glob.glob(pattern), key=os.path.getmtime)
@@ -70,10 +71,10 @@ def main():
                   '| kernel | workgroups | launches | avg us | total ms |', '|---|---:|---:|---:|---:|']
         for (kn, wg), (n, dur) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:16]:
             lines.append(f'| `{kn}` | {wg} | {n} | {dur/n/1e3:.1f} | {dur/1e6:.2f} |')
-        dom = [(n, dur) for (kn, wg), (n, dur) in acc.items() if 'sepconv_pipe_kernel' in kn and wg == 963]
+        dom = [(n, dur) for (kn, wg), (n, dur) in acc.items() if 'sepconv_wide_kernel' in kn and wg == 1280]
         if dom:
             n = sum(x[0] for x in dom); dur = sum(x[1] for x in dom)
-            lines += ['', f'Dominant layer class (sepconv 728->728 @19x19, 963 workgroups): {n} launches, '
+            lines += ['', f'Dominant layer class (sepconv 728->728 @19x19, kernels_wide.hip, 1280 workgroups): {n} launches, '
                           f'average {dur/n/1e3:.1f} us.']
         lines.append('')
     pmc = {}
@@ -106,7 +107,7 @@ def main():
             lines.append(f'| `{kn}` | {f[1] or w[1]} | {f[0]:.0f} | {w[0]:.0f} | {mb:.1f} | {(f[2] or w[2])/1e3:.1f} |')
         lines.append('')
         # the dominant kernel of bench.py (728 -> 728 separable conv at 19x19, n = 256 -> 963 workgroups)
-        dom = [(kn, d) for kn, d in names.items() if 'sepconv_pipe_kernel' in kn and '[963 wg]' in kn]
+        dom = [(kn, d) for kn, d in names.items() if 'sepconv_wide_kernel' in kn and '[1280 wg]' in kn]
         if dom:
             import json
             nl = sum((d.get('FETCH_SIZE') or d.get('WRITE_SIZE'))[1] for _, d in dom)
@@ -116,7 +117,7 @@ def main():
                                               'corrected_bytes_per_launch': (2 * fetch + write) * 1024,
                                               'source': os.path.basename(out), 'launches': nl}}
             json.dump(js, open(os.path.join(os.path.dirname(out), 'traffic.json'), 'w'), indent=1)
-            lines += [f'Dominant kernel (963 workgroups): FETCH_SIZE {fetch:.0f} KiB, WRITE_SIZE {write:.0f} KiB per launch '
+            lines += [f'Dominant kernel (1280 workgroups): FETCH_SIZE {fetch:.0f} KiB, WRITE_SIZE {write:.0f} KiB per launch '
                       f'-> corrected {(2 * fetch + write) * 1024 / 1e6:.1f} MB (algorithmic 270 MB incl. residual reads).', '']
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines[:40]))
