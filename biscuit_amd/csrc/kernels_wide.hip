@@ -41,44 +41,48 @@ constexpr int KP = 736;                 // padded input channels (46 k-blocks of
 constexpr int KST = KP / 32;             // 23 k-steps of 32 (one v_mfma_f32_16x16x32_bf16 deep)
 constexpr int KC = 64;                  // channels per chunk
 constexpr int NCH = (KP + KC - 1) / KC; // 12 chunks: 11 whole ones and one of 32 channels
-constexpr int IW = 19, IH = 19;         // map size
-constexpr int TR = 4;                   // map rows per tile
-constexpr int TPI = (IH + TR - 1) / TR; // tiles per image (5)
-constexpr int PW = IW + 2;              // slots per row of the padded halo image
-constexpr int NSLOT = (TR + 2) * PW;    // 126 slots of 128 B (64 channels of one pixel)
-constexpr int NDMA = 16;                // LDS-DMA instructions (1 KiB each) that cover the halo image: 2 per wave
-constexpr int RAW_BYTES = NDMA * 1024;
 constexpr int MT = 80;                  // MFMA rows per tile
 constexpr int A_STR = KC * 2 + 32;      // 160 B = 10 slots of 16 B: the 16x16x32 fragment read (lane -> row l&15, 16-byte
                                         // k-group l>>4) is conflict-free for ds_read_b128's lane groups iff slots/row = 2 (mod 4)
-constexpr int A_BYTES = (MT + 1) * A_STR;   // row 80 takes the results of pad slots
-constexpr int NSTEP = 5;                // pixels per lane: 16 lane groups = 4 tile rows x 4 segments of 5 (5, 5, 5, 4) pixels
+constexpr int A_BYTES = (MT + 1) * A_STR;   // row 80 takes the results of pixels past the end of a map row
+constexpr int NSTEP = 5;                // pixels per depthwise run
 constexpr int WN = 8, RN = 6, MF = 5;   // waves, 16-wide n-fragments per wave, 16-row m-fragments
 constexpr int NFT = WN * RN;            // 48 n-fragments of 16 output channels
 constexpr int CPW = RN * 16;            // 96 output channels per wave
-
-// LDS map.  Loop buffers first, the folded-BN table at the very top; the epilogue's staging tile (per wave 80 rows of
-// its 192 channels) aliases the loop buffers.
-constexpr int OFF_RAW = 0;                       // 2 halo images (bf16, as they arrive)
-constexpr int OFF_A = OFF_RAW + 2 * RAW_BYTES;
-constexpr int OFF_TAPS = OFF_A + 2 * A_BYTES;
 constexpr int TAPS_BYTES = 9 * KP * 4;
-constexpr int LOOP_END = OFF_TAPS + TAPS_BYTES;
 constexpr int STG_ROW = CPW * 2 + 16;    // 13 pieces of 16 B: odd
 constexpr int STG_PPR = STG_ROW / 16;
-// a wave's staging rows live in two pieces: rows [0, STG_R1) above the loop's buffers (free while the loop runs: the
-// residual tile's first rows are copied there under the loop), rows [STG_R1, 80) over the loop's buffers
-constexpr int STG_R1 = 43;
-constexpr int STG_W1 = STG_R1 * STG_ROW, STG_W2 = (MT - STG_R1) * STG_ROW;
-constexpr int NRES1 = (STG_R1 * STG_PPR + 63) / 64;          // LDS-DMA instructions per wave and piece (9 and 8)
-constexpr int NRES2 = ((MT - STG_R1) * STG_PPR + 63) / 64;
 constexpr int SB_BYTES = 2 * 768 * 4;
 constexpr int LDS_TOTAL = 160 * 1024;
 constexpr int OFF_SB = LDS_TOTAL - SB_BYTES;
-constexpr int OFF_STG1 = LOOP_END, OFF_STG2 = 0;
-static_assert(OFF_STG1 + WN * STG_W1 <= OFF_SB && OFF_STG2 + WN * STG_W2 <= LOOP_END, "LDS budget");
-static_assert(4 * NSTEP >= IW && 2 * WN == 4 * TR, "lane groups do not cover the tile");
-static_assert(NDMA * 1024 >= NSLOT * 128 && NDMA == 2 * WN, "halo DMA cover");
+
+// Geometry of one instance: IW x IW maps, TR map rows per tile (TR * IW <= 80 pixels).
+template <int IW_, int TR_>
+struct Geo {
+    static constexpr int IW = IW_, IH = IW_, TR = TR_;
+    static constexpr int TPI = (IH + TR - 1) / TR;           // tiles per image
+    static constexpr int PW = IW + 2;                        // slots per row of the padded halo image
+    static constexpr int NSLOT = (TR + 2) * PW;              // slots of 128 B (64 channels of one pixel)
+    static constexpr int NDMA = (NSLOT + 7) / 8;             // LDS-DMA instructions (1 KiB each) that cover the image
+    static constexpr int HPW = (NDMA + WN - 1) / WN;         // ... per wave
+    static constexpr int RAW_BYTES = HPW * WN * 1024;
+    static constexpr int SEG = 16 / TR;                      // depthwise runs per tile row (16 lane groups in all)
+    // LDS map.  Loop buffers first, the folded-BN table at the very top; the epilogue's staging tile (per wave 80 rows of
+    // its 96 channels) in two pieces: rows [0, STG_R1) above the loop's buffers (free while the loop runs: the residual
+    // tile's first rows are copied there under the loop), rows [STG_R1, 80) over the loop's buffers
+    static constexpr int OFF_RAW = 0;                        // 2 halo images (bf16, as they arrive)
+    static constexpr int OFF_A = OFF_RAW + 2 * RAW_BYTES;
+    static constexpr int OFF_TAPS = OFF_A + 2 * A_BYTES;
+    static constexpr int LOOP_END = OFF_TAPS + TAPS_BYTES;
+    static constexpr int STG_R1 = (OFF_SB - LOOP_END) / (WN * STG_ROW) < MT ? (OFF_SB - LOOP_END) / (WN * STG_ROW) : MT;
+    static constexpr int STG_W1 = STG_R1 * STG_ROW, STG_W2 = (MT - STG_R1) * STG_ROW;
+    static constexpr int NRES1 = (STG_R1 * STG_PPR + 63) / 64;          // LDS-DMA instructions per wave and piece
+    static constexpr int NRES2 = ((MT - STG_R1) * STG_PPR + 63) / 64;
+    static constexpr int OFF_STG1 = LOOP_END, OFF_STG2 = 0;
+    static_assert(OFF_STG1 + WN * STG_W1 <= OFF_SB && OFF_STG2 + WN * STG_W2 <= LOOP_END, "LDS budget");
+    static_assert(SEG * NSTEP >= IW && SEG * TR == 16 && TR * IW <= MT, "depthwise runs do not cover the tile");
+    static_assert(NRES1 <= NCH, "the residual prefetch needs one loop iteration per instruction");
+};
 
 struct WideParams {
     const bf16_t* in;       // [n*361][736]
@@ -159,21 +163,22 @@ __device__ __forceinline__ float2 unpack2(unsigned d) {
     return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u));
 }
 
+template <int PW>
 __device__ __forceinline__ unsigned raw_dword(const unsigned char* smem, int raw_addr, int j, int r) {
     return *reinterpret_cast<const unsigned*>(smem + raw_addr + ((j + 1) + r * PW) * 128);
 }
 
-template <bool RELU, int M>
-__device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[2]) {
+template <bool RELU, int PW, int M>
+__device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[NSTEP]) {
     if constexpr (M < 3) {
 #pragma unroll
         for (int t = 3 * M; t < 3 * M + 3; ++t) st.tw[t] = *reinterpret_cast<const float2*>(smem + tap_addr + t * KP * 4);
     } else if constexpr (M < 5) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) st.x[M - 3][r] = raw_dword(smem, raw_addr, M - 4, r);
+        for (int r = 0; r < 3; ++r) st.x[M - 3][r] = raw_dword<PW>(smem, raw_addr, M - 4, r);
     } else if constexpr (M == 5) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) st.d[r] = raw_dword(smem, raw_addr, 1, r);
+        for (int r = 0; r < 3; ++r) st.d[r] = raw_dword<PW>(smem, raw_addr, 1, r);
     } else if constexpr (M < 8) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) st.c[M - 6][r] = unpack2<RELU>(st.x[M - 6][r]);
@@ -185,7 +190,7 @@ __device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_
         if constexpr (K == 7) {
             if constexpr (S + 1 < NSTEP) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) st.d[r] = raw_dword(smem, raw_addr, S + 2, r);
+                for (int r = 0; r < 3; ++r) st.d[r] = raw_dword<PW>(smem, raw_addr, S + 2, r);
             }
         } else if constexpr (K < 10) {
             constexpr int T = K < 7 ? K : K - 1, R = T / 3, DX = T % 3;
@@ -194,18 +199,18 @@ __device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_
         } else if constexpr (K == 10) {
             unsigned pk;
             asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(st.o0), "v"(st.o1));
-            *reinterpret_cast<unsigned*>(smem + (S + 1 < NSTEP ? aw[0] + S * A_STR : aw[1])) = pk;
+            *reinterpret_cast<unsigned*>(smem + aw[S]) = pk;
         } else {
             if constexpr (S + 1 < NSTEP) st.c[S % 3][K - 11] = unpack2<RELU>(st.d[K - 11]);
         }
     }
 }
 
-template <bool RELU, int LO, int HI>
-__device__ __forceinline__ void dw_ops(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[2]) {
+template <bool RELU, int PW, int LO, int HI>
+__device__ __forceinline__ void dw_ops(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[NSTEP]) {
     if constexpr (LO < HI) {
-        dw_op<RELU, LO>(st, smem, raw_addr, tap_addr, aw);
-        dw_ops<RELU, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
+        dw_op<RELU, PW, LO>(st, smem, raw_addr, tap_addr, aw);
+        dw_ops<RELU, PW, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
     }
 }
 
@@ -251,8 +256,12 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <bool RELU>
+template <bool RELU, typename G>
 __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams p) {
+    constexpr int IW = G::IW, IH = G::IH, TR = G::TR, TPI = G::TPI, PW = G::PW, NSLOT = G::NSLOT, HPW = G::HPW;
+    constexpr int RAW_BYTES = G::RAW_BYTES, OFF_RAW = G::OFF_RAW, OFF_A = G::OFF_A, OFF_TAPS = G::OFF_TAPS;
+    constexpr int STG_R1 = G::STG_R1, STG_W1 = G::STG_W1, STG_W2 = G::STG_W2, NRES1 = G::NRES1, NRES2 = G::NRES2;
+    constexpr int OFF_STG1 = G::OFF_STG1, OFF_STG2 = G::OFF_STG2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -272,10 +281,10 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     WSTAMP(0);
     // ---- per-lane constants -------------------------------------------------------------------------------
     // halo DMA: instruction j = wave + 8t covers pieces [64j, 64j+64) of the padded image (piece = slot*8 + 16-byte part)
-    unsigned halo_off[2];
-    unsigned long long halo_mask[2];
+    unsigned halo_off[HPW];
+    unsigned long long halo_mask[HPW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < HPW; ++t) {
         const int P = (wave + WN * t) * 64 + lane;
         const int slot = P >> 3, piece = P & 7;
         const int sy = slot / PW, sx = slot - sy * PW;
@@ -289,11 +298,11 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     // depthwise: channel pair cp, lane group grp (0..15) = tile row grp >> 2, pixels [5 (grp & 3), 5 (grp & 3) + 5) of it
     const int cp = lane & 31;
     const int grp = wave * 2 + (lane >> 5);
-    const int drow = grp >> 2, dx0 = (grp & 3) * NSTEP;
+    const int drow = grp / G::SEG, dx0 = (grp - drow * G::SEG) * NSTEP;
     const int raw_lane = (drow * PW + dx0) * 128 + cp * 4;      // slot (row - 1, x0 - 1) of the padded image: column -1, row -1
-    // A-chunk address of the run's first pixel (the next three follow at A_STR) and of its fifth, which the last
-    // segment of a row does not have (row 80 of the chunk takes the result)
-    const int aw[2] = {(drow * IW + dx0) * A_STR + cp * 4, (dx0 + 4 < IW ? drow * IW + dx0 + 4 : MT) * A_STR + cp * 4};
+    int aw[NSTEP];                                              // A-chunk address of each pixel's result (row 80: past the map row)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) aw[s] = (dx0 + s < IW ? drow * IW + dx0 + s : MT) * A_STR + cp * 4;
     const int tap_lane = OFF_TAPS + cp * 8;
 
     // matrix stage: lane -> (row l&15 of a 16-row fragment, 16-byte k-group l>>4)
@@ -319,7 +328,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     // ---- prologue: every load the first stages need goes out before anything waits ---------------------------
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(p.in);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) dma16(inb, halo_off[t], lds0 + OFF_RAW + (wave + WN * t) * 1024, halo_mask[t]);
+    for (int t = 0; t < HPW; ++t) dma16(inb, halo_off[t], lds0 + OFF_RAW + (wave + WN * t) * 1024, halo_mask[t]);
     {   // depthwise taps (26 496 B) and folded BN (2 x 3 072 B): plain copies, wave w takes instructions w, w+8, ...
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -335,11 +344,11 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
 #pragma unroll
     for (int j = 0; j < RN; ++j) bq[j] = load_b(0, j);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < HPW; ++t)
         dma16(inb + KC * 2, halo_off[t], lds0 + OFF_RAW + RAW_BYTES + (wave + WN * t) * 1024, halo_mask[t]);
     // zero the slots the DMA never writes (pad columns, rows outside the map) in both halo buffers
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < HPW; ++t) {
         const int P = t * 512 + tid;
         const int slot = P >> 3;
         const int sy = slot / PW, sx = slot - sy * PW;
@@ -357,14 +366,16 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         for (int j = 0; j < RN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     WSTAMP(1);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // all but the two DMAs of halo chunk 1 have landed
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HPW) : "memory");  // all but the DMAs of halo chunk 1 have landed
     WSTAMP(2);
     __syncthreads();
     WSTAMP(3);
     {   // D(0): the first A chunk, nothing to overlap it with
         DwState st;
-        const int aw0[2] = {opaque(OFF_A + aw[0]), opaque(OFF_A + aw[1])};
-        dw_ops<RELU, 0, NDW>(st, smem, OFF_RAW + raw_lane, opaque(tap_lane), aw0);
+        int aw0[NSTEP];
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) aw0[s] = opaque(OFF_A + aw[s]);
+        dw_ops<RELU, PW, 0, NDW>(st, smem, OFF_RAW + raw_lane, opaque(tap_lane), aw0);
     }
     WSTAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // halo chunk 1
@@ -393,14 +404,16 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         if (c + 2 < NCH) {
             const unsigned long long tl = c + 2 == NCH - 1 ? tail_lanes : ~0ull;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < HPW; ++t)
                 dma16(inb + (c + 2) * (KC * 2), halo_off[t], lds0 + OFF_RAW + CUR * RAW_BYTES + (wave + WN * t) * 1024,
                       halo_mask[t] & tl);
         }
         if (has_res && c < NRES1) res_dma(c, 0, STG_R1, lds0 + OFF_STG1 + wave * STG_W1);
         const int a_cur = opaque(OFF_A + CUR * A_BYTES + a_lane);
         const int raw_addr = OFF_RAW + NXT * RAW_BYTES + raw_lane;
-        const int awn[2] = {opaque(OFF_A + NXT * A_BYTES + aw[0]), opaque(OFF_A + NXT * A_BYTES + aw[1])};
+        int awn[NSTEP];
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) awn[s] = opaque(OFF_A + NXT * A_BYTES + aw[s]);
         // taps of chunk c+1; the last chunk has 32 channels: pairs 16..31 read a clamped (valid, unused) address
         const int tap_addr = opaque(((c + 1 == NCH - 1 && cp >= 16) ? tap_lane - 128 : tap_lane) + (c + 1) * (KC * 4));
         DwState st;
@@ -414,7 +427,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                 for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR);
             }
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
-            if constexpr (DO_D) dw_ops<RELU, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
+            if constexpr (DO_D) dw_ops<RELU, PW, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
             mfma16(acc[I][J], bq[J], a[I]);
@@ -513,26 +526,36 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
 
 }  // namespace
 
+using G19 = Geo<19, 4>;     // blocks 5-12 and block13_sepconv1: 5 tiles of 4 (the last: 3) rows per image
+using G37 = Geo<37, 2>;     // block4_sepconv2: 19 tiles of 2 (the last: 1) rows per image
+
 bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo) {
-    return dtype == 1 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == IH && W == IW && K == KP &&
-           Nstore == KP && ldi == KP && ldo == KP;
+    return dtype == 1 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == W && (W == G19::IW || W == G37::IW) &&
+           K == KP && Nstore == KP && ldi == KP && ldo == KP;
 }
 
 // wp16: the layer's pointwise weights in 16x16x32 fragment order (blob entry "<layer>/wp16")
 int launch_sepconv_wide(int prod, const GemmParams& g, const void* wp16, hipStream_t s) {
-    if (g.M % (IH * IW) != 0 || g.k_off != 0 || !g.scale || !g.bias || !wp16) return (int)hipErrorInvalidValue;
+    const bool big = g.W == G37::IW;
+    const int hw = g.H * g.W;
+    if ((g.W != G19::IW && !big) || g.H != g.W || g.M % hw != 0 || g.k_off != 0 || !g.scale || !g.bias || !wp16)
+        return (int)hipErrorInvalidValue;
     WideParams p;
     p.in = reinterpret_cast<const bf16_t*>(g.in);
     p.wp = reinterpret_cast<const uint4*>(wp16);
     p.dw = g.dw; p.scale = g.scale; p.bias = g.bias;
     p.residual = reinterpret_cast<const bf16_t*>(g.residual);
     p.out = reinterpret_cast<bf16_t*>(g.out);
-    p.n = g.M / (IH * IW);
+    p.n = g.M / hw;
     p.relu = g.relu;
     const bool relu_in = prod == PROD_DW_RELU;
-    auto kern = relu_in ? sepconv_wide_kernel<true> : sepconv_wide_kernel<false>;
-    static BqLdsAttr attr[2];
-    if (const int e = attr[relu_in].ensure(reinterpret_cast<const void*>(kern), LDS_TOTAL)) return e;
+    void (*const kerns[4])(const WideParams) = {sepconv_wide_kernel<false, G19>, sepconv_wide_kernel<true, G19>,
+                                                sepconv_wide_kernel<false, G37>, sepconv_wide_kernel<true, G37>};
+    const int ki = (big ? 2 : 0) + (relu_in ? 1 : 0);
+    auto kern = kerns[ki];
+    const int tpi = big ? G37::TPI : G19::TPI;
+    static BqLdsAttr attr[4];
+    if (const int e = attr[ki].ensure(reinterpret_cast<const void*>(kern), LDS_TOTAL)) return e;
 #ifdef BQ_EXPERIMENTS
     // BQ_STAMPS_WIDE=<file>: in-kernel s_memtime stamps of the first launch with (BQ_STAMPS_NORES: without) a residual
     static const char* stamp_file = bq_exp_env("BQ_STAMPS_WIDE");
@@ -548,7 +571,7 @@ int launch_sepconv_wide(int prod, const GemmParams& g, const void* wp16, hipStre
         state = 1;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(p.n * TPI), dim3(64 * WN), LDS_TOTAL, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.n * tpi), dim3(64 * WN), LDS_TOTAL, s, p);
 #ifdef BQ_EXPERIMENTS
     if (state == 1) {
         std::vector<unsigned long long> h(64 * WN * 32);

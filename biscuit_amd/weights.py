@@ -234,8 +234,9 @@ def pack_fragments16(wkn, kpad, npad):
 
 
 def wide_layers():
-    """The 25 separable convolutions 728 -> 728 on 19x19 maps (blocks 5-12 and block13_sepconv1): kernels_wide.hip."""
-    return [f'block{b}_sepconv{i}' for b in range(5, 13) for i in (1, 2, 3)] + ['block13_sepconv1']
+    """The 26 separable convolutions 728 -> 728 of kernels_wide.hip: block4_sepconv2 (37x37 maps), blocks 5-12 and
+    block13_sepconv1 (19x19 maps)."""
+    return ['block4_sepconv2'] + [f'block{b}_sepconv{i}' for b in range(5, 13) for i in (1, 2, 3)] + ['block13_sepconv1']
 
 
 def fold_bn(w, name):

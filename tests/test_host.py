@@ -76,9 +76,9 @@ def test_blob_directory_roundtrip():
         nm, off, ln = struct.unpack_from('<48sQQ', blob, 16 + 64 * i)
         names[nm.rstrip(b'\0').decode()] = (off, ln)
         assert off % 256 == 0 and off + ln <= len(blob)
-    # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 25 wide layers (bf16 blobs only)
-    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 25
-    assert names['block5_sepconv1/wp16'][1] == 23 * 48 * 64 * 8 * 2 and 'block4_sepconv2/wp16' not in names
+    # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 26 wide layers (bf16 blobs only)
+    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 26
+    assert names['block5_sepconv1/wp16'][1] == 23 * 48 * 64 * 8 * 2 and 'block4_sepconv2/wp16' in names and 'block4_sepconv1/wp16' not in names
     off, ln = names['block5_sepconv2/scale']
     s, b = W.fold_bn(w, 'block5_sepconv2_bn')
     got = np.frombuffer(blob, np.float32, ln // 4, off)
