@@ -401,8 +401,10 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
         char nm[64];
         snprintf(nm, sizeof nm, "block%d_sepconv1", block);
         RUN(run_conv(c, {nm, PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1, R}, s));
+        TAP(nm, Y, 19, 19, 728, 736);
         snprintf(nm, sizeof nm, "block%d_sepconv2", block);
         RUN(run_conv(c, {nm, PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1, R}, s));
+        TAP(nm, C, 19, 19, 728, 736);
         snprintf(nm, sizeof nm, "block%d_sepconv3", block);
         RUN(run_conv(c, {nm, PROD_DW, C, Y, X, nullptr, n, 19, 19, 19, 19, 736, 736, 0, R}, s));
         void* t = X; X = Y; Y = t;

@@ -1,25 +1,26 @@
 #!/usr/bin/env python3
-"""Build-time guard for kernels_wide.hip (run by `make`).
+"""Build-time guard for kernels_wide.hip (run by `make`; takes any number of assembly files).
 
 The kernel issues its MFMAs as inline asm (accumulators tied in place in the accumulator file) and its LDS-DMA as
 inline asm too, so hipcc neither pads their hazards nor counts their memory operations.  This script reads the
-generated assembly and fails the build unless, in every sepconv_wide_kernel instance:
+generated assembly and fails the build unless, in every sepconv_wide*_kernel instance:
   * nothing uses scratch (a spill reload is a vector-memory operation the loop's counted `s_waitcnt vmcnt(N)` does not
     expect; it would also sit in the hot loop);
-  * every v_mfma keeps its accumulator in place (dst == C) in the accumulator file;
+  * every v_mfma keeps its accumulator in place (dst == C); a tile kept in ordinary registers is touched by no other
+    instruction between the first and the last MFMA, and nothing but MFMAs touches the accumulator file in between;
   * no VALU instruction writes a register of an MFMA's A/B operands within the two instructions in front of it
     (the 2 wait states hipcc would have inserted had it seen the MFMA);
-  * every v_accvgpr_read of the epilogue is at least 16 wait states behind the last MFMA (the explicit s_nops).
+  * the epilogue's first read of an accumulator is at least 18 wait states behind the last MFMA (the explicit s_nops).
 """
 import re
 import sys
 
-path = sys.argv[1]
-text = open(path).read()
-kernels = re.findall(r'^(_ZN\S*sepconv_wide_kernel\S*):[^\n]*\n(.*?)s_endpgm', text, re.S | re.M)
-if not kernels:
-    sys.exit('check_wide: no sepconv_wide_kernel instance found in ' + path)
-meta = dict(re.findall(r'\.name:\s+(\S*sepconv_wide_kernel\S*)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)', text))
+kernels = []
+for path in sys.argv[1:]:
+    found = re.findall(r'^(_ZN\S*sepconv_wide\d*_kernel\S*):[^\n]*\n(.*?)s_endpgm', open(path).read(), re.S | re.M)
+    if not found:
+        sys.exit('check_wide: no sepconv_wide*_kernel instance found in ' + path)
+    kernels += found
 bad = []
 rng = re.compile(r'([va])\[(\d+):(\d+)\]|([va])(\d+)\b')
 
@@ -40,14 +41,18 @@ for name, body in kernels:
         bad.append(f'{name}: scratch access ({body.count("scratch_")} instructions)')
     ins = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith((';', '.'))]
     n_mfma = 0
-    last_mfma = None
+    first_mfma = last_mfma = None
+    vacc = set()                        # accumulator tiles kept in ordinary registers
     for k, ln in enumerate(ins):
         if ln.startswith('v_mfma'):
             n_mfma += 1
+            first_mfma = k if first_mfma is None else first_mfma
             last_mfma = k
             ops = [o.strip() for o in ln.split(None, 1)[1].split(',')]
-            if ops[0] != ops[3] or not ops[0].startswith('a['):
+            if ops[0] != ops[3] or not ops[0].startswith(('a[', 'v[')):
                 bad.append(f'{name}: MFMA accumulator not in place: {ln}')
+            if ops[0].startswith('v['):
+                vacc |= regs(ops[0])
             ab = regs(ops[1]) | regs(ops[2])
             for back in (1, 2):
                 if k - back >= 0 and VALU.match(ins[k - back]):
@@ -56,11 +61,44 @@ for name, body in kernels:
                         bad.append(f'{name}: VALU write {ins[k - back]!r} {back} instruction(s) before {ln!r}')
     if n_mfma == 0:
         bad.append(f'{name}: no MFMA found')
-    # the first accumulator read after the last MFMA must be behind >= 16 wait states of s_nop
+        continue
+    for ln in ins[first_mfma:last_mfma]:
+        if not ln.startswith('v_mfma') and ln.split(None, 1)[0][:2] in ('v_', 'ds', 'gl', 'bu', 'fl') and len(ln.split(None, 1)) > 1 \
+                and regs(ln.split(None, 1)[1]) & vacc:
+            bad.append(f'{name}: {ln!r} touches an accumulator tile kept in vector registers inside the loop')
+    # hipcc does not know an asm MFMA's latency: between the first and the last MFMA nothing else may touch the
+    # accumulator file (no copy of a tile out of it, no use of it as spill space)
+    for ln in ins[first_mfma:last_mfma]:
+        if not ln.startswith('v_mfma') and re.search(r'\ba(\[|\d)', ln.split(None, 1)[1] if len(ln.split(None, 1)) > 1 else ''):
+            bad.append(f'{name}: {ln!r} touches the accumulator file between MFMAs')
+    # weight fragments loaded by inline asm (kernels named *wide32*): hipcc does not know the load is asynchronous, so nothing
+    # but an MFMA (behind the hand-written s_waitcnt) may read a register between such a load and its next overwrite
+    pending = set()                     # (the loop only: the prologue also has loads hipcc issues and tracks itself)
+    for ln in ins[first_mfma:last_mfma + 1]:
+        parts = ln.split(None, 1)
+        if len(parts) < 2:
+            continue
+        ops = [o.strip() for o in parts[1].split(',')]
+        if parts[0] == 'global_load_dwordx4' and 'offset' in ln and name.find('wide32') >= 0:
+            pending |= regs(ops[0])
+            continue
+        if parts[0].startswith('v_mfma'):       # behind its hand-written wait: the data has arrived
+            pending -= regs(ops[1]) | regs(ops[2])
+            continue
+        used = regs(parts[1])
+        if parts[0].startswith(('v_', 'ds_read', 'global_load', 'buffer_load')):      # first operand is a destination
+            src = regs(','.join(ops[1:]))
+            if src & pending:
+                bad.append(f'{name}: {ln!r} reads a register of an in-flight asm weight load')
+            pending -= regs(ops[0])
+        elif used & pending:
+            bad.append(f'{name}: {ln!r} reads a register of an in-flight asm weight load')
+    # the first accumulator read after the last MFMA must be behind >= 18 wait states of s_nop
     states = 0
     for ln in ins[last_mfma + 1:]:
-        if ln.startswith('v_accvgpr_read'):
-            if states < 16:
+        touched = len(ln.split(None, 1)) > 1 and bool(regs(ln.split(None, 1)[1]) & vacc)
+        if ln.startswith('v_accvgpr_read') or touched:
+            if states < 18:
                 bad.append(f'{name}: accumulator read {states} wait states after the last MFMA')
             break
         m = re.match(r's_nop\s+(\d+)', ln)

@@ -455,7 +455,14 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     chunk(I0{}, K2{}, std::true_type{}, NCH - 2);
     chunk(I1{}, K1{}, std::false_type{}, NCH - 1);
 
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs have written their accumulators (see mfma16)
+    // The last MFMAs have to have written their accumulators before anything reads them (see mfma16), and hipcc must not
+    // move an accumulator read up in front of these wait states: every tile is an operand of one of the two statements
+    // (an asm statement takes 30 operands; a tied one counts twice).
+#define BQ_ACC_ROW(i) "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5])
+    static_assert(MF == 5 && RN == 6, "operand lists below");
+    asm volatile("s_nop 15\n\ts_nop 15" : BQ_ACC_ROW(0), BQ_ACC_ROW(1), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]));
+    asm volatile("" : "+a"(acc[2][3]), "+a"(acc[2][4]), "+a"(acc[2][5]), BQ_ACC_ROW(3), BQ_ACC_ROW(4));
+#undef BQ_ACC_ROW
     // ---- epilogue: folded BN (+ residual) (+ ReLU), bf16, whole 384-byte row pieces to HBM ----------------------
     // per wave a private staging tile of 80 rows x 192 channels (the loop's buffers are free: every wave is past the
     // closing barrier); the residual tile is copied into it by LDS-DMA, every lane adds its accumulator crumbs in

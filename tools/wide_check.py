@@ -6,7 +6,7 @@ from biscuit_amd.engine import Engine
 from biscuit_amd.synthetic import make_tiles
 from biscuit_amd.weights import synthetic_weights
 TAPS = [('block2_out', (74, 74, 128)), ('block3_sepconv1', (74, 74, 256)), ('block3_sepconv2', (74, 74, 256)), ('block3_out', (37, 37, 256)),
-        ('block4_sepconv1', (37, 37, 728)), ('block4_sepconv2', (37, 37, 728)), ('block4_out', (19, 19, 728)), ('block5_out', (19, 19, 728)),
+        ('block4_sepconv1', (37, 37, 728)), ('block4_sepconv2', (37, 37, 728)), ('block4_out', (19, 19, 728)), ('block5_sepconv1', (19, 19, 728)), ('block5_sepconv2', (19, 19, 728)), ('block5_out', (19, 19, 728)),
         ('block12_out', (19, 19, 728)), ('block13_out', (10, 10, 1024))]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 w = synthetic_weights(1)
