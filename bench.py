@@ -372,7 +372,7 @@ def run(args):
         out['kernels'] = [{'name': e.name, 'launches_per_step': e.launches / psteps,
                            'ms_per_launch': e.ms / e.launches, 'share': e.ms / tot,
                            'tflops': e.flops / (e.ms / e.launches * 1e-3) / 1e12,
-                           'gbps': e.bytes / (e.ms / e.launches * 1e-3) / 1e9} for e in ents[:14]]
+                           'gbps': e.bytes / (e.ms / e.launches * 1e-3) / 1e9} for e in ents[:48]]
 
     if solo and not args.no_extras:
         out['b1_latency'] = b1_latency(eng, args.mc)

@@ -20,7 +20,8 @@ struct Blob { const unsigned char* p = nullptr; size_t n = 0; };
 struct GemmLayer {
     std::string name;
     const void* wp = nullptr;
-    const void* wp16 = nullptr;   // the same weights in 16x16x32 fragment order (728-wide 19x19 layers, kernels_wide.hip)
+    const void* wp16 = nullptr;   // the same weights in 16x16x32 fragment order (728 -> 728 layers, kernels_wide.hip)
+    const void* wp32 = nullptr;   // ... in 32x32x16 fragment order (strided shortcuts, kernels_respool.hip)
     const float* scale = nullptr;
     const float* bias = nullptr;
     const float* dw = nullptr;
@@ -314,6 +315,43 @@ int tap_nhwc(bq_ctx* c, Tap* t, const char* name, const void* buf, int n, int H,
 #define TAP(name, buf, H, W, C, ld) \
     do { int _t = tap_nhwc(c, tap, name, buf, n, H, W, C, ld, s); if (_t) return _t < 0 ? _t : BQ_OK; } while (0)
 
+// End of a block with a strided shortcut: out = maxpool3x3/s2(y) + BN(conv1x1/s2(x)).  bf16: one kernel
+// (kernels_respool.hip) unless the shortcut tensor itself was asked for; otherwise the shortcut goes to `out` first and
+// the pooling pass adds to it in place.  x and out must not overlap.
+int block_end(bq_ctx* c, const char* res_name, const char* pool_name, const void* x, const void* y, void* out, int n,
+              int Hi, int ci, int co, int cout, hipStream_t s, Tap* tap, int* tapped) {
+    const int Ho = (Hi + 1) / 2;
+    const double es = (double)esize(c);
+    auto it = c->layers.find(res_name);
+    if (it == c->layers.end()) return fail(c, BQ_ERR_WEIGHTS, std::string("layer not loaded: ") + res_name);
+    const GemmLayer& L = it->second;
+    const bool want_res = tap && tap->want && strcmp(tap->want, res_name) == 0;
+    static const bool no_fuse = bq_exp_env("BQ_NO_RESPOOL") != nullptr;
+    *tapped = 0;
+    // measured per batch of 256 (one stream): block 2 0.62 -> 0.46 ms, block 3 0.34 -> 0.27 ms; block 4 (K = 256, six
+    // 128-channel workgroups per pixel tile) 0.26 -> 0.34 ms and block 13 0.19 -> 0.20 ms stay on the two-kernel path
+    static const bool fuse_all = bq_exp_env("BQ_RESPOOL_ALL") != nullptr;
+    if (c->cfg.dtype == BQ_DTYPE_BF16 && L.wp32 && !want_res && !no_fuse && (L.kpad <= 128 || fuse_all)) {
+        const double px = (double)n * Ho * Ho;
+        ProfScope ps(c, s, std::string("respool_") + std::to_string(Hi) + "_c" + std::to_string(cout),
+                     2.0 * px * L.cin * L.cout + 9.0 * px * co,
+                     es * ((double)n * Hi * Hi * co + px * co + px * ci) + es * (double)L.cin * L.cout);
+        const int e = launch_respool(x, L.wp32, L.scale, L.bias, y, out, n, Hi, Hi, L.kpad, ci, co, L.nfp, s);
+        if (e) return fail(c, BQ_ERR_HIP, std::string("launch(respool) ") + res_name + ": " + hipGetErrorString((hipError_t)e));
+        return BQ_OK;
+    }
+    {
+        const int r = run_conv(c, {res_name, PROD_S2, x, out, nullptr, nullptr, n, Ho, Ho, Hi, Hi, ci, co, 0}, s);
+        if (r != BQ_OK) return r;
+        const int t = tap_nhwc(c, tap, res_name, out, n, Ho, Ho, cout, co, s);
+        if (t) { *tapped = 1; return t < 0 ? t : BQ_OK; }
+    }
+    const double px = (double)n * Ho * Ho * co;
+    ProfScope ps(c, s, pool_name, 9.0 * px, es * ((double)n * Hi * Hi * co + 2.0 * px));
+    if (launch_pool_add(y, out, out, n, Hi, Hi, co, c->cfg.dtype, s)) return fail(c, BQ_ERR_HIP, "pool_add launch failed");
+    return BQ_OK;
+}
+
 // Stem + entry flow (blocks 1-4) of n tiles.  A/B/C/R are scratch for n tiles; the block-4 output
 // (19x19x736 per tile) goes to out4.  Returns 1 if a debug tap matched (caller stops).
 int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void* B, void* C, void* R,
@@ -337,35 +375,30 @@ int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void*
     RUN(run_conv(c, {"block1_conv2", PROD_IM2COL, A, B, nullptr, nullptr, n, 147, 147, 149, 149, 32, 64, 1}, s));
     TAP("block1_conv2", B, 147, 147, 64, 64);
 
-    // entry flow: blocks 2-4.  x lives in B.
-    // (Folding the max-pool + add into the residual kernel's store pass was measured at
-    // +1.2 ms/batch: the 9-tap gather serialises behind the GEMM; kept as separate kernels.)
+    // entry flow: blocks 2-4.  The block's input lives in `cur`, its output goes to `nxt` (block 4: out4)
     struct Entry { int block, cin, cout, Hi; };
     const Entry entry[3] = {{2, 64, 128, 147}, {3, 128, 256, 74}, {4, 256, 728, 37}};
+    void* cur = B; void* nxt = R;
     for (const Entry& e : entry) {
         const int Ho = (e.Hi + 1) / 2;
         const int ci = pad16(e.cin), co = pad16(e.cout);
-        char nm[64], tn[64];
-        snprintf(nm, sizeof nm, "block%d_res", e.block);
-        RUN(run_conv(c, {nm, PROD_S2, B, R, nullptr, nullptr, n, Ho, Ho, e.Hi, e.Hi, ci, co, 0}, s));
-        TAP(nm, R, Ho, Ho, e.cout, co);
+        char nm[64], rn[64], tn[64];
         snprintf(nm, sizeof nm, "block%d_sepconv1", e.block);
-        RUN(run_conv(c, {nm, e.block == 2 ? PROD_DW : PROD_DW_RELU, B, A, nullptr, nullptr, n, e.Hi, e.Hi,
+        RUN(run_conv(c, {nm, e.block == 2 ? PROD_DW : PROD_DW_RELU, cur, A, nullptr, nullptr, n, e.Hi, e.Hi,
                          e.Hi, e.Hi, ci, co, 1}, s));
         TAP(nm, A, e.Hi, e.Hi, e.cout, co);
         snprintf(nm, sizeof nm, "block%d_sepconv2", e.block);
         RUN(run_conv(c, {nm, PROD_DW, A, C, nullptr, nullptr, n, e.Hi, e.Hi, e.Hi, e.Hi, co, co, 0}, s));
         TAP(nm, C, e.Hi, e.Hi, e.cout, co);
-        {
-            const double px = (double)n * Ho * Ho * co;
-            snprintf(tn, sizeof tn, "maxpool_add_%d_c%d", e.Hi, e.cout);
-            ProfScope ps(c, s, tn, 9.0 * px, es * ((double)n * e.Hi * e.Hi * co + 2.0 * px));
-            void* dst = e.block == 4 ? out4 : B;
-            if (launch_pool_add(C, R, dst, n, e.Hi, e.Hi, co, dt, s))
-                return fail(c, BQ_ERR_HIP, "pool_add launch failed");
-        }
+        void* dst = e.block == 4 ? out4 : nxt;
+        snprintf(rn, sizeof rn, "block%d_res", e.block);
+        snprintf(tn, sizeof tn, "maxpool_add_%d_c%d", e.Hi, e.cout);
+        int tapped = 0;
+        RUN(block_end(c, rn, tn, cur, C, dst, n, e.Hi, ci, co, e.cout, s, tap, &tapped));
+        if (tapped) return BQ_OK;
         snprintf(nm, sizeof nm, "block%d_out", e.block);
-        TAP(nm, e.block == 4 ? out4 : B, Ho, Ho, e.cout, co);
+        TAP(nm, dst, Ho, Ho, e.cout, co);
+        void* t = cur; cur = nxt; nxt = t;
     }
     return BQ_OK;
 }
@@ -384,9 +417,13 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     int sub = (tap && tap->want) ? n : env_sub;
     if (sub <= 0 || sub > n / 2) sub = n;
     const size_t tile4 = (size_t)361 * 736 * esize(c);
-    unsigned char* X4 = sub == n ? (unsigned char*)B : (unsigned char*)B + (size_t)(n / 2) * kMaxAct * esize(c);
+    // Block 4 reads its input from B (blocks 2-4 alternate between B and R) and must not write over it: in one piece
+    // its output goes to R, and B is the scratch buffer S of the middle and exit flow; in sub-batches it goes to the
+    // upper half of B, which no sub-batch touches.
+    unsigned char* X4 = sub == n ? (unsigned char*)R : (unsigned char*)B + (size_t)(n / 2) * kMaxAct * esize(c);
+    void* S = sub == n ? B : R;
     if (sub == n) {
-        RUN(entry_flow(c, in_nchw, n, B, A, B, C, R, s, tap));
+        RUN(entry_flow(c, in_nchw, n, X4, A, B, C, R, s, tap));
         if (tap && tap->written >= 0) return BQ_OK;
     } else {
         for (int i0 = 0; i0 < n; i0 += sub) {
@@ -400,30 +437,29 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     for (int block = 5; block <= 12; ++block) {
         char nm[64];
         snprintf(nm, sizeof nm, "block%d_sepconv1", block);
-        RUN(run_conv(c, {nm, PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1, R}, s));
+        RUN(run_conv(c, {nm, PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1, S}, s));
         TAP(nm, Y, 19, 19, 728, 736);
         snprintf(nm, sizeof nm, "block%d_sepconv2", block);
-        RUN(run_conv(c, {nm, PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1, R}, s));
+        RUN(run_conv(c, {nm, PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1, S}, s));
         TAP(nm, C, 19, 19, 728, 736);
         snprintf(nm, sizeof nm, "block%d_sepconv3", block);
-        RUN(run_conv(c, {nm, PROD_DW, C, Y, X, nullptr, n, 19, 19, 19, 19, 736, 736, 0, R}, s));
+        RUN(run_conv(c, {nm, PROD_DW, C, Y, X, nullptr, n, 19, 19, 19, 19, 736, 736, 0, S}, s));
         void* t = X; X = Y; Y = t;
         snprintf(nm, sizeof nm, "block%d_out", block);
         TAP(nm, X, 19, 19, 728, 736);
     }
     // exit flow
-    RUN(run_conv(c, {"block13_res", PROD_S2, X, R, nullptr, nullptr, n, 10, 10, 19, 19, 736, 1024, 0}, s));
     RUN(run_conv(c, {"block13_sepconv1", PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1}, s));
     RUN(run_conv(c, {"block13_sepconv2", PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 1024, 0}, s));
-    {
-        const double px = (double)n * 100 * 1024;
-        ProfScope ps(c, s, "maxpool_add_19_c1024", 9.0 * px, es * ((double)n * 361 * 1024 + 2.0 * px));
-        if (launch_pool_add(C, R, X, n, 19, 19, 1024, dt, s)) return fail(c, BQ_ERR_HIP, "pool_add launch failed");
+    {   // the block's output goes to S (X is its input); X is scratch from here on
+        int tapped = 0;
+        RUN(block_end(c, "block13_res", "maxpool_add_19_c1024", X, C, S, n, 19, 736, 1024, 1024, s, tap, &tapped));
+        if (tapped) return BQ_OK;
     }
-    TAP("block13_out", X, 10, 10, 1024, 1024);
-    RUN(run_conv(c, {"block14_sepconv1", PROD_DW, X, Y, nullptr, C, n, 10, 10, 10, 10, 1024, 1536, 1, R}, s));
+    TAP("block13_out", S, 10, 10, 1024, 1024);
+    RUN(run_conv(c, {"block14_sepconv1", PROD_DW, S, Y, nullptr, C, n, 10, 10, 10, 10, 1024, 1536, 1, X}, s));
     TAP("block14_sepconv1", Y, 10, 10, 1536, 1536);
-    RUN(run_conv(c, {"block14_sepconv2", PROD_DW, Y, C, nullptr, X, n, 10, 10, 10, 10, 1536, 2048, 1, R}, s));
+    RUN(run_conv(c, {"block14_sepconv2", PROD_DW, Y, C, nullptr, S, n, 10, 10, 10, 10, 1536, 2048, 1, X}, s));
     TAP("block14_sepconv2", C, 10, 10, 2048, 2048);
     {
         ProfScope ps(c, s, "global_avg_pool", (double)n * 100 * 2048, es * (double)n * 100 * 2048 + 4.0 * n * 2048);
@@ -509,6 +545,12 @@ int register_gemm_layer(bq_ctx* c, const std::string& name, int cin, int cout, i
         if (w16->second.n != (size_t)(kpad / 32) * ((size_t)L.nfp * 2) * 1024)
             return fail(c, BQ_ERR_WEIGHTS, "bad size for " + name + "/wp16");
         L.wp16 = w16->second.p;
+    }
+    auto w32 = c->entries.find(name + "/wp32");
+    if (w32 != c->entries.end()) {
+        if (w32->second.n != (size_t)(kpad / 16) * (size_t)L.nfp * 1024)
+            return fail(c, BQ_ERR_WEIGHTS, "bad size for " + name + "/wp32");
+        L.wp32 = w32->second.p;
     }
     L.scale = entry_f32(c, name + "/scale");
     L.bias = entry_f32(c, name + "/bias");

@@ -111,6 +111,8 @@ int launch_stem1(const void* in_nchw, int n, const float* w27x32, const float* s
                  const float* bias, void* out_nhwc, int dtype, hipStream_t s);
 int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, int Wi, int C,
                     int dtype, hipStream_t s);
+int launch_respool(const void* x, const void* wp32, const float* scale, const float* bias, const void* y, void* out,
+                   int n, int Hi, int Wi, int K, int ldx, int ld, int nf32, hipStream_t s);
 int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s);
 int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, const long long* tile0_dev,
                       unsigned seed_lo, unsigned seed_hi, unsigned thresh, float dscale,

@@ -233,6 +233,19 @@ def pack_fragments16(wkn, kpad, npad):
     return np.ascontiguousarray(t).reshape(kpad // 32, npad // 16, 64, 8)
 
 
+def pack_fragments32(wkn, kpad, npad):
+    """W[K][N] -> v_mfma_f32_32x32x16 fragment order [KS][NF32][64][8] float32 (zero padded): k-step ks (16 deep), 32-wide
+    n-fragment nf, lane = h*32 + r holds W[k = ks*16 + h*8 + v][n = nf*32 + r] in element v.  All fragments of one
+    k-step are contiguous."""
+    k, n = wkn.shape
+    assert kpad % 16 == 0 and kpad >= k and npad % 32 == 0 and npad >= n
+    full = np.zeros((kpad, npad), np.float32)
+    full[:k, :n] = wkn
+    t = full.reshape(kpad // 16, 2, 8, npad // 32, 32)      # [ks][h][v][nf][r]
+    t = t.transpose(0, 3, 1, 4, 2)                          # [ks][nf][h][r][v]
+    return np.ascontiguousarray(t).reshape(kpad // 16, npad // 32, 64, 8)
+
+
 def wide_layers():
     """The 26 separable convolutions 728 -> 728 of kernels_wide.hip: block4_sepconv2 (37x37 maps), blocks 5-12 and
     block13_sepconv1 (19x19 maps)."""
@@ -279,6 +292,10 @@ def pack_blob(w, dtype='bf16'):
     add_affine('block1_conv2', s, b, npad)
     for name, cin, cout in residual_plan():
         npad = add_mat(name, w[name + '_conv/kernel'].reshape(cin, cout), pad_channels(cin))
+        if dtype == 'bf16' and npad % 128 == 0 and cin <= 128:   # kernels_respool.hip: shortcut conv + max-pool + add
+            # in one kernel (blocks 2 and 3; the wider shortcuts measured faster as two kernels)
+            add(name + '/wp32', f32_to_bf16_bits(pack_fragments32(w[name + '_conv/kernel'].reshape(cin, cout),
+                                                                  pad_channels(cin), npad)))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)
     wide = set(wide_layers())

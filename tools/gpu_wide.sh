@@ -2,7 +2,7 @@
 # parity of the bf16 path (per layer, end to end) and the per-kernel timing table
 mkdir -p gpurun_out
 ( timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -x -k "every_layer or end_to_end or ragged or golden or full_size or full_mode" 2>&1 | grep -v amdgpu.ids | tail -25 ) > gpurun_out/pytest_wide.log 2>&1
-( timeout 600 python bench.py --no-extras --no-cpu-baseline --steps 10 2>gpurun_out/bench_wide.err | tail -1 ) > gpurun_out/bench_wide.json
+( timeout 600 python bench.py --no-extras --no-cpu-baseline --steps 10 --streams 1 2>gpurun_out/bench_wide.err | tail -1 ) > gpurun_out/bench_wide.json
 tail -12 gpurun_out/pytest_wide.log | cut -c1-300
 python - <<'PY'
 import json
