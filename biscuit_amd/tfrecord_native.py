@@ -29,6 +29,8 @@ ABI = {
     'bqio_image_bytes': (_i, [_vp, _i64, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
     'bqio_decode': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
     'bqio_masked_crc32c': (C.c_uint32, [C.c_char_p, C.c_size_t]),
+    'bqio_inflate': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t]),
+    'bqio_inflate_fallbacks': (_i64, []),
 }
 
 
@@ -55,6 +57,22 @@ def lib():
 
 def available():
     return os.path.exists(LIB_PATH)
+
+
+def inflate(zdata, out_len):
+    """The reader's own zlib-stream decompressor (csrc/inflate_fast.h): ``zlib.decompress(zdata)`` when that has exactly
+    ``out_len`` bytes, ValueError for anything zlib would refuse.  For tests."""
+    import numpy as np
+    out = np.empty(out_len, np.uint8)
+    e = lib().bqio_inflate(bytes(zdata), len(zdata), out.ctypes.data, out_len)
+    if e != 0:
+        raise ValueError(f'bqio_inflate: error {e}')
+    return out.tobytes()
+
+
+def inflate_fallbacks():
+    """Streams handed to zlib after the reader's own decompressor refused them although zlib accepts them (0 = none)."""
+    return int(lib().bqio_inflate_fallbacks())
 
 
 class UnsupportedImage(ValueError):

@@ -55,6 +55,15 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
 /* masked CRC-32C of a buffer (the TFRecord checksum), exported for tests and writers. */
 uint32_t bqio_masked_crc32c(const uint8_t* data, size_t len);
 
+/* The reader's own zlib-stream decompressor (csrc/inflate_fast.h), exported for tests: inflates `n` bytes at zdata into
+ * exactly out_len bytes at out.  BQIO_OK, or BQIO_ERR_CORRUPT for anything zlib's uncompress() would refuse (bad header,
+ * invalid or over-subscribed codes, a distance before the start, wrong length, Adler-32 mismatch, trailing bytes). */
+int bqio_inflate(const uint8_t* zdata, size_t n, uint8_t* out, size_t out_len);
+
+/* How many PNG streams bqio_decode handed to zlib after the decompressor above refused them and zlib accepted them
+ * (process-wide).  Always 0 unless that decompressor has a bug; the tests assert it. */
+int64_t bqio_inflate_fallbacks(void);
+
 #ifdef __cplusplus
 }
 #endif

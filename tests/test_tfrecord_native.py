@@ -175,3 +175,117 @@ def test_mutated_files_never_crash(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(tn.LIB_PATH)))
     out = subprocess.run([sys.executable, '-c', code] + paths, capture_output=True, text=True, cwd=root, timeout=300)
     assert out.returncode == 0 and 'survived' in out.stdout, out.stderr[-500:]
+
+
+# ---- the reader's own zlib-stream decompressor (csrc/inflate_fast.h) against zlib ------------------------------------
+def _streams():
+    import zlib
+    rng = np.random.default_rng(11)
+    walk = np.clip(np.cumsum(rng.integers(-3, 4, 70000)), 0, 255).astype(np.uint8).tobytes()
+    datas = [b'', b'a', b'ab' * 5, bytes(rng.integers(0, 256, 1000, dtype=np.uint8)), (b'hello world, ' * 6000)[:70000],
+             bytes(rng.integers(0, 2, 66000, dtype=np.uint8)), walk, bytes(rng.integers(0, 256, 70000, dtype=np.uint8))]
+    for d in datas:
+        for level in (0, 1, 6, 9):
+            for strat in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+                co = zlib.compressobj(level=level, strategy=strat)
+                yield d, co.compress(d) + co.flush()
+        co = zlib.compressobj(level=6, wbits=9)               # 512-byte window: short distances only
+        yield d, co.compress(d) + co.flush()
+
+
+def test_inflate_equals_zlib():
+    """Stored, fixed and dynamic blocks, every strategy zlib has, empty to multi-block inputs: identical bytes."""
+    n = 0
+    for data, z in _streams():
+        assert tn.inflate(z, len(data)) == data
+        n += 1
+    assert n == 8 * 21
+
+
+def test_inflate_rejects_what_zlib_rejects():
+    """Flipped bits, truncations, wrong expected length, trailing bytes: the verdict is zlib's (and when both accept,
+    the bytes are the same)."""
+    import random
+    import zlib
+    data, z = next(s for s in _streams() if len(s[0]) == 70000 and len(s[1]) < 40000)
+    rnd = random.Random(3)
+    verdicts = [0, 0]
+    for t in range(1500):
+        b = bytearray(z)
+        for _ in range(rnd.choice([1, 1, 3])):
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        if t % 5 == 0:
+            b = b[:rnd.randrange(len(b))]
+        try:
+            ref = zlib.decompress(bytes(b))
+            ref_ok = len(ref) == len(data)
+        except zlib.error:
+            ref_ok = False
+        try:
+            got = tn.inflate(bytes(b), len(data))
+            ok = True
+        except ValueError:
+            ok = False
+        assert ok == ref_ok, t
+        if ok:
+            assert got == ref
+        verdicts[ok] += 1
+    assert verdicts[0] > 1000
+    for bad in (z + b'\0', z[:-1], z[:2] + z[3:]):
+        with pytest.raises(ValueError):
+            tn.inflate(bad, len(data))
+    with pytest.raises(ValueError):
+        tn.inflate(z, len(data) + 1)
+    with pytest.raises(ValueError):
+        tn.inflate(z, len(data) - 1)
+    with pytest.raises(ValueError):
+        tn.inflate(b'\x78\x9c' + b'\x07' * 20, 10)          # reserved block type
+
+
+def test_every_png_filter_and_no_zlib_fallback(tmp_path):
+    """Scanline filters None/Sub/Up/Average/Paeth forced one at a time (hand-made PNGs: Pillow picks filters itself),
+    for grey, RGB and RGBA, against the arrays they encode; and the decoder never needed zlib as a second opinion."""
+    import zlib
+    rng = np.random.default_rng(4)
+    px = 64
+
+    def png(arr, ftype, ctype):
+        h, w = arr.shape[:2]
+        rows = arr.reshape(h, -1).astype(np.int32)
+        bpp = rows.shape[1] // w
+        out = bytearray()
+        prev = np.zeros_like(rows[0])
+        for y in range(h):
+            cur = rows[y]
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+            ul = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+            if ftype == 0: f = cur
+            elif ftype == 1: f = cur - left
+            elif ftype == 2: f = cur - prev
+            elif ftype == 3: f = cur - ((left + prev) >> 1)
+            else:
+                p = left + prev - ul
+                pa, pb, pc = abs(p - left), abs(p - prev), abs(p - ul)
+                f = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+            out += bytes([ftype]) + (f & 255).astype(np.uint8).tobytes()
+            prev = cur
+
+        def chunk(t, d):
+            return struct.pack('>I', len(d)) + t + d + struct.pack('>I', zlib.crc32(t + d))
+        return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', w, h, 8, ctype, 0, 0, 0)) +
+                chunk(b'IDAT', zlib.compress(bytes(out), 6)) + chunk(b'IEND', b''))
+
+    base = (rng.integers(0, 256, (px, px, 4)) // 8 * 8).astype(np.uint8)
+    base[:, : px // 2] = np.linspace(0, 255, px // 2, dtype=np.uint8)[None, :, None]
+    payloads, want = [], []
+    for ctype, arr in ((0, base[..., 0]), (2, base[..., :3]), (6, base)):
+        for ftype in range(5):
+            payloads.append(png(arr, ftype, ctype))
+            want.append(np.repeat(arr[..., None], 3, 2) if ctype == 0 else arr[..., :3])
+    path = str(tmp_path / 'filters.tfrecords')
+    _write(path, payloads)
+    before = tn.inflate_fallbacks()
+    with tn.NativeReader(path) as r:
+        got, _ = r.decode(tile_px=px)
+    np.testing.assert_array_equal(got, np.stack(want))
+    assert tn.inflate_fallbacks() == before == 0
