@@ -157,7 +157,7 @@ struct BitReader {
         cnt |= 56;
     }
     unsigned peek(int n) const { return (unsigned)(buf & ((1ull << n) - 1)); }
-    void drop(unsigned n) { buf >>= n; cnt -= n; }
+    void drop(unsigned n) { buf >>= (n & 63); cnt -= n; }    // & 63: what the shift instruction does anyway, so no mask is emitted
     unsigned take(int n) { const unsigned v = peek(n); drop((unsigned)n); return v; }
     const uint8_t* position() const { return in - (cnt >> 3); }   // first byte not consumed
 };

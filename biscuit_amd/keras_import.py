@@ -11,7 +11,11 @@ labels.  ``load_model_dir`` turns that directory into the canonical weight dict 
   * variables are read with ``tf_bundle.BundleReader``; optimizer slots, metrics and counters are skipped;
   * object-based checkpoints name variables by their path from the model object
     (``layer_with_weights-0/layer_with_weights-7/depthwise_kernel/.ATTRIBUTES/VARIABLE_VALUE``), not by
-    layer name, so layers are put in order by those indices (nested models expand in place) and matched
+    layer name.  When the SavedModel carries ``keras_metadata.pb`` (TF >= 2.5) and the checkpoint its object graph,
+    every layer is bound BY NAME: the metadata gives the Keras name of each object path, the object graph says which
+    object a ``layer_with_weights-N`` path is (``block5_sepconv2_bn`` is that layer wherever Keras numbers it; the
+    automatically named ``conv2d[_k]`` / ``batch_normalization[_k]`` of the four shortcuts are taken in the order of
+    their suffixes).  Without it, layers are put in order by those indices (nested models expand in place) and matched
     to the architecture of keras.applications.Xception + Slideflow's two hidden layers by kind and shape:
     the 3x3 convolutions are ``block1_conv1/2``, the separable convolutions are ``sepconv_plan()`` in order,
     the 1x1 convolutions the four residual branches in order, the dense layers ``hidden_0``, ``hidden_1``,
@@ -91,7 +95,8 @@ def _collect_layers(reader):
     if not layers:
         raise ImportError_('no layer_with_weights-N/... variables in the checkpoint '
                            f'(keys look like {reader.keys()[:3]}): not an object-based Keras checkpoint')
-    return [layers[k] for k in sorted(layers)], skipped
+    order = sorted(layers)
+    return [layers[k] for k in order], order, skipped
 
 
 def _kind(vars_, reader):
@@ -106,16 +111,87 @@ def _kind(vars_, reader):
     return None
 
 
+def _keras_names(reader, prefix):
+    """{layer_with_weights index path: Keras layer name} from ``keras_metadata.pb`` + the checkpoint's object graph, or
+    None when either is missing."""
+    cands = [os.path.join(prefix, 'keras_metadata.pb'), os.path.join(os.path.dirname(os.path.abspath(prefix)), 'keras_metadata.pb'),
+             os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(prefix))), 'keras_metadata.pb')]
+    meta = next((c for c in cands if os.path.isfile(c)), None)
+    graph = reader.object_graph()
+    if meta is None or not graph:
+        return None
+    nodes = tf_bundle.parse_object_graph(graph)
+    if not nodes:
+        return None
+    name_of_path = {r['node_path']: r['metadata'].get('name') for r in tf_bundle.parse_saved_metadata(open(meta, 'rb').read())
+                    if isinstance(r['metadata'], dict) and r['metadata'].get('name')}
+    # every path from the root through layer-K / layer_with_weights-N children, per node
+    name_of_node, weighted = {}, {}
+    stack, seen = [(0, 'root', ())], set()
+    while stack:
+        nid, path, wpath = stack.pop()
+        if path in name_of_path:
+            name_of_node.setdefault(nid, name_of_path[path])
+        if wpath is not None and wpath:
+            weighted[wpath] = nid
+        if (nid, wpath) in seen or nid >= len(nodes):
+            continue
+        seen.add((nid, wpath))
+        for child, cid in nodes[nid]['children'].items():
+            m = re.fullmatch(r'layer_with_weights-(\d+)', child)
+            if m:
+                stack.append((cid, f'{path}.{child}', None if wpath is None else wpath + (int(m.group(1)),)))
+            elif re.fullmatch(r'layer-\d+', child):
+                stack.append((cid, f'{path}.{child}', None))
+    names = {wp: name_of_node.get(nid) for wp, nid in weighted.items()}
+    return names if all(names.values()) and names else None
+
+
+def _bind_by_name(layers, keys, kinds, names, reader):
+    """{layer index: canonical layer name} for convolutions, separable convolutions and BatchNormalizations from their
+    Keras names; the dense layers keep their order."""
+    def suffix(n, base):
+        return int(n[len(base) + 1:] or 0) if n != base else 0
+    out = {}
+    auto_conv = sorted((suffix(names[k], 'conv2d'), i) for i, k in enumerate(keys) if re.fullmatch(r'conv2d(_\d+)?', names[k]))
+    auto_bn = sorted((suffix(names[k], 'batch_normalization'), i) for i, k in enumerate(keys)
+                     if re.fullmatch(r'batch_normalization(_\d+)?', names[k]))
+    plan_r = W.residual_plan()
+    if len(auto_conv) != len(plan_r) or len(auto_bn) != len(plan_r):
+        raise ImportError_(f'{len(auto_conv)} conv2d / {len(auto_bn)} batch_normalization layers with automatic names; '
+                           f'the four shortcuts of keras.applications.Xception have one of each')
+    for n, (_, i) in enumerate(auto_conv):
+        out[i] = plan_r[n][0] + '_conv'
+    for n, (_, i) in enumerate(auto_bn):
+        out[i] = plan_r[n][0] + '_bn'
+    want = {name for name, kind in keras_layer_order() if kind != 'dense'}
+    for i, k in enumerate(keys):
+        if i in out or kinds[i] == 'dense':
+            continue
+        if names[k] not in want:
+            raise ImportError_(f'layer {names[k]!r} ({kinds[i]}) is not a layer of keras.applications.Xception')
+        out[i] = names[k]
+    if len(set(out.values())) != len(out):
+        raise ImportError_('two layers of the checkpoint carry the same Keras name')
+    return out
+
+
 def from_bundle(prefix, verify=True):
     """Canonical weight dict from a checkpoint prefix / ``variables`` directory / SavedModel directory."""
     reader = tf_bundle.BundleReader(prefix, verify=verify)
-    layers, _ = _collect_layers(reader)
+    layers, keys, skipped = _collect_layers(reader)
+    if skipped:
+        raise ImportError_(f'{len(skipped)} variables outside the layer_with_weights-N tree (first: {skipped[0]}): '
+                           'not the hp.nature2022 classifier, or a layout this importer does not know')
     kinds = []
     for n, lv in enumerate(layers):
         k = _kind(lv, reader)
         if k is None:
             raise ImportError_(f'layer {n} has variables {sorted(lv)}: not a layer of the Xception classifier')
         kinds.append(k)
+    names = _keras_names(reader, prefix)
+    if names is not None and all(k in names for k in keys):
+        return _assemble_named(layers, kinds, _bind_by_name(layers, keys, kinds, names, reader), reader)
     convs3 = [i for i, (k, lv) in enumerate(zip(kinds, layers)) if k == 'conv' and reader.shape(lv['kernel'])[:2] == (3, 3)]
     convs1 = [i for i, (k, lv) in enumerate(zip(kinds, layers)) if k == 'conv' and reader.shape(lv['kernel'])[:2] == (1, 1)]
     seps = [i for i, k in enumerate(kinds) if k == 'sep']
@@ -164,6 +240,30 @@ def from_bundle(prefix, verify=True):
             if 'bias' in lv:        # y = BN(conv + b): fold the bias into the moving mean
                 w[f'{bn_name(name)}/moving_mean'] = w[f'{bn_name(name)}/moving_mean'] - reader.tensor(lv['bias']).astype(np.float32)
     n_classes = int(w['logits/kernel'].shape[-1]) if w['logits/kernel'].ndim == 2 else -1
+    try:
+        return W.validate(w, n_classes)
+    except ValueError as e:
+        raise ImportError_(str(e)) from None
+
+
+def _assemble_named(layers, kinds, name_of, reader):
+    """Canonical dict from {layer index: canonical name} (name-bound checkpoints)."""
+    dense = [i for i, k in enumerate(kinds) if k == 'dense']
+    if len(dense) != 3:
+        raise ImportError_(f'found {len(dense)} dense layers; hp.nature2022 (biscuit/hp.py:13,21) has hidden_layers=2 + logits')
+    name_of = dict(name_of)
+    name_of.update({dense[0]: 'hidden_0', dense[1]: 'hidden_1', dense[2]: 'logits'})
+    w, conv_bias = {}, {}
+    for i, name in name_of.items():
+        for var, key in layers[i].items():
+            if var == 'bias' and kinds[i] in ('conv', 'sep'):
+                conv_bias[name] = reader.tensor(key).astype(np.float32)
+            else:
+                w[f'{name}/{var}'] = reader.tensor(key).astype(np.float32)
+    for name, b in conv_bias.items():                 # y = BN(conv + b): fold the bias into the moving mean
+        bn = name[:-len('_conv')] + '_bn' if name.endswith('_res_conv') else name + '_bn'
+        w[f'{bn}/moving_mean'] = w[f'{bn}/moving_mean'] - b
+    n_classes = int(w['logits/kernel'].shape[-1]) if w.get('logits/kernel', np.zeros(0)).ndim == 2 else -1
     try:
         return W.validate(w, n_classes)
     except ValueError as e:
@@ -258,25 +358,53 @@ def load_model_dir(model_dir, verify=True):
     return from_bundle(model_dir, verify=verify), read_params(model_dir)
 
 
-def export_bundle(prefix, w, nested=True, optimizer_slots=False):
+def export_bundle(prefix, w, nested=True, optimizer_slots=False, metadata=None, order=None):
     """Write the canonical dict as an object-based Keras checkpoint in Keras' layer order (the inverse of
     ``from_bundle``; ``nested`` puts the backbone under ``layer_with_weights-0`` like a base model called
-    inside the classifier).  Test fixture generator and an exit path back to TensorFlow."""
-    tensors = {'_CHECKPOINTABLE_OBJECT_GRAPH': b'', 'save_counter' + _SUFFIX: np.asarray(1, np.int64)}
+    inside the classifier).  ``metadata``: also write the object graph and this ``keras_metadata.pb`` path with the Keras
+    layer names; ``order``: the weighted layers in another numbering (a permutation of ``keras_layer_order()``).
+    Test fixture generator and an exit path back to TensorFlow."""
+    tensors = {'save_counter' + _SUFFIX: np.asarray(1, np.int64)}
     idx_backbone = idx_top = 0
-    for name, kind in keras_layer_order():
-        if kind == 'dense' or not nested:
-            path = f'layer_with_weights-{(idx_top + 1) if nested else idx_top}'
+    res_block = {name: n for n, (name, _, _) in enumerate(W.residual_plan())}
+    nodes = [{'children': {}, 'attributes': {}}]               # object graph: root, [backbone model], layers
+    records = [{'node_id': 0, 'node_path': 'root', 'identifier': '_tf_keras_network', 'metadata': {'name': 'model'}}]
+    if nested:
+        nodes.append({'children': {}, 'attributes': {}})
+        nodes[0]['children']['layer_with_weights-0'] = 1
+        nodes[0]['children']['layer-1'] = 1
+        records.append({'node_id': 1, 'node_path': 'root.layer-1', 'identifier': '_tf_keras_network', 'metadata': {'name': 'xception'}})
+    for name, kind in (order or keras_layer_order()):
+        top = kind == 'dense' or not nested
+        if top:
+            n = (idx_top + 1) if nested else idx_top
+            path, parent, ppath = f'layer_with_weights-{n}', 0, 'root'
             idx_top += 1
         else:
-            path = f'layer_with_weights-0/layer_with_weights-{idx_backbone}'
+            n = idx_backbone
+            path, parent, ppath = f'layer_with_weights-0/layer_with_weights-{n}', 1, 'root.layer-1'
             idx_backbone += 1
+        nid = len(nodes)
+        nodes.append({'children': {}, 'attributes': {}})
+        nodes[parent]['children'][f'layer_with_weights-{n}'] = nid
+        nodes[parent]['children'][f'layer-{2 * n + 2}'] = nid          # some layers without weights in between
+        base = name[:-len('_conv')] if name.endswith('_res_conv') else name[:-len('_bn')] if name.endswith('_res_bn') else None
+        keras_name = name
+        if base in res_block:                                    # Keras' automatic names, offset as after earlier models
+            keras_name = ('conv2d' if name.endswith('_conv') else 'batch_normalization') + f'_{res_block[base] + 5}'
+        records.append({'node_id': nid, 'node_path': f'{ppath}.layer-{2 * n + 2}', 'identifier': '_tf_keras_layer',
+                        'metadata': {'name': keras_name, 'class_name': kind}})
         for k, v in w.items():
             layer, _, var = k.partition('/')
             if layer == name:
                 tensors[f'{path}/{var}{_SUFFIX}'] = np.asarray(v, np.float32)
+                nodes[nid]['attributes'][var] = f'{path}/{var}{_SUFFIX}'
                 if optimizer_slots and var in ('kernel', 'pointwise_kernel'):
                     tensors[f'{path}/{var}/.OPTIMIZER_SLOT/optimizer/m{_SUFFIX}'] = np.zeros_like(v, np.float32)
     if optimizer_slots:
         tensors['optimizer/iter' + _SUFFIX] = np.asarray(7, np.int64)
+    tensors['_CHECKPOINTABLE_OBJECT_GRAPH'] = tf_bundle.build_object_graph(nodes) if metadata else b''
     tf_bundle.write_bundle(prefix, tensors)
+    if metadata:
+        with open(metadata, 'wb') as f:
+            f.write(tf_bundle.build_saved_metadata(records))

@@ -408,3 +408,58 @@ def parse_object_graph(buf):
                 node['attributes'][name] = key
         nodes.append(node)
     return nodes
+
+
+def _ld(field, payload):
+    """One length-delimited protobuf field."""
+    return _put_varint(field << 3 | 2) + _put_varint(len(payload)) + bytes(payload)
+
+
+def build_object_graph(nodes):
+    """Inverse of ``parse_object_graph`` (test fixtures, ``keras_import.export_bundle``)."""
+    out = b''
+    for node in nodes:
+        body = b''
+        for name, nid in node.get('children', {}).items():
+            body += _ld(1, _put_varint(1 << 3) + _put_varint(nid) + _ld(2, name.encode()))
+        for name, key in node.get('attributes', {}).items():
+            body += _ld(2, _ld(1, name.encode()) + _ld(3, key.encode()))
+        out += _ld(1, body)
+    return out
+
+
+# ---------------------------------------------------------------------------------- keras_metadata.pb
+def parse_saved_metadata(buf):
+    """``keras_metadata.pb`` (tensorflow/python/keras/protobuf/saved_metadata.proto: ``SavedMetadata{repeated SavedObject
+    nodes = 1}``, ``SavedObject{node_id = 2, node_path = 3, identifier = 4, metadata = 5 (JSON)}``) ->
+    [{'node_id', 'node_path', 'identifier', 'metadata'}]; a metadata string that is not JSON comes back as {}."""
+    import json
+    out = []
+    for fn, wt, v in _fields(memoryview(buf)):
+        if fn != 1 or wt != 2:
+            continue
+        rec = {'node_id': 0, 'node_path': '', 'identifier': '', 'metadata': {}}
+        for f2, w2, v2 in _fields(v):
+            if f2 == 2 and w2 == 0:
+                rec['node_id'] = v2
+            elif f2 == 3 and w2 == 2:
+                rec['node_path'] = bytes(v2).decode()
+            elif f2 == 4 and w2 == 2:
+                rec['identifier'] = bytes(v2).decode()
+            elif f2 == 5 and w2 == 2:
+                try:
+                    rec['metadata'] = json.loads(bytes(v2).decode())
+                except ValueError:
+                    rec['metadata'] = {}
+        out.append(rec)
+    return out
+
+
+def build_saved_metadata(records):
+    """Inverse of ``parse_saved_metadata`` for [{'node_id', 'node_path', 'identifier', 'metadata': dict}]."""
+    import json
+    out = b''
+    for r in records:
+        out += _ld(1, _put_varint(2 << 3) + _put_varint(r['node_id']) + _ld(3, r['node_path'].encode()) +
+                   _ld(4, r.get('identifier', '_tf_keras_layer').encode()) + _ld(5, json.dumps(r['metadata']).encode()))
+    return out

@@ -345,3 +345,43 @@ def test_big_endian_and_sliced_entries_are_refused(tmp_path):
     open(prefix + '.data-00000-of-00001', 'wb').write(big)
     B.write_table(prefix + '.index', {B.HEADER_KEY: _pb(1, 0, 1), b'x': _entry_proto(1, (4,), 0, 300, x.astype('<f4').tobytes())})
     assert np.array_equal(B.BundleReader(prefix).tensor('x'), np.arange(4, dtype=np.float32))
+
+
+def test_layers_bound_by_name_when_the_savedmodel_names_them(tmp_path, synth):
+    """keras_metadata.pb + the checkpoint's object graph name every layer: the import must not depend on how Keras
+    numbered ``layer_with_weights-N``.  Here each shortcut convolution is numbered BEFORE the block's last
+    BatchNormalization (same shape as the shortcut's own): position-based matching would swap the two."""
+    order = K.keras_layer_order()
+    names = [n for n, _ in order]
+    for block in (2, 3, 4, 13):
+        i, j = names.index(f'block{block}_sepconv2_bn'), names.index(f'block{block}_res_conv')
+        assert j == i + 1
+        order[i], order[j] = order[j], order[i]
+        names[i], names[j] = names[j], names[i]
+    d = tmp_path / 'named'
+    K.export_bundle(str(d / 'variables' / 'variables'), synth, metadata=str(d / 'keras_metadata.pb'), order=order)
+    w = K.from_bundle(str(d))
+    assert set(w) == set(synth) and all(np.array_equal(w[k], synth[k]) for k in synth)
+    # the same files without the metadata: the position-based path sees two BatchNormalizations in a row and refuses
+    os.remove(d / 'keras_metadata.pb')
+    with pytest.raises(K.ImportError_, match='ambiguous|BatchNormalization'):
+        K.from_bundle(str(d))
+    # Keras order + metadata: still fine, and a layer name that is not Xception's is an error, not a guess
+    e = tmp_path / 'plain'
+    K.export_bundle(str(e / 'variables' / 'variables'), synth, metadata=str(e / 'keras_metadata.pb'))
+    assert W.pack_blob(K.from_bundle(str(e)), 'bf16') == W.pack_blob(synth, 'bf16')
+    recs = B.parse_saved_metadata(open(e / 'keras_metadata.pb', 'rb').read())
+    assert len(recs) == 2 + len(K.keras_layer_order()) and recs[2]['metadata']['name'] == 'block1_conv1'
+    for r in recs:
+        if r['metadata'].get('name') == 'block7_sepconv2_bn':
+            r['metadata']['name'] = 'block7_sepconv9_bn'
+    open(e / 'keras_metadata.pb', 'wb').write(B.build_saved_metadata(recs))
+    with pytest.raises(K.ImportError_, match='block7_sepconv9_bn'):
+        K.from_bundle(str(e))
+
+
+def test_variables_outside_the_layer_tree_are_an_error(tmp_path, synth):
+    def edit(t):
+        t['some_other_object/kernel/.ATTRIBUTES/VARIABLE_VALUE'] = np.zeros((3, 3), np.float32)
+    with pytest.raises(K.ImportError_, match='outside the layer_with_weights'):
+        K.from_bundle(_rewrite(tmp_path, synth, edit))
