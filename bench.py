@@ -492,7 +492,7 @@ def b1_latency(eng, mc_n, calls=50):
     return res
 
 
-def tfrecord_leg(pool_e, args, n_slides=4, tiles_per_slide=256):
+def tfrecord_leg(pool_e, args, n_slides=8, tiles_per_slide=256):
     """``evaluate`` fed from self-written PNG TFRecords (configure.py:118-124: PNG tiles, one file per slide):
     host decode (libbiscuit_io.so on the box's cores) -> pinned buffer -> H2D -> the same kernels."""
     import shutil
@@ -503,12 +503,14 @@ def tfrecord_leg(pool_e, args, n_slides=4, tiles_per_slide=256):
     from biscuit_amd.synthetic import make_tiles
     d = tempfile.mkdtemp(prefix='bq_tfr_')
     try:
-        base = make_tiles(32, seed=21)
+        # 8 slides: the first slide's decode and the last slide's kernels are not overlapped with anything, the six in
+        # between are (decode of slide s+1 under H2D + kernels of slide s)
+        base = [tfrecord.encode_image(t) for t in make_tiles(32, seed=21)]      # 32 distinct PNGs, written many times
         paths = []
         for s in range(n_slides):
-            t = base[(np.arange(tiles_per_slide) + s) % 32]
             p = os.path.join(d, f's{s}.tfrecords')
-            tfrecord.write_slide(p, f's{s}', t, np.zeros((tiles_per_slide, 2), np.int64))
+            tfrecord.write_slide(p, f's{s}', [base[(i + s) % 32] for i in range(tiles_per_slide)],
+                                 np.zeros((tiles_per_slide, 2), np.int64))
             paths.append(p)
         nbytes = sum(os.path.getsize(p) for p in paths)
         tfrecord_native.load()

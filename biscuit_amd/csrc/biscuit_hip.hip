@@ -226,7 +226,7 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
                             L.nfp % 4 == 0 && a.dwtmp && nsplit == 1;
     ProfScope ps(c, s, will_split ? std::string("split_") + cls : std::string(cls), will_split ? 0.0 : flops, will_split ? 0.0 : bytes);
     static const bool no_tile = bq_exp_env("BQ_NO_TILE") != nullptr;
-    static const int tile_mask = bq_exp_env("BQ_TILE_MASK") ? atoi(bq_exp_env("BQ_TILE_MASK")) : 7;   // kinds enabled (bit k)
+    static const int tile_mask = bq_exp_env("BQ_TILE_MASK") ? atoi(bq_exp_env("BQ_TILE_MASK")) : 15;  // kinds enabled (bit k)
     if (!no_tile && dtype == BQ_DTYPE_BF16 && !a.residual) {
         int kind = -1;
         if (a.prod == PROD_IM2COL && L.cin == 32 && L.cout == 64) kind = 0;

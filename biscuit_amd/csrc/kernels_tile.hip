@@ -41,7 +41,8 @@ struct TileParams {
     const float* dw;       // [9][CIN] fp32 (MODE_SEP)
     const float* scale;    // [NF*32]
     const float* bias;
-    bf16_t* out;           // NHWC [n][H][W][NF*32]
+    bf16_t* out;           // NHWC [n][H][W][ldo] (ldo = NF*32 unless the launch writes a slice of the channels)
+    int ldo;
     int n, H, W, Hi, Wi;   // output / input maps
     int tyn, txn;          // tiles per image
     int relu;
@@ -664,7 +665,7 @@ __global__ void __launch_bounds__(512) tile_sep2p_kernel(const TileParams p) {
                 const int oy = ty * T2 + 2 * wave + (pix >> 4), ox = tx * T2 + (pix & 15);
                 if (oy < p.H && ox < p.W)
                     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) +
-                                              (((size_t)(img * p.H + oy) * p.W + ox) * N) * 2 + pc * 16) =
+                                              (((size_t)(img * p.H + oy) * p.W + ox) * p.ldo) * 2 + pc * 16) =
                         *reinterpret_cast<const uint4*>(priv + pix * SST + pc * 16);
             }
         }
@@ -701,12 +702,27 @@ int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, 
     p.wp = reinterpret_cast<const uint4*>(wp);
     p.dw = dw; p.scale = scale; p.bias = bias;
     p.out = reinterpret_cast<bf16_t*>(out);
+    p.ldo = 0;                                         // (only the split launches of kind 3 set it)
     p.n = n; p.H = H; p.W = W; p.Hi = Hi; p.Wi = Wi;
     p.tyn = (H + TH - 1) / TH; p.txn = (W + TW - 1) / TW;
     p.relu = relu;
     static const bool sep2 = bq_exp_env("BQ_TILE_SEP1") == nullptr;   // the lane = channel-pair form (default)
     if (sep2 && kind == 1) return launch_tile_sep2<64, 4, false>(p, num_cus, s);
-    if (sep2 && kind == 2) return launch_tile_sep2<128, 4, false>(p, num_cus, s);
+    if (sep2 && kind == 2) { p.ldo = 128; return launch_tile_sep2<128, 4, false>(p, num_cus, s); }
+    if (sep2 && kind == 3) {
+        // 128 -> 256 (block3_sepconv1, 74x74): the 128 -> 128 kernel twice, each launch its half of the output channels
+        // (weights, scale and bias of a half are contiguous; the pixel rows of the output are 256 channels apart).
+        // The depthwise stage and the input read are done twice -- 0.58 ms on the pipelined kernel against 2 x 0.2 ms.
+        p.ldo = 256;
+        for (int half = 0; half < 2; ++half) {
+            TileParams q = p;
+            q.wp = p.wp + (size_t)half * 4 * (128 / 16) * 64;
+            q.scale = p.scale + half * 128; q.bias = p.bias + half * 128;
+            q.out = p.out + half * 128;
+            if (const int e = launch_tile_sep2<128, 4, true>(q, num_cus, s)) return e;
+        }
+        return 0;
+    }
     switch (kind) {
         case 0: return launch_tile<MODE_CONV3, 32, 2, false, 2>(p, num_cus, s);
         case 1: return launch_tile<MODE_SEP, 64, 4, false, 3>(p, num_cus, s);

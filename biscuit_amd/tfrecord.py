@@ -230,13 +230,20 @@ def encode_example(slide, image_raw, loc_x, loc_y):
     return _ld(1, entries)
 
 
-def write_slide(path, slide, tiles, locs=None, fmt='PNG'):
+def encode_image(tile, fmt='PNG'):
+    """One tile as the bytes Slideflow stores in ``image_raw``."""
     from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.asarray(tile, np.uint8)).save(buf, format=fmt, **({'quality': 95} if fmt == 'JPEG' else {}))
+    return buf.getvalue()
+
+
+def write_slide(path, slide, tiles, locs=None, fmt='PNG'):
+    """One TFRecord file for one slide.  ``tiles``: arrays, or already encoded images (bytes)."""
     with open(path, 'wb') as f:
         for i, t in enumerate(tiles):
-            buf = io.BytesIO()
-            Image.fromarray(np.asarray(t, np.uint8)).save(buf, format=fmt, **({'quality': 95} if fmt == 'JPEG' else {}))
+            image = bytes(t) if isinstance(t, (bytes, bytearray, memoryview)) else encode_image(t, fmt)
             lx, ly = (locs[i] if locs is not None else (i, 0))
-            payload = encode_example(slide, buf.getvalue(), int(lx), int(ly))
+            payload = encode_example(slide, image, int(lx), int(ly))
             head = struct.pack('<Q', len(payload))
             f.write(head + struct.pack('<I', masked_crc(head)) + payload + struct.pack('<I', masked_crc(payload)))
