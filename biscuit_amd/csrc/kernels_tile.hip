@@ -41,11 +41,13 @@ struct TileParams {
     const float* dw;       // [9][CIN] fp32 (MODE_SEP)
     const float* scale;    // [NF*32]
     const float* bias;
-    bf16_t* out;           // NHWC [n][H][W][ldo] (ldo = NF*32 unless the launch writes a slice of the channels)
-    int ldo;
+    bf16_t* out;           // NHWC [n][H][W][NF*32]; tile_sep2p_kernel: [n][H][W][ldo]
     int n, H, W, Hi, Wi;   // output / input maps
     int tyn, txn;          // tiles per image
     int relu;
+    int ldo;               // tile_sep2p_kernel: channels per output pixel in memory (a launch may write a slice of them).
+                           // LAST on purpose: the 64 -> 128 instance of tile_sep2_kernel lost 16 % (0.48 -> 0.56 ms) to the
+                           // schedule hipcc found when this field sat in the middle of its kernel arguments.
 };
 
 // WPE = waves per SIMD the register budget is set for (= persistent workgroups per CU): measured 0.68 -> 0.57 ms
