@@ -22,7 +22,7 @@ for path in sys.argv[1:]:
         sys.exit('check_wide: no sepconv_wide*_kernel instance found in ' + path)
     kernels += found
 bad = []
-rng = re.compile(r'([va])\[(\d+):(\d+)\]|([va])(\d+)\b')
+rng = re.compile(r'(?<![0-9A-Za-z_])([va])\[(\d+):(\d+)\]|(?<![0-9A-Za-z_])([va])(\d+)\b')
 
 
 def regs(tok):
@@ -49,7 +49,7 @@ for name, body in kernels:
             first_mfma = k if first_mfma is None else first_mfma
             last_mfma = k
             ops = [o.strip() for o in ln.split(None, 1)[1].split(',')]
-            if ops[0] != ops[3] or not ops[0].startswith(('a[', 'v[')):
+            if (ops[0] != ops[3] and ops[3] != '0') or not ops[0].startswith(('a[', 'v[')):      # C = 0: a tile's first MFMA
                 bad.append(f'{name}: MFMA accumulator not in place: {ln}')
             if ops[0].startswith('v['):
                 vacc |= regs(ops[0])
@@ -66,11 +66,16 @@ for name, body in kernels:
         if not ln.startswith('v_mfma') and ln.split(None, 1)[0][:2] in ('v_', 'ds', 'gl', 'bu', 'fl') and len(ln.split(None, 1)) > 1 \
                 and regs(ln.split(None, 1)[1]) & vacc:
             bad.append(f'{name}: {ln!r} touches an accumulator tile kept in vector registers inside the loop')
-    # hipcc does not know an asm MFMA's latency: between the first and the last MFMA nothing else may touch the
-    # accumulator file (no copy of a tile out of it, no use of it as spill space)
+    # hipcc does not know an asm MFMA's latency: between the first and the last MFMA nothing else may touch a register
+    # of an accumulator tile (no copy of a tile out of the accumulator file, no use of a tile as spill space; accumulator
+    # registers that hold no tile are the compiler's to use)
+    acc_regs = set()
+    for ln in ins:
+        if ln.startswith('v_mfma'):
+            acc_regs |= regs(ln.split(None, 1)[1].split(',')[0])
     for ln in ins[first_mfma:last_mfma]:
-        if not ln.startswith('v_mfma') and re.search(r'\ba(\[|\d)', ln.split(None, 1)[1] if len(ln.split(None, 1)) > 1 else ''):
-            bad.append(f'{name}: {ln!r} touches the accumulator file between MFMAs')
+        if not ln.startswith('v_mfma') and len(ln.split(None, 1)) > 1 and regs(ln.split(None, 1)[1]) & acc_regs:
+            bad.append(f'{name}: {ln!r} touches an accumulator tile between MFMAs')
     # weight fragments loaded by inline asm (kernels named *wide32*): hipcc does not know the load is asynchronous, so nothing
     # but an MFMA (behind the hand-written s_waitcnt) may read a register between such a load and its next overwrite
     pending = set()                     # (the loop only: the prologue also has loads hipcc issues and tracks itself)
@@ -96,8 +101,8 @@ for name, body in kernels:
     # the first accumulator read after the last MFMA must be behind >= 18 wait states of s_nop
     states = 0
     for ln in ins[last_mfma + 1:]:
-        touched = len(ln.split(None, 1)) > 1 and bool(regs(ln.split(None, 1)[1]) & vacc)
-        if ln.startswith('v_accvgpr_read') or touched:
+        touched = len(ln.split(None, 1)) > 1 and bool(regs(ln.split(None, 1)[1]) & acc_regs)
+        if touched:
             if states < 18:
                 bad.append(f'{name}: accumulator read {states} wait states after the last MFMA')
             break

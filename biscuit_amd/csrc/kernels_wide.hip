@@ -240,6 +240,12 @@ __device__ __forceinline__ void mfma16(f32x4v& acc, const uint4& b, const uint4&
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
                  : "+a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
 }
+// The very first k-step of a tile: C is the constant 0, the accumulators need no initialisation (120 writes per wave).
+__device__ __forceinline__ void mfma16_first(f32x4v& acc, const uint4& b, const uint4& a) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0"
+                 : "=a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
+}
 
 // An LDS base address the compiler must take as it is: offsets beyond the 16-bit immediate of ds_* would otherwise be
 // re-associated into one base register per distinct offset (a dozen registers this kernel does not have).
@@ -359,11 +365,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             *reinterpret_cast<uint4*>(smem + OFF_RAW + RAW_BYTES + P * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    f32x4v acc[MF][RN];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < RN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    f32x4v acc[MF][RN];                                          // first written by the first k-step's MFMAs (C = 0)
 
     WSTAMP(1);
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HPW) : "memory");  // all but the DMAs of halo chunk 1 have landed
@@ -396,8 +398,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         const unsigned off = ok ? (unsigned)((m0 + row0 + row) * KP + ch0 + col * 8) * 2u : 0u;
         dma16(resb, off, lds_base + j * 1024, __builtin_amdgcn_ballot_w64(ok));
     };
-    auto chunk = [&](auto cur_c, auto ksc_c, auto do_d_c, int c) {
+    auto chunk = [&](auto cur_c, auto ksc_c, auto do_d_c, auto first_c, int c) {
         constexpr int CUR = decltype(cur_c)::value;             // c & 1
+        constexpr bool FIRST = decltype(first_c)::value;        // chunk 0: its first k-step starts the accumulators
         constexpr int KSC = decltype(ksc_c)::value;             // k-steps of chunk c (2, or 1 for the last)
         constexpr bool DO_D = decltype(do_d_c)::value;
         constexpr int NXT = CUR ^ 1;
@@ -430,7 +433,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             if constexpr (DO_D) dw_ops<RELU, PW, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
-            mfma16(acc[I][J], bq[J], a[I]);
+            if constexpr (FIRST && D == 0) mfma16_first(acc[I][J], bq[J], a[I]);
+            else mfma16(acc[I][J], bq[J], a[I]);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 1))          // 1 = weights stay in registers
             if constexpr (I == MF - 1) {                        // the fragment is dead: fetch it for the next k-step
@@ -448,12 +452,14 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>; using K1 = std::integral_constant<int, 1>;
-    for (int c = 0; c < NCH - 2; c += 2) {
-        chunk(I0{}, K2{}, std::true_type{}, c);
-        chunk(I1{}, K2{}, std::true_type{}, c + 1);
+    chunk(I0{}, K2{}, std::true_type{}, std::true_type{}, 0);
+    chunk(I1{}, K2{}, std::true_type{}, std::false_type{}, 1);
+    for (int c = 2; c < NCH - 2; c += 2) {
+        chunk(I0{}, K2{}, std::true_type{}, std::false_type{}, c);
+        chunk(I1{}, K2{}, std::true_type{}, std::false_type{}, c + 1);
     }
-    chunk(I0{}, K2{}, std::true_type{}, NCH - 2);
-    chunk(I1{}, K1{}, std::false_type{}, NCH - 1);
+    chunk(I0{}, K2{}, std::true_type{}, std::false_type{}, NCH - 2);
+    chunk(I1{}, K1{}, std::false_type{}, std::false_type{}, NCH - 1);
 
     // The last MFMAs have to have written their accumulators before anything reads them (see mfma16), and hipcc must not
     // move an accumulator read up in front of these wait states: every tile is an operand of one of the two statements
