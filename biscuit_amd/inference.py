@@ -170,36 +170,62 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 ([rs] if rs.shape[0] else []), ([rg] if rg.shape[0] else [])
             pend_n = rest.shape[0]
 
+    # With a pool, everything this function itself enqueues (H2D copies, concatenations, a device-side loader) goes to
+    # a side stream, not to the default stream: the pool's CU-masked streams are ordinary (blocking) HIP streams, and
+    # an operation on the legacy default stream is a barrier across all of those -- one such operation per batch and
+    # the batches in flight never overlap (measured: 14.9 k tiles/s instead of 24 k through this function).
+    prep = torch.cuda.Stream(device=dev) if (pool and torch.device(dev).type == 'cuda') else None
+    if prep is not None:
+        prep.wait_stream(torch.cuda.current_stream(dev))        # the caller's tensors were made there
+
+    def on_prep(fn):
+        def call():
+            if prep is None:
+                return fn()
+            with torch.cuda.stream(prep):
+                return fn()
+        return call
     # slides whose tiles come from a loader (TFRecords) are decoded one slide ahead on a host thread:
     # the native decoder releases the GIL, so decode, H2D copy and the GPU work of the previous slide overlap
     from concurrent.futures import ThreadPoolExecutor
     lazy = any(callable(slides[si].tiles) for si in mine)
     prefetch = ThreadPoolExecutor(1) if lazy else None
-    pending = prefetch.submit(slides[mine[0]].load) if prefetch and mine else None
-    for li, si in enumerate(mine):
-        s = slides[si]
+    import contextlib
+
+    def stream_slides():
+        nonlocal pend_n, rows_slide, rows_true
+        pending = prefetch.submit(on_prep(slides[mine[0]].load)) if prefetch and mine else None
+        for li, si in enumerate(mine):
+            s = slides[si]
+            if prefetch:
+                loaded = pending.result()
+                pending = prefetch.submit(on_prep(slides[mine[li + 1]].load)) if li + 1 < len(mine) else None
+            else:
+                loaded = s.load()
+            t = _to_device(loaded, dev)
+            assert t.shape[0] == s.n_tiles, (s.name, t.shape, s.n_tiles)
+            if s.n_tiles == 0:
+                continue
+            pend_tiles.append(t)
+            pend_sidx.append(torch.full((s.n_tiles,), li, dtype=torch.int32, device=dev))
+            pend_gidx.append(offsets[si] + np.arange(s.n_tiles, dtype=np.int64))
+            pend_n += s.n_tiles
+            if keep_tiles:
+                rows_slide += [s.name] * s.n_tiles
+                rows_true += [s.y_true] * s.n_tiles
+                if s.loc is not None:
+                    rows_loc.append(np.asarray(s.loc))
+            flush()
+        flush(final=True)
+
+    try:
+        with (torch.cuda.stream(prep) if prep is not None else contextlib.nullcontext()):
+            stream_slides()
+    finally:
         if prefetch:
-            loaded = pending.result()
-            pending = prefetch.submit(slides[mine[li + 1]].load) if li + 1 < len(mine) else None
-        else:
-            loaded = s.load()
-        t = _to_device(loaded, dev)
-        assert t.shape[0] == s.n_tiles, (s.name, t.shape, s.n_tiles)
-        if s.n_tiles == 0:
-            continue
-        pend_tiles.append(t)
-        pend_sidx.append(torch.full((s.n_tiles,), li, dtype=torch.int32, device=dev))
-        pend_gidx.append(offsets[si] + np.arange(s.n_tiles, dtype=np.int64))
-        pend_n += s.n_tiles
-        if keep_tiles:
-            rows_slide += [s.name] * s.n_tiles
-            rows_true += [s.y_true] * s.n_tiles
-            if s.loc is not None:
-                rows_loc.append(np.asarray(s.loc))
-        flush()
-    flush(final=True)
-    if prefetch:
-        prefetch.shutdown()
+            prefetch.shutdown()
+    if prep is not None:
+        torch.cuda.current_stream(dev).wait_stream(prep)
 
     if pool:
         pool.synchronize()
