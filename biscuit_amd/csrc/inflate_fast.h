@@ -144,11 +144,20 @@ inline uint32_t adler32(const uint8_t* p, size_t n) {
     return (b << 16) | a;
 }
 
-struct BitReader {
-    const uint8_t* in;
-    uint64_t buf = 0;
-    unsigned cnt = 0;
-    explicit BitReader(const uint8_t* p) : in(p) {}
+// ---- one stream's decoder state ---------------------------------------------------------------------------------
+// The symbol loop keeps its state in a Cursor (a local object whose address does not escape: after inlining the fields
+// live in registers); a Stream carries a Cursor from block to block.
+struct Cursor {
+    uint64_t buf;                                        // bit buffer, LSB first
+    unsigned cnt;                                        // valid bits in buf
+    const uint8_t* in;                                   // next byte to load
+    const uint8_t* in_end;                               // end of the deflate data (the Adler-32 trailer follows)
+    uint8_t* out;
+    uint8_t* out0;
+    uint8_t* out_end;
+    const uint32_t* lt;
+    const uint32_t* dt;
+
     void refill() {                                      // afterwards 56 <= cnt <= 63
         uint64_t w;
         memcpy(&w, in, 8);                               // little-endian host (x86-64)
@@ -160,139 +169,234 @@ struct BitReader {
     void drop(unsigned n) { buf >>= (n & 63); cnt -= n; }    // & 63: what the shift instruction does anyway, so no mask is emitted
     unsigned take(int n) { const unsigned v = peek(n); drop((unsigned)n); return v; }
     const uint8_t* position() const { return in - (cnt >> 3); }   // first byte not consumed
+    void restart(const uint8_t* p) { in = p; buf = 0; cnt = 0; }
+    uint32_t lookup_lt() const {
+        uint32_t e = lt[buf & ((1u << LT_BITS) - 1)];
+        if (e & F_SUB) e = lt[(e >> 16) + ((buf >> LT_BITS) & ((1u << ((e >> 8) & 0x1F)) - 1))];
+        return e;
+    }
+    uint32_t lookup_dt() const {
+        uint32_t d = dt[buf & ((1u << DT_BITS) - 1)];
+        if (d & F_SUB) d = dt[(d >> 16) + ((buf >> DT_BITS) & ((1u << ((d >> 8) & 0x1F)) - 1))];
+        return d;
+    }
 };
+
+enum { STEP_GO = 0, STEP_EOB = 1, STEP_BAD = 2 };
+
+// One refill's worth of symbols: up to three literals, or literals and then a match, or the end of the block.
+// Bits used after a refill (>= 56 available): 3 x 15 for three literals; otherwise the bit buffer is refilled again in
+// front of the length/distance pair (15 + 5 + 15 + 13 = 48).
+static inline __attribute__((always_inline)) int step(Cursor& c) {
+    if (c.position() > c.in_end || c.out > c.out_end) return STEP_BAD;
+    c.refill();
+    uint32_t e = c.lookup_lt();
+    if (e & F_LITERAL) {
+        c.drop(e & 0xFF);
+        *c.out++ = (uint8_t)(e >> 16);
+        e = c.lookup_lt();
+        if (e & F_LITERAL) {
+            c.drop(e & 0xFF);
+            *c.out++ = (uint8_t)(e >> 16);
+            e = c.lookup_lt();
+            if (e & F_LITERAL) {
+                c.drop(e & 0xFF);
+                *c.out++ = (uint8_t)(e >> 16);
+                return STEP_GO;
+            }
+        }
+        if (c.out > c.out_end) return STEP_BAD;
+        c.refill();
+    }
+    if (e & F_SPECIAL) {
+        if (e >> 16) return STEP_BAD;                     // invalid code
+        c.drop(e & 0xFF);
+        return STEP_EOB;
+    }
+    c.drop(e & 0xFF);
+    const unsigned len = (e >> 16) + c.take((int)((e >> 8) & 0x1F));
+    const uint32_t d = c.lookup_dt();
+    if (d & F_SPECIAL) return STEP_BAD;
+    c.drop(d & 0xFF);
+    const size_t dist = (d >> 16) + c.take((int)((d >> 8) & 0x1F));
+    if (dist > (size_t)(c.out - c.out0) || (size_t)(c.out_end - c.out) < len) return STEP_BAD;
+    const uint8_t* src = c.out - dist;
+    uint8_t* dst = c.out;
+    c.out += len;
+    if (dist >= 8) {
+        do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < c.out);
+    } else {
+        do { *dst++ = *src++; } while (dst < c.out);
+    }
+    return STEP_GO;
+}
+
+struct Stream {
+    enum State { HEADER, SYMBOLS, DONE, FAILED };
+    Cursor c;
+    Tables* tables;
+    size_t out_n;
+    bool final_block;
+    State state;
+};
+
+// `in` readable for n + 16 bytes (zero padding), `out` writable for out_n + OUT_SLACK bytes.
+inline void begin(Stream& s, const uint8_t* in, size_t n, uint8_t* out, size_t out_n, Tables& T) {
+    s.tables = &T; s.out_n = out_n; s.final_block = false; s.state = Stream::FAILED;
+    if (n < 6) return;
+    const unsigned cmf = in[0], flg = in[1];
+    if ((cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) return;
+    s.c.restart(in + 2);
+    s.c.in_end = in + n - 4;                              // the trailer is not deflate data
+    s.c.out = s.c.out0 = out;
+    s.c.out_end = out + out_n;
+    s.c.lt = T.lt; s.c.dt = T.dt;
+    s.state = Stream::HEADER;
+}
+
+// From the end of a block to the next symbol loop (state SYMBOLS: tables built), through stored blocks on the way; or
+// to the end of the stream (DONE: length, position and Adler-32 verified) or its failure.
+inline void next_block(Stream& s) {
+    Cursor& c = s.c;
+    s.state = Stream::FAILED;
+    for (;;) {
+        if (s.final_block) {
+            if (c.out != c.out_end) return;
+            c.drop(c.cnt & 7);
+            const uint8_t* p = c.position();
+            if (p != c.in_end) return;                    // zlib: trailing garbage / truncated stream
+            const uint32_t want = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+            if (adler32(c.out0, s.out_n) == want) s.state = Stream::DONE;
+            return;
+        }
+        if (c.position() > c.in_end) return;
+        c.refill();
+        s.final_block = c.take(1) != 0;
+        const unsigned type = c.take(2);
+        if (type == 0) {
+            c.drop(c.cnt & 7);
+            const uint8_t* p = c.position();
+            if (c.in_end - p < 4) return;
+            const unsigned len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
+            if ((len ^ nlen) != 0xFFFFu) return;
+            p += 4;
+            if ((size_t)(c.in_end - p) < len || (size_t)(c.out_end - c.out) < len) return;
+            memcpy(c.out, p, len);
+            c.out += len;
+            c.restart(p + len);
+            continue;
+        }
+        if (type == 3) return;
+        uint8_t lens[320];
+        int hlit, hdist;
+        if (type == 1) {
+            hlit = 288; hdist = 32;
+            for (int i = 0; i < 144; ++i) lens[i] = 8;
+            for (int i = 144; i < 256; ++i) lens[i] = 9;
+            for (int i = 256; i < 280; ++i) lens[i] = 7;
+            for (int i = 280; i < 288; ++i) lens[i] = 8;
+            for (int i = 0; i < 32; ++i) lens[288 + i] = 5;
+        } else {
+            hlit = (int)c.take(5) + 257; hdist = (int)c.take(5) + 1;
+            const int hclen = (int)c.take(4) + 4;
+            if (hlit > 286 || hdist > 30) return;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t cl[19] = {0};
+            c.refill();
+            for (int i = 0; i < hclen; ++i) {
+                if (c.cnt < 3) c.refill();
+                cl[order[i]] = (uint8_t)c.take(3);
+            }
+            uint32_t pre[128 + 1];
+            if (!build_table(cl, 19, pre, 7, 128, true, [](int sym) { return entry((unsigned)sym, 0, 0, 0); })) return;
+            int i = 0;
+            while (i < hlit + hdist) {
+                if (c.position() > c.in_end) return;
+                c.refill();
+                const uint32_t e = pre[c.peek(7)];
+                if (e & F_SPECIAL) return;
+                c.drop(e & 0xFF);
+                const unsigned sym = e >> 16;
+                if (sym < 16) { lens[i++] = (uint8_t)sym; continue; }
+                unsigned rep, val = 0;
+                if (sym == 16) {
+                    if (i == 0) return;
+                    val = lens[i - 1]; rep = 3 + c.take(2);
+                } else if (sym == 17) rep = 3 + c.take(3);
+                else rep = 11 + c.take(7);
+                if (i + (int)rep > hlit + hdist) return;
+                memset(lens + i, (int)val, rep);
+                i += (int)rep;
+            }
+            if (lens[256] == 0) return;                   // no end-of-block code
+        }
+        if (!build_table(lens, hlit, s.tables->lt, LT_BITS, LT_SIZE, false, litlen_entry)) return;
+        if (!build_table(lens + hlit, hdist, s.tables->dt, DT_BITS, DT_SIZE, false, dist_entry)) return;
+        s.state = Stream::SYMBOLS;
+        return;
+    }
+}
+
+// The symbols of one block.
+inline void run_symbols(Stream& s) {
+    Cursor c = s.c;
+    int r;
+    do { r = step(c); } while (r == STEP_GO);
+    s.c = c;
+    s.state = r == STEP_EOB ? Stream::HEADER : Stream::FAILED;
+}
+
+// The symbols of two streams in lock-step, until either leaves its block.  A Huffman-coded stream is one dependent
+// chain (table load -> shift -> next table load, ~6 cycles per symbol however wide the machine); two independent chains
+// in one loop give the out-of-order core twice the work per cycle.
+inline void run_symbols2(Stream& sa, Stream& sb) {
+    Cursor a = sa.c, b = sb.c;
+    int ra = STEP_GO, rb = STEP_GO;
+    for (;;) {
+        ra = step(a);
+        if (ra != STEP_GO) break;
+        rb = step(b);
+        if (rb != STEP_GO) break;
+    }
+    sa.c = a; sb.c = b;
+    if (ra != STEP_GO) sa.state = ra == STEP_EOB ? Stream::HEADER : Stream::FAILED;
+    if (rb != STEP_GO) sb.state = rb == STEP_EOB ? Stream::HEADER : Stream::FAILED;
+}
+
+inline void finish_alone(Stream& s) {
+    for (;;) {
+        if (s.state == Stream::HEADER) next_block(s);
+        if (s.state != Stream::SYMBOLS) return;
+        run_symbols(s);
+    }
+}
 
 // Decompress a zlib stream of n bytes; `in` must be readable for n + 16 bytes (zero padding), `out` writable for
 // out_n + OUT_SLACK bytes.  Returns true iff the stream is well-formed, inflates to exactly out_n bytes and its Adler-32
 // matches.
 inline bool inflate_zlib(const uint8_t* in, size_t n, uint8_t* out, size_t out_n, Tables& T) {
-    if (n < 6) return false;
-    const unsigned cmf = in[0], flg = in[1];
-    if ((cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) return false;
-    const uint8_t* const in_end = in + n - 4;             // the trailer is not deflate data
-    uint8_t* const out0 = out;
-    uint8_t* const out_end = out + out_n;
-    BitReader br(in + 2);
+    Stream s;
+    begin(s, in, n, out, out_n, T);
+    finish_alone(s);
+    return s.state == Stream::DONE;
+}
+
+// Two streams at once (same contract each, separate tables): ok_a / ok_b as inflate_zlib would return them.
+inline void inflate_zlib2(const uint8_t* in_a, size_t n_a, uint8_t* out_a, size_t out_n_a, Tables& Ta, bool& ok_a,
+                          const uint8_t* in_b, size_t n_b, uint8_t* out_b, size_t out_n_b, Tables& Tb, bool& ok_b) {
+    Stream a, b;
+    begin(a, in_a, n_a, out_a, out_n_a, Ta);
+    begin(b, in_b, n_b, out_b, out_n_b, Tb);
     for (;;) {
-        br.refill();
-        const unsigned final_block = br.take(1), type = br.take(2);
-        if (type == 0) {
-            br.drop(br.cnt & 7);
-            const uint8_t* p = br.position();
-            if (in_end - p < 4) return false;
-            const unsigned len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8);
-            if ((len ^ nlen) != 0xFFFFu) return false;
-            p += 4;
-            if ((size_t)(in_end - p) < len || (size_t)(out_end - out) < len) return false;
-            memcpy(out, p, len);
-            out += len;
-            br = BitReader(p + len);
-        } else if (type == 1 || type == 2) {
-            uint8_t lens[320];
-            int hlit, hdist;
-            if (type == 1) {
-                hlit = 288; hdist = 32;
-                for (int i = 0; i < 144; ++i) lens[i] = 8;
-                for (int i = 144; i < 256; ++i) lens[i] = 9;
-                for (int i = 256; i < 280; ++i) lens[i] = 7;
-                for (int i = 280; i < 288; ++i) lens[i] = 8;
-                for (int i = 0; i < 32; ++i) lens[288 + i] = 5;
-            } else {
-                hlit = (int)br.take(5) + 257; hdist = (int)br.take(5) + 1;
-                const int hclen = (int)br.take(4) + 4;
-                if (hlit > 286 || hdist > 30) return false;
-                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                uint8_t cl[19] = {0};
-                br.refill();
-                for (int i = 0; i < hclen; ++i) {
-                    if (br.cnt < 3) br.refill();
-                    cl[order[i]] = (uint8_t)br.take(3);
-                }
-                uint32_t pre[128 + 1];
-                if (!build_table(cl, 19, pre, 7, 128, true, [](int s) { return entry((unsigned)s, 0, 0, 0); })) return false;
-                int i = 0;
-                while (i < hlit + hdist) {
-                    if (br.position() > in_end) return false;
-                    br.refill();
-                    const uint32_t e = pre[br.peek(7)];
-                    if (e & F_SPECIAL) return false;
-                    br.drop(e & 0xFF);
-                    const unsigned sym = e >> 16;
-                    if (sym < 16) { lens[i++] = (uint8_t)sym; continue; }
-                    unsigned rep, val = 0;
-                    if (sym == 16) {
-                        if (i == 0) return false;
-                        val = lens[i - 1]; rep = 3 + br.take(2);
-                    } else if (sym == 17) rep = 3 + br.take(3);
-                    else rep = 11 + br.take(7);
-                    if (i + (int)rep > hlit + hdist) return false;
-                    memset(lens + i, (int)val, rep);
-                    i += (int)rep;
-                }
-                if (lens[256] == 0) return false;         // no end-of-block code
-            }
-            if (!build_table(lens, hlit, T.lt, LT_BITS, LT_SIZE, false, litlen_entry)) return false;
-            if (!build_table(lens + hlit, hdist, T.dt, DT_BITS, DT_SIZE, false, dist_entry)) return false;
-            // ---- the symbol loop ------------------------------------------------------------------------------
-            for (;;) {
-                if (br.position() > in_end || out > out_end) return false;
-                br.refill();
-                uint32_t e = T.lt[br.peek(LT_BITS)];
-                if (e & F_SUB) e = T.lt[(e >> 16) + ((br.buf >> LT_BITS) & ((1u << ((e >> 8) & 0x1F)) - 1))];
-                if (e & F_LITERAL) {                      // up to three literals per refill (3 x 15 bits < 56)
-                    br.drop(e & 0xFF);
-                    *out++ = (uint8_t)(e >> 16);
-                    e = T.lt[br.peek(LT_BITS)];
-                    if (e & F_SUB) e = T.lt[(e >> 16) + ((br.buf >> LT_BITS) & ((1u << ((e >> 8) & 0x1F)) - 1))];
-                    if (e & F_LITERAL) {
-                        br.drop(e & 0xFF);
-                        *out++ = (uint8_t)(e >> 16);
-                        e = T.lt[br.peek(LT_BITS)];
-                        if (e & F_SUB) e = T.lt[(e >> 16) + ((br.buf >> LT_BITS) & ((1u << ((e >> 8) & 0x1F)) - 1))];
-                        if (e & F_LITERAL) {
-                            br.drop(e & 0xFF);
-                            *out++ = (uint8_t)(e >> 16);
-                            continue;
-                        }
-                    }
-                    if (out > out_end) return false;
-                    br.refill();
-                }
-                if (e & F_SPECIAL) {
-                    if (e >> 16) return false;            // invalid code
-                    br.drop(e & 0xFF);
-                    break;                                // end of block
-                }
-                br.drop(e & 0xFF);
-                const unsigned lx = (e >> 8) & 0x1F;
-                const unsigned len = (e >> 16) + br.take((int)lx);          // <= 20 bits so far since the refill
-                uint32_t d = T.dt[br.peek(DT_BITS)];
-                if (d & F_SUB) d = T.dt[(d >> 16) + ((br.buf >> DT_BITS) & ((1u << ((d >> 8) & 0x1F)) - 1))];
-                if (d & F_SPECIAL) return false;
-                br.drop(d & 0xFF);                        // <= 35 bits
-                const unsigned dx = (d >> 8) & 0x1F;
-                const size_t dist = (d >> 16) + br.take((int)dx);           // <= 48 bits
-                if (dist > (size_t)(out - out0) || (size_t)(out_end - out) < len) return false;
-                const uint8_t* src = out - dist;
-                uint8_t* dst = out;
-                out += len;
-                if (dist >= 8) {
-                    do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 8; dst += 8; } while (dst < out);
-                } else {
-                    do { *dst++ = *src++; } while (dst < out);
-                }
-            }
-        } else {
-            return false;
-        }
-        if (final_block) break;
+        if (a.state == Stream::HEADER) next_block(a);
+        if (b.state == Stream::HEADER) next_block(b);
+        if (a.state != Stream::SYMBOLS || b.state != Stream::SYMBOLS) break;
+        run_symbols2(a, b);
     }
-    if (out != out_end) return false;
-    br.drop(br.cnt & 7);
-    const uint8_t* p = br.position();
-    if (p != in_end) return false;                        // zlib: trailing garbage / truncated stream
-    const uint32_t want = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
-    return adler32(out0, out_n) == want;
+    finish_alone(a);
+    finish_alone(b);
+    ok_a = a.state == Stream::DONE;
+    ok_b = b.state == Stream::DONE;
 }
 
 }  // namespace bqinf

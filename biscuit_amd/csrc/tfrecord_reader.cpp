@@ -196,22 +196,28 @@ void unfilter_avg(uint8_t* cur, const uint8_t* up, size_t stride) {
 // returns BQIO_OK / BQIO_ERR_FORMAT (wrong size) / BQIO_ERR_UNSUPPORTED / BQIO_ERR_CORRUPT
 std::atomic<long long> g_inflate_fallbacks{0};     // streams zlib accepted after inflate_fast.h refused them (a bug if ever > 0)
 
-// zlib stream -> exactly raw_n bytes at raw (writable for raw_n + bqinf::OUT_SLACK); z readable for z_n + 16 bytes
-bool inflate_exact(const uint8_t* z, size_t z_n, uint8_t* raw, size_t raw_n, bqinf::Tables& T) {
-    if (bqinf::inflate_zlib(z, z_n, raw, raw_n, T)) return true;
-    uLongf got = (uLongf)raw_n;
-    if (uncompress(raw, &got, z, (uLong)z_n) != Z_OK || got != raw_n) return false;
-    ++g_inflate_fallbacks;
-    return true;
-}
+// One PNG tile in three steps, so that a worker can inflate two tiles' streams in one loop (inflate_fast.h:
+// inflate_zlib2): parse the chunks, inflate, unfilter into the RGB output.
+struct PngJob {
+    std::vector<uint8_t> zbuf, raw;          // IDAT payloads (+ 16 zero bytes), scanlines (+ slack)
+    bqinf::Tables tables;
+    uint8_t pal[256][3];
+    int npal = 0, ctype = -1, bpp = 0;
+    uint32_t w = 0, h = 0;
+    size_t stride = 0, raw_n = 0, z_n = 0;
+};
 
-int decode_png(Span img, int px, uint8_t* out, std::vector<uint8_t>& zbuf, std::vector<uint8_t>& raw, bqinf::Tables& T) {
+// returns BQIO_OK / BQIO_ERR_FORMAT (wrong size) / BQIO_ERR_UNSUPPORTED / BQIO_ERR_CORRUPT
+int png_parse(Span img, int px, PngJob& J) {
+    std::vector<uint8_t>& zbuf = J.zbuf;
+    std::vector<uint8_t>& raw = J.raw;
+    uint8_t (&pal)[256][3] = J.pal;
+    int& npal = J.npal;
     const uint8_t* p = img.p + 8;
     const uint8_t* end = img.p + img.n;
     uint32_t w = 0, h = 0;
     int depth = 0, ctype = -1, interlace = 0;
-    uint8_t pal[256][3];
-    int npal = 0;
+    npal = 0;
     zbuf.clear();
     bool seen_end = false;
     while (end - p >= 12 && !seen_end) {
@@ -237,12 +243,29 @@ int decode_png(Span img, int px, uint8_t* out, std::vector<uint8_t>& zbuf, std::
     if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 6))
         return BQIO_ERR_UNSUPPORTED;
     if ((int)w != px || (int)h != px) return BQIO_ERR_FORMAT;
-    const int bpp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : 4;
-    const size_t stride = (size_t)w * bpp;
-    const size_t raw_n = (stride + 1) * h, z_n = zbuf.size();
-    raw.resize(raw_n + bqinf::OUT_SLACK);
+    J.ctype = ctype; J.w = w; J.h = h;
+    J.bpp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : 4;
+    J.stride = (size_t)w * J.bpp;
+    J.raw_n = (J.stride + 1) * h; J.z_n = zbuf.size();
+    raw.resize(J.raw_n + bqinf::OUT_SLACK);
     zbuf.insert(zbuf.end(), 16, (uint8_t)0);              // the bit reader loads 8 bytes at a time
-    if (!inflate_exact(zbuf.data(), z_n, raw.data(), raw_n, T)) return BQIO_ERR_CORRUPT;
+    return BQIO_OK;
+}
+
+// zlib as the second opinion on a stream inflate_fast.h refused
+bool inflate_second_opinion(PngJob& J) {
+    uLongf got = (uLongf)J.raw_n;
+    if (uncompress(J.raw.data(), &got, J.zbuf.data(), (uLong)J.z_n) != Z_OK || got != J.raw_n) return false;
+    ++g_inflate_fallbacks;
+    return true;
+}
+
+int png_finish(PngJob& J, uint8_t* out) {
+    std::vector<uint8_t>& raw = J.raw;
+    const uint8_t (&pal)[256][3] = J.pal;
+    const int npal = J.npal, ctype = J.ctype, bpp = J.bpp;
+    const uint32_t w = J.w, h = J.h;
+    const size_t stride = J.stride;
     // unfilter in place (the filter byte stays in front of every scanline)
     for (uint32_t y = 0; y < h; ++y) {
         uint8_t* cur = raw.data() + (stride + 1) * y + 1;
@@ -394,6 +417,21 @@ int bqio_inflate(const uint8_t* zdata, size_t n, uint8_t* out, size_t out_len) {
     return BQIO_OK;
 }
 
+int bqio_inflate2(const uint8_t* za, size_t na, uint8_t* out_a, size_t len_a, const uint8_t* zb, size_t nb, uint8_t* out_b,
+                  size_t len_b, int* ok_a, int* ok_b) {
+    if (!za || !zb || !ok_a || !ok_b || (!out_a && len_a) || (!out_b && len_b)) return BQIO_ERR_ARG;
+    std::vector<uint8_t> a(za, za + na), b(zb, zb + nb), ra(len_a + bqinf::OUT_SLACK), rb(len_b + bqinf::OUT_SLACK);
+    a.insert(a.end(), 16, (uint8_t)0);
+    b.insert(b.end(), 16, (uint8_t)0);
+    std::vector<bqinf::Tables> tables(2);
+    bool oa = false, ob = false;
+    bqinf::inflate_zlib2(a.data(), na, ra.data(), len_a, tables[0], oa, b.data(), nb, rb.data(), len_b, tables[1], ob);
+    if (oa && len_a) memcpy(out_a, ra.data(), len_a);
+    if (ob && len_b) memcpy(out_b, rb.data(), len_b);
+    *ok_a = oa; *ok_b = ob;
+    return BQIO_OK;
+}
+
 int64_t bqio_inflate_fallbacks(void) { return (int64_t)g_inflate_fallbacks.load(); }
 
 int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc, int n_threads,
@@ -403,28 +441,41 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
     if (bad_index) *bad_index = -1;
     if (count == 0) return BQIO_OK;
     if (n_threads < 1) n_threads = 1;
-    if (n_threads > count) n_threads = (int)count;
+    if (n_threads > (count + 1) / 2) n_threads = (int)((count + 1) / 2);
     std::atomic<int64_t> next(0);
     std::atomic<int> status(BQIO_OK);
     std::atomic<int64_t> bad(-1);
     const size_t tile_bytes = (size_t)tile_px * tile_px * 3;
     auto work = [&]() {
-        std::vector<uint8_t> zbuf, raw;
-        std::vector<bqinf::Tables> tables(1);             // 13 KB of decode tables per worker, off the stack
+        std::vector<PngJob> jobs(2);                      // two tiles at a time: their streams are inflated in one loop
+        auto fail = [&](int e, int64_t i) {
+            int expect = BQIO_OK;
+            if (status.compare_exchange_strong(expect, e)) bad.store(first + i);
+        };
         for (;;) {
-            const int64_t i = next.fetch_add(1);
-            if (i >= count || status.load() != BQIO_OK) return;
-            Example ex;
-            int e = BQIO_OK;
-            if (!parse_example(r->records[(size_t)(first + i)], ex) || !ex.image.p) e = BQIO_ERR_CORRUPT;
-            else if (image_format(ex.image) != BQIO_IMG_PNG) e = BQIO_ERR_UNSUPPORTED;
-            else e = decode_png(ex.image, tile_px, out + (size_t)i * tile_bytes, zbuf, raw, tables[0]);
-            if (e != BQIO_OK) {
-                int expect = BQIO_OK;
-                if (status.compare_exchange_strong(expect, e)) bad.store(first + i);
-                return;
+            const int64_t i0 = next.fetch_add(2);
+            if (i0 >= count || status.load() != BQIO_OK) return;
+            const int nj = i0 + 1 < count ? 2 : 1;
+            Example ex[2];
+            for (int k = 0; k < nj; ++k) {
+                int e = BQIO_OK;
+                if (!parse_example(r->records[(size_t)(first + i0 + k)], ex[k]) || !ex[k].image.p) e = BQIO_ERR_CORRUPT;
+                else if (image_format(ex[k].image) != BQIO_IMG_PNG) e = BQIO_ERR_UNSUPPORTED;
+                else e = png_parse(ex[k].image, tile_px, jobs[k]);
+                if (e != BQIO_OK) { fail(e, i0 + k); return; }
             }
-            if (loc) { loc[2 * i] = ex.loc_x; loc[2 * i + 1] = ex.loc_y; }
+            bool ok[2] = {false, false};
+            if (nj == 2)
+                bqinf::inflate_zlib2(jobs[0].zbuf.data(), jobs[0].z_n, jobs[0].raw.data(), jobs[0].raw_n, jobs[0].tables, ok[0],
+                                     jobs[1].zbuf.data(), jobs[1].z_n, jobs[1].raw.data(), jobs[1].raw_n, jobs[1].tables, ok[1]);
+            else
+                ok[0] = bqinf::inflate_zlib(jobs[0].zbuf.data(), jobs[0].z_n, jobs[0].raw.data(), jobs[0].raw_n, jobs[0].tables);
+            for (int k = 0; k < nj; ++k) {
+                int e = (ok[k] || inflate_second_opinion(jobs[k])) ? png_finish(jobs[k], out + (size_t)(i0 + k) * tile_bytes)
+                                                                   : BQIO_ERR_CORRUPT;
+                if (e != BQIO_OK) { fail(e, i0 + k); return; }
+                if (loc) { loc[2 * (i0 + k)] = ex[k].loc_x; loc[2 * (i0 + k) + 1] = ex[k].loc_y; }
+            }
         }
     };
     std::vector<std::thread> pool;

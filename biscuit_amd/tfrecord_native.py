@@ -30,6 +30,8 @@ ABI = {
     'bqio_decode': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
     'bqio_masked_crc32c': (C.c_uint32, [C.c_char_p, C.c_size_t]),
     'bqio_inflate': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t]),
+    'bqio_inflate2': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp, C.c_size_t,
+                          C.POINTER(_i), C.POINTER(_i)]),
     'bqio_inflate_fallbacks': (_i64, []),
 }
 
@@ -68,6 +70,19 @@ def inflate(zdata, out_len):
     if e != 0:
         raise ValueError(f'bqio_inflate: error {e}')
     return out.tobytes()
+
+
+def inflate2(za, len_a, zb, len_b):
+    """Two zlib streams through the reader's two-stream loop: (bytes | None, bytes | None), None where ``inflate`` would
+    raise.  For tests."""
+    import numpy as np
+    oa, ob = np.empty(len_a, np.uint8), np.empty(len_b, np.uint8)
+    ka, kb = C.c_int(0), C.c_int(0)
+    e = lib().bqio_inflate2(bytes(za), len(za), oa.ctypes.data, len_a, bytes(zb), len(zb), ob.ctypes.data, len_b,
+                            C.byref(ka), C.byref(kb))
+    if e != 0:
+        raise ValueError(f'bqio_inflate2: error {e}')
+    return (oa.tobytes() if ka.value else None), (ob.tobytes() if kb.value else None)
 
 
 def inflate_fallbacks():

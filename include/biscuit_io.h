@@ -60,6 +60,11 @@ uint32_t bqio_masked_crc32c(const uint8_t* data, size_t len);
  * invalid or over-subscribed codes, a distance before the start, wrong length, Adler-32 mismatch, trailing bytes). */
 int bqio_inflate(const uint8_t* zdata, size_t n, uint8_t* out, size_t out_len);
 
+/* The same for two streams decoded in one loop (what bqio_decode does with pairs of tiles): *ok_a / *ok_b = 1 where
+ * bqio_inflate would have returned BQIO_OK.  Returns BQIO_OK unless an argument is bad. */
+int bqio_inflate2(const uint8_t* za, size_t na, uint8_t* out_a, size_t len_a, const uint8_t* zb, size_t nb, uint8_t* out_b,
+                  size_t len_b, int* ok_a, int* ok_b);
+
 /* How many PNG streams bqio_decode handed to zlib after the decompressor above refused them and zlib accepted them
  * (process-wide).  Always 0 unless that decompressor has a bug; the tests assert it. */
 int64_t bqio_inflate_fallbacks(void);

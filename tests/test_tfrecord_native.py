@@ -289,3 +289,27 @@ def test_every_png_filter_and_no_zlib_fallback(tmp_path):
         got, _ = r.decode(tile_px=px)
     np.testing.assert_array_equal(got, np.stack(want))
     assert tn.inflate_fallbacks() == before == 0
+
+
+def test_two_streams_in_one_loop():
+    """bqio_decode inflates tiles in pairs (inflate_fast.h: run_symbols2).  Every pairing of streams of different
+    block structure and length gives each stream what it gives alone -- also next to a corrupt or truncated partner."""
+    import itertools
+    import zlib
+    streams = list(_streams())[::9]                     # 19 streams: every data kind, mixed levels / strategies
+    assert len({len(d) for d, _ in streams}) >= 6
+    for (da, za), (db, zb) in itertools.islice(itertools.product(streams, streams), 0, None, 7):
+        a, b = tn.inflate2(za, len(da), zb, len(db))
+        assert a == da and b == db
+    data, z = next(s for s in _streams() if len(s[0]) == 70000 and len(s[1]) < 40000)
+    bad = bytearray(z); bad[len(z) // 2] ^= 0x10
+    for partner, plen in ((bytes(bad), len(data)), (z[:len(z) // 3], len(data)), (z, len(data) + 1), (b'', 0), (b'\x78\x9c\x07', 5)):
+        a, b = tn.inflate2(z, len(data), partner, plen)
+        assert a == data and b is None
+        a, b = tn.inflate2(partner, plen, z, len(data))
+        assert a is None and b == data
+    try:
+        ref = zlib.decompress(bytes(bad))
+    except zlib.error:
+        ref = None
+    assert ref is None or ref != data

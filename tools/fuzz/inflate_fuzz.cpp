@@ -48,7 +48,19 @@ int main(int argc, char** argv) {
         // exact-size buffers so that ASan sees any overrun: input + 16 zero bytes, output + slack
         std::vector<uint8_t> zin(z.size() + 16, 0), out(d.size() + bqinf::OUT_SLACK), ref(d.size());
         memcpy(zin.data(), z.data(), z.size());
-        const bool ok = bqinf::inflate_zlib(zin.data(), z.size(), out.data(), d.size(), T);
+        bool ok;
+        if (it & 1) {                                    // odd iterations: through the two-stream loop, next to the previous stream
+            static std::vector<uint8_t> pin, pout; static size_t pn = 0, plen = 0; static bqinf::Tables T2;
+            bool pok = false;
+            if (pin.empty()) ok = bqinf::inflate_zlib(zin.data(), z.size(), out.data(), d.size(), T);
+            else {
+                std::vector<uint8_t> pin2(pin), pout2(plen + bqinf::OUT_SLACK);
+                bqinf::inflate_zlib2(pin2.data(), pn, pout2.data(), plen, T2, pok, zin.data(), z.size(), out.data(), d.size(), T, ok);
+            }
+            pin = zin; pn = z.size(); plen = d.size();
+        } else {
+            ok = bqinf::inflate_zlib(zin.data(), z.size(), out.data(), d.size(), T);
+        }
         uLongf got = (uLongf)ref.size();
         const bool ref_ok = uncompress(ref.data(), &got, z.data(), (uLong)z.size()) == Z_OK && got == d.size();
         if (ok != ref_ok || (ok && memcmp(out.data(), ref.data(), d.size()) != 0)) {
