@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libbiscuit_hip.so')
 
-BQ_DTYPE_F32, BQ_DTYPE_BF16 = 0, 1
+BQ_DTYPE_F32, BQ_DTYPE_BF16, BQ_DTYPE_F16 = 0, 1, 2
 BQ_MC_HEAD, BQ_MC_FULL = 0, 1
 BQ_PROF_MAX = 64
 

@@ -82,7 +82,8 @@ struct DeviceGuard {
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int pad16(int c) { return (c + 15) / 16 * 16; }
-inline size_t esize(const bq_ctx* c) { return c->cfg.dtype == BQ_DTYPE_BF16 ? 2 : 4; }
+inline bool is16(int dtype) { return dtype == BQ_DTYPE_BF16 || dtype == BQ_DTYPE_F16; }
+inline size_t esize(const bq_ctx* c) { return is16(c->cfg.dtype) ? 2 : 4; }
 
 constexpr long long kStaged = 3LL * 299 * 299;
 constexpr long long kMaxAct = 147LL * 147 * 128;
@@ -151,7 +152,7 @@ struct ProfScope {
 // ---- GEMM layer launch -----------------------------------------------------------
 int pick_shape(const bq_ctx* c, int prod, int nfp) {
     if (prod == PROD_IM2COL) return SHAPE_A;
-    if (c->cfg.dtype == BQ_DTYPE_BF16) {
+    if (is16(c->cfg.dtype)) {
         static const bool s2_small = !bq_exp_env("BQ_S2_BIG");
         // 64-row tiles halve the staging tile: four workgroups per CU instead of two for N = 256
         // (128->256 @37x37: 0.161 -> 0.111 ms); for N = 128 they measured slower (0.194 -> 0.234 ms)
@@ -189,7 +190,7 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     const int dtype = c->cfg.dtype;
     const int shape = pick_shape(c, a.prod, L.nfp);
     if (shape < 0) return fail(c, BQ_ERR_ARG, std::string("no kernel shape for ") + a.layer);
-    const int vec = dtype == BQ_DTYPE_BF16 ? 8 : 4;
+    const int vec = is16(dtype) ? 8 : 4;
     int nsplit = 1;
     while (gemm_lds_bytes(dtype, shape, L.kpad / nsplit) > 160 * 1024) {
         nsplit *= 2;
@@ -222,19 +223,19 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     // 3-6 MB weight matrix per 32-64 rows); BQ_SPLIT=1 forces it for every separable conv.
     static const bool split_env = bq_exp_env("BQ_SPLIT") != nullptr;
     static const bool no_split = bq_exp_env("BQ_NO_SPLIT") != nullptr;
-    const bool will_split = !no_split && (split_env || L.kpad >= 1024) && dtype == BQ_DTYPE_BF16 && dwp &&
+    const bool will_split = !no_split && (split_env || L.kpad >= 1024) && is16(dtype) && dwp &&
                             L.nfp % 4 == 0 && a.dwtmp && nsplit == 1;
     ProfScope ps(c, s, will_split ? std::string("split_") + cls : std::string(cls), will_split ? 0.0 : flops, will_split ? 0.0 : bytes);
     static const bool no_tile = bq_exp_env("BQ_NO_TILE") != nullptr;
     static const int tile_mask = bq_exp_env("BQ_TILE_MASK") ? atoi(bq_exp_env("BQ_TILE_MASK")) : 15;  // kinds enabled (bit k)
-    if (!no_tile && dtype == BQ_DTYPE_BF16 && !a.residual) {
+    if (!no_tile && is16(dtype) && !a.residual) {
         int kind = -1;
         if (a.prod == PROD_IM2COL && L.cin == 32 && L.cout == 64) kind = 0;
         else if (a.prod == PROD_DW && L.cin == 64 && L.cout == 128) kind = 1;
         else if (a.prod == PROD_DW && L.cin == 128 && L.cout == 128) kind = 2;
         else if (a.prod == PROD_DW_RELU && L.cin == 128 && L.cout == 256) kind = 3;
         if (kind >= 0 && ((tile_mask >> kind) & 1)) {
-            const int e = launch_tile_conv(kind, a.in, L.wp, L.dw, L.scale, L.bias, a.out, a.n, a.H, a.W, a.Hi, a.Wi,
+            const int e = launch_tile_conv(dtype, kind, a.in, L.wp, L.dw, L.scale, L.bias, a.out, a.n, a.H, a.W, a.Hi, a.Wi,
                                            a.relu, c->num_cus, s);
             if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(tile) ") + a.layer + ": " +
                                                        hipGetErrorString((hipError_t)e));
@@ -244,14 +245,14 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     if (will_split) {
         {
             ProfScope pd(c, s, std::string("dw3x3_") + cls, 18.0 * M * L.cin, 2.0 * es * M * L.cin);
-            const int e = launch_dw3x3(a.in, L.dw, a.dwtmp, a.n, a.H, a.W, a.ldi, a.prod == PROD_DW_RELU, s);
+            const int e = launch_dw3x3(dtype, a.in, L.dw, a.dwtmp, a.n, a.H, a.W, a.ldi, a.prod == PROD_DW_RELU, s);
             if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(dw3x3) ") + a.layer);
         }
         ProfScope pg(c, s, std::string("gemm_") + cls, 2.0 * M * L.cin * L.cout,
                      es * (M * L.cin + M * L.cout * (a.residual ? 2.0 : 1.0)));
         p.in = a.dwtmp; p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
-        const int e = launch_gemm_tile(p, s);
+        const int e = launch_gemm_tile(dtype, p, s);
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(gemm_tile) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;
@@ -261,7 +262,7 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
         wide_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, a.ldo, a.ldi, a.ldo) && p.M % (a.H * a.W) == 0) {
         p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
-        const int e = launch_sepconv_wide(a.prod, p, L.wp16, s);
+        const int e = launch_sepconv_wide(dtype, a.prod, p, L.wp16, s);
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(wide) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;
@@ -270,7 +271,7 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     if (!no_pipe && nsplit == 1 && pipe_supported(dtype, a.prod, L.nfp, a.W, L.kpad)) {
         p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
-        const int e = launch_sepconv_pipe(a.prod, p, s);
+        const int e = launch_sepconv_pipe(dtype, a.prod, p, s);
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(pipe) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;
@@ -331,12 +332,12 @@ int block_end(bq_ctx* c, const char* res_name, const char* pool_name, const void
     // measured per batch of 256 (one stream): block 2 0.62 -> 0.46 ms, block 3 0.34 -> 0.27 ms; block 4 (K = 256, six
     // 128-channel workgroups per pixel tile) 0.26 -> 0.34 ms and block 13 0.19 -> 0.20 ms stay on the two-kernel path
     static const bool fuse_all = bq_exp_env("BQ_RESPOOL_ALL") != nullptr;
-    if (c->cfg.dtype == BQ_DTYPE_BF16 && L.wp32 && !want_res && !no_fuse && (L.kpad <= 128 || fuse_all)) {
+    if (is16(c->cfg.dtype) && L.wp32 && !want_res && !no_fuse && (L.kpad <= 128 || fuse_all)) {
         const double px = (double)n * Ho * Ho;
         ProfScope ps(c, s, std::string("respool_") + std::to_string(Hi) + "_c" + std::to_string(cout),
                      2.0 * px * L.cin * L.cout + 9.0 * px * co,
                      es * ((double)n * Hi * Hi * co + px * co + px * ci) + es * (double)L.cin * L.cout);
-        const int e = launch_respool(x, L.wp32, L.scale, L.bias, y, out, n, Hi, Hi, L.kpad, ci, co, L.nfp, s);
+        const int e = launch_respool(c->cfg.dtype, x, L.wp32, L.scale, L.bias, y, out, n, Hi, Hi, L.kpad, ci, co, L.nfp, s);
         if (e) return fail(c, BQ_ERR_HIP, std::string("launch(respool) ") + res_name + ": " + hipGetErrorString((hipError_t)e));
         return BQ_OK;
     }
@@ -575,9 +576,9 @@ extern "C" {
 bq_ctx* bq_create(int device_id, const bq_config* cfg) {
     if (!cfg) { g_create_error = "cfg is null"; return nullptr; }
     if (cfg->tile_px != 299 || cfg->n_classes != 2 ||
-        (cfg->dtype != BQ_DTYPE_F32 && cfg->dtype != BQ_DTYPE_BF16) || !(cfg->dropout >= 0.f) ||
-        !(cfg->dropout < 1.f)) {
-        g_create_error = "unsupported config (need tile_px=299, n_classes=2, dtype f32|bf16, 0<=dropout<1)";
+        (cfg->dtype != BQ_DTYPE_F32 && cfg->dtype != BQ_DTYPE_BF16 && cfg->dtype != BQ_DTYPE_F16) ||
+        !(cfg->dropout >= 0.f) || !(cfg->dropout < 1.f)) {
+        g_create_error = "unsupported config (need tile_px=299, n_classes=2, dtype f32|bf16|f16, 0<=dropout<1)";
         return nullptr;
     }
     int ndev = 0;
@@ -689,8 +690,8 @@ int bq_load_weights(bq_ctx* c, const void* host_blob, size_t nbytes) {
         uint64_t off, len; memcpy(&off, e + 48, 8); memcpy(&len, e + 56, 8);
         c->entries[name] = Blob{c->d_blob + off, (size_t)len};
     }
-    const int vec = c->cfg.dtype == BQ_DTYPE_BF16 ? 8 : 4;
-    const int elt = c->cfg.dtype == BQ_DTYPE_BF16 ? 2 : 4;
+    const int vec = is16(c->cfg.dtype) ? 8 : 4;
+    const int elt = is16(c->cfg.dtype) ? 2 : 4;
     c->stem_w = entry_f32(c, "block1_conv1/w");
     c->stem_s = entry_f32(c, "block1_conv1/scale");
     c->stem_b = entry_f32(c, "block1_conv1/bias");

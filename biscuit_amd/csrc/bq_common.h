@@ -32,6 +32,11 @@ struct BqLdsAttr {
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// IEEE half: the second 16-bit storage / matrix-core type (BQ_DTYPE_F16).  Same MFMA rate as bf16, 8x finer rounding
+// (11 against 8 significand bits), range +-65504: kernels that write it run with MODE.FP16_OVFL set, so an overflow
+// saturates instead of becoming inf (bq_f16_saturate below).
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -92,12 +97,12 @@ size_t gemm_lds_bytes(int dtype, int shape, int K);
 int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t s);
 int gemm_tile_rows(int shape);
 bool pipe_supported(int dtype, int prod, int nfp, int W, int K);
-int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s);
+int launch_sepconv_pipe(int dtype, int prod, const GemmParams& p, hipStream_t s);
 bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo);
-int launch_sepconv_wide(int prod, const GemmParams& p, const void* wp16, hipStream_t s);
-int launch_dw3x3(const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
-int launch_gemm_tile(const GemmParams& p, hipStream_t s);
-int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, const float* scale,
+int launch_sepconv_wide(int dtype, int prod, const GemmParams& p, const void* wp16, hipStream_t s);
+int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
+int launch_gemm_tile(int dtype, const GemmParams& p, hipStream_t s);
+int launch_tile_conv(int dtype, int kind, const void* in, const void* wp, const float* dw, const float* scale,
                      const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
                      hipStream_t s);
 
@@ -111,7 +116,7 @@ int launch_stem1(const void* in_nchw, int n, const float* w27x32, const float* s
                  const float* bias, void* out_nhwc, int dtype, hipStream_t s);
 int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, int Wi, int C,
                     int dtype, hipStream_t s);
-int launch_respool(const void* x, const void* wp32, const float* scale, const float* bias, const void* y, void* out,
+int launch_respool(int dtype, const void* x, const void* wp32, const float* scale, const float* bias, const void* y, void* out,
                    int n, int Hi, int Wi, int K, int ldx, int ld, int nf32, hipStream_t s);
 int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s);
 int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, const long long* tile0_dev,
@@ -133,6 +138,12 @@ int launch_nchw_to_f32_nhwc(const void* x, int n, int C, int HW, float* out, int
 
 // ---- device helpers ----------------------------------------------------------------
 #define BQ_FIXED_SHIFT 40
+
+// MODE.FP16_OVFL (bit 23 of the wave's MODE register) = 1: an FP16 result that overflows is clamped to +-MAX_FP16
+// (true infinities are kept).  First statement of every kernel that converts to f16.
+__device__ __forceinline__ void bq_f16_saturate() {
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // hwreg(HW_REG_MODE, 23, 1)
+}
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned)b) << 16);

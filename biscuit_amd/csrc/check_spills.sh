@@ -12,7 +12,7 @@ $HIPCC --offload-arch=$ARCH -O3 -std=c++17 -S --cuda-device-only kernels_pipe.hi
 report=$(awk '/\.name:/ {name=$2}
               /\.private_segment_fixed_size:/ {priv[name]=$2}
               /\.vgpr_spill_count:/ {spill[name]=$2}
-              END {for (n in spill) if (n ~ /sepconv_pipe_kernelILb0E/) print n, spill[n], priv[n]}' build/kernels_pipe.s)
+              END {for (n in spill) if (n ~ /sepconv_pipe_kernelI[^L]*Lb0E/) print n, spill[n], priv[n]}' build/kernels_pipe.s)
 if [ -z "$report" ]; then
   echo "check_spills: no sepconv_pipe_kernel<RELU=false> instance found in the assembly (mangling changed?)" >&2
   exit 1

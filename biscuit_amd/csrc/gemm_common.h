@@ -6,7 +6,75 @@ namespace bqk {
 
 template <typename T> struct TT;
 template <> struct TT<bf16_t> { static constexpr int VEC = 8; };
+template <> struct TT<f16_t> { static constexpr int VEC = 8; };
 template <> struct TT<float> { static constexpr int VEC = 4; };
+
+// The two 16-bit storage formats behind one interface: halves of a packed dword to fp32 (exact), an fp32 pair to a
+// packed dword (round to nearest even, one instruction), ReLU on a packed dword (both formats are sign-magnitude:
+// a signed 16-bit max with 0 per half), the mnemonics of the matrix instructions.
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+    static constexpr bool F16 = false;
+    static __device__ __forceinline__ float lo(unsigned u) { return __uint_as_float(u << 16); }
+    static __device__ __forceinline__ float hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        unsigned o;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+        return o;
+    }
+    // d = a * b + c with a = the low / high half of a packed dword, b and c fp32 (one rounding)
+    static __device__ __forceinline__ float fma_lo(unsigned u, float b, float c) { return fmaf(lo(u), b, c); }
+    static __device__ __forceinline__ float fma_hi(unsigned u, float b, float c) { return fmaf(hi(u), b, c); }
+    // c + the low / high half (one rounding)
+    static __device__ __forceinline__ float add_lo(float c, unsigned u) { return c + lo(u); }
+    static __device__ __forceinline__ float add_hi(float c, unsigned u) { return c + hi(u); }
+};
+template <> struct H16<f16_t> {
+    static constexpr bool F16 = true;
+    static __device__ __forceinline__ float lo(unsigned u) {
+        float f;
+        asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(f) : "v"(u));
+        return f;
+    }
+    static __device__ __forceinline__ float hi(unsigned u) {
+        float f;
+        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(u));
+        return f;
+    }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        unsigned o;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+        return o;
+    }
+    // v_fma_mix_f32 takes the half straight out of the packed dword: the product and the sum are formed from the
+    // exact fp32 values, rounded once -- the same result as lo()/hi() followed by fmaf, without the conversion
+    static __device__ __forceinline__ float fma_lo(unsigned u, float b, float c) {
+        float d;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(u), "v"(b), "v"(c));
+        return d;
+    }
+    static __device__ __forceinline__ float fma_hi(unsigned u, float b, float c) {
+        float d;
+        asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(u), "v"(b), "v"(c));
+        return d;
+    }
+    static __device__ __forceinline__ float add_lo(float c, unsigned u) {
+        float d;
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(u), "v"(c));
+        return d;
+    }
+    static __device__ __forceinline__ float add_hi(float c, unsigned u) {
+        float d;
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(u), "v"(c));
+        return d;
+    }
+};
+
+__device__ __forceinline__ unsigned relu_pk16(unsigned x) {   // ReLU on two packed bf16 / f16: one v_pk_max_i16
+    typedef short s16x2r __attribute__((ext_vector_type(2)));
+    const s16x2r z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2r, x), z));
+}
 
 template <typename T> __device__ __forceinline__ void unpack(const uint4& v, float* f);
 template <> __device__ __forceinline__ void unpack<bf16_t>(const uint4& v, float* f) {
@@ -14,6 +82,11 @@ template <> __device__ __forceinline__ void unpack<bf16_t>(const uint4& v, float
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
     f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack<f16_t>(const uint4& v, float* f) {
+    typedef H16<f16_t> F;
+    f[0] = F::lo(v.x); f[1] = F::hi(v.x); f[2] = F::lo(v.y); f[3] = F::hi(v.y);
+    f[4] = F::lo(v.z); f[5] = F::hi(v.z); f[6] = F::lo(v.w); f[7] = F::hi(v.w);
 }
 template <> __device__ __forceinline__ void unpack<float>(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
@@ -31,6 +104,10 @@ template <> __device__ __forceinline__ uint4 pack<bf16_t>(const float* f) {
     return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
                       pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
 }
+template <> __device__ __forceinline__ uint4 pack<f16_t>(const float* f) {
+    typedef H16<f16_t> F;
+    return make_uint4(F::pack2(f[0], f[1]), F::pack2(f[2], f[3]), F::pack2(f[4], f[5]), F::pack2(f[6], f[7]));
+}
 template <> __device__ __forceinline__ uint4 pack<float>(const float* f) {
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
                       __float_as_uint(f[3]));
@@ -43,6 +120,10 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
     v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
     v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t* p, float* v) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = H16<f16_t>::lo(u.x); v[1] = H16<f16_t>::hi(u.x); v[2] = H16<f16_t>::lo(u.y); v[3] = H16<f16_t>::hi(u.y);
+}
 template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
     const float4 u = *reinterpret_cast<const float4*>(p);
     v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
@@ -50,6 +131,9 @@ template <> __device__ __forceinline__ void load4<float>(const float* p, float* 
 template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, const float* v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(H16<f16_t>::pack2(v[0], v[1]), H16<f16_t>::pack2(v[2], v[3]));
 }
 template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -60,6 +144,10 @@ __device__ __forceinline__ void mma(f32x16& acc, const uint4& w, const uint4& a)
 template <> __device__ __forceinline__ void mma<bf16_t>(f32x16& acc, const uint4& w, const uint4& a) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w),
                                                    __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma<f16_t>(f32x16& acc, const uint4& w, const uint4& a) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w),
+                                                  __builtin_bit_cast(f16x8, a), acc, 0, 0, 0);
 }
 template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const uint4& w, const uint4& a) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);

@@ -21,6 +21,8 @@
 //    identically on both operands.
 #include "gemm_common.h"
 
+#include <type_traits>
+
 namespace {
 using namespace bqk;
 
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_fused_kernel(const GemmPara
     static_assert(MF % WM == 0, "row fragments must split evenly over WM");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+    if constexpr (std::is_same<T, f16_t>::value) bq_f16_saturate();
     const int tid = threadIdx.x;
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int m0 = tile * MT;
@@ -286,7 +289,7 @@ int launch_inst(const GemmParams& p, hipStream_t s) {
 int gemm_tile_rows(int shape) { return 32 * kShapes[shape].MF; }
 
 size_t gemm_lds_bytes(int dtype, int shape, int K) {
-    const int vec = dtype == 1 ? 8 : 4;
+    const int vec = dtype != 0 ? 8 : 4;
     return (size_t)(((K / vec) | 1) * 16) * (32 * kShapes[shape].MF);
 }
 
@@ -309,6 +312,21 @@ int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t
         BQ_CASE(bf16_t, PROD_S2, SHAPE_K)
         BQ_CASE(bf16_t, PROD_DW, SHAPE_F)
         BQ_CASE(bf16_t, PROD_DW, SHAPE_G)
+    } else if (dtype == 2) {
+        BQ_CASE(f16_t, PROD_IM2COL, SHAPE_A)
+        BQ_CASE(f16_t, PROD_DW, SHAPE_B)
+        BQ_CASE(f16_t, PROD_S2, SHAPE_B)
+        BQ_CASE(f16_t, PROD_DW, SHAPE_C)
+        BQ_CASE(f16_t, PROD_DW_RELU, SHAPE_C)
+        BQ_CASE(f16_t, PROD_S2, SHAPE_C)
+        BQ_CASE(f16_t, PROD_DW, SHAPE_D)
+        BQ_CASE(f16_t, PROD_DW_RELU, SHAPE_D)
+        BQ_CASE(f16_t, PROD_S2, SHAPE_D)
+        BQ_CASE(f16_t, PROD_DW, SHAPE_E)
+        BQ_CASE(f16_t, PROD_S2, SHAPE_E)
+        BQ_CASE(f16_t, PROD_S2, SHAPE_K)
+        BQ_CASE(f16_t, PROD_DW, SHAPE_F)
+        BQ_CASE(f16_t, PROD_DW, SHAPE_G)
     } else {
         BQ_CASE(float, PROD_IM2COL, SHAPE_A)
         BQ_CASE(float, PROD_DW, SHAPE_B)

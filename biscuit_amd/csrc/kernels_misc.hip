@@ -8,14 +8,20 @@ namespace {
 template <typename T> __device__ __forceinline__ T from_f32(float f);
 template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float f) { return (bf16_t)f; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float f) { return (f16_t)f; }   // FP16_OVFL: saturates
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v; }
 
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
-    const unsigned short a = __builtin_bit_cast(unsigned short, (bf16_t)lo);
-    const unsigned short b = __builtin_bit_cast(unsigned short, (bf16_t)hi);
+template <typename T>
+__device__ __forceinline__ unsigned pk16(float lo, float hi) {
+    const unsigned short a = __builtin_bit_cast(unsigned short, from_f32<T>(lo));
+    const unsigned short b = __builtin_bit_cast(unsigned short, from_f32<T>(hi));
     return (unsigned)a | ((unsigned)b << 16);
+}
+template <typename T> __device__ __forceinline__ void f16_mode() {
+    if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) bq_f16_saturate();
 }
 
 // ---------------------------------------------------------------- K0 staging
@@ -25,6 +31,7 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
 template <typename T>
 __global__ void __launch_bounds__(512) stage_u8_kernel(const uint8_t* __restrict__ tiles, int px,
                                                        T* __restrict__ out) {
+    f16_mode<T>();
     const int npix = px * px;
     const int nbytes = npix * 3;
     const uint8_t* src = tiles + (size_t)blockIdx.x * nbytes;
@@ -118,6 +125,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) stage_apply_kernel(const uint8_t* __restrict__ tiles, int px,
                                                           const unsigned long long* __restrict__ stats,
                                                           T* __restrict__ out) {
+    f16_mode<T>();
     const int npix = px * px, nbytes = npix * 3;
     const int tile = blockIdx.x / kStageSlices, sl = blockIdx.x - tile * kStageSlices;
     const uint8_t* src = tiles + (size_t)tile * nbytes;
@@ -141,6 +149,7 @@ __global__ void __launch_bounds__(256) stage_apply_kernel(const uint8_t* __restr
 template <typename T>
 __global__ void stage_f32_kernel(const float* __restrict__ tiles, long long total_pix, int npix,
                                  T* __restrict__ out) {
+    f16_mode<T>();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total_pix) return;
     const long long img = i / npix;
@@ -162,6 +171,7 @@ __global__ void __launch_bounds__(256) stem1_kernel(const T* __restrict__ in, in
                                                     const float* __restrict__ scale,
                                                     const float* __restrict__ bias,
                                                     T* __restrict__ out) {
+    f16_mode<T>();
     const int po = (px - 3) / 2 + 1;  // 149
     const long long total = (long long)n * po * po;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,8 +212,8 @@ __global__ void __launch_bounds__(256) stem1_kernel(const T* __restrict__ in, in
 #pragma unroll
         for (int j = 0; j < 32; j += 8)
             *reinterpret_cast<uint4*>(o + j) =
-                make_uint4(pk_bf16(acc[j], acc[j + 1]), pk_bf16(acc[j + 2], acc[j + 3]),
-                           pk_bf16(acc[j + 4], acc[j + 5]), pk_bf16(acc[j + 6], acc[j + 7]));
+                make_uint4(pk16<T>(acc[j], acc[j + 1]), pk16<T>(acc[j + 2], acc[j + 3]),
+                           pk16<T>(acc[j + 4], acc[j + 5]), pk16<T>(acc[j + 6], acc[j + 7]));
     } else {
 #pragma unroll
         for (int j = 0; j < 32; j += 4)
@@ -218,6 +228,7 @@ template <typename T, int VEC>
 __global__ void __launch_bounds__(256) pool_add_kernel(const T* __restrict__ y, const T* __restrict__ res,
                                                        T* __restrict__ out, int n, int Hi, int Wi,
                                                        int Ho, int Wo, int C) {
+    f16_mode<T>();
     const int chunks = C / VEC;
     const long long total = (long long)n * Ho * Wo * chunks;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -416,8 +427,13 @@ inline int grid_for(long long total, int block) { return (int)((total + block - 
 
 }  // namespace
 
-#define BQ_DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
-    do { if ((dtype) == 1) { CALL_BF16; } else { CALL_F32; } } while (0)
+// CALL is written for the type name T_; instantiated for bf16 (dtype 1), f16 (2) and fp32 (0)
+#define BQ_DISPATCH_T(dtype, ...)                                              \
+    do {                                                                       \
+        if ((dtype) == 1) { using T_ = bf16_t; __VA_ARGS__; }                  \
+        else if ((dtype) == 2) { using T_ = f16_t; __VA_ARGS__; }              \
+        else { using T_ = float; __VA_ARGS__; }                                \
+    } while (0)
 
 int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, double* stats_scratch, hipStream_t s) {
     if (n <= 0) return 0;
@@ -427,15 +443,12 @@ int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, d
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(stage_stats_kernel, dim3(n * kStageSlices), dim3(256), 0, s, tiles, px, st);
         BQ_DISPATCH_T(dtype,
-                      hipLaunchKernelGGL(stage_apply_kernel<bf16_t>, dim3(n * kStageSlices), dim3(256), 0, s, tiles, px,
-                                         st, (bf16_t*)out),
-                      hipLaunchKernelGGL(stage_apply_kernel<float>, dim3(n * kStageSlices), dim3(256), 0, s, tiles, px,
-                                         st, (float*)out));
+                      hipLaunchKernelGGL(stage_apply_kernel<T_>, dim3(n * kStageSlices), dim3(256), 0, s, tiles, px,
+                                         st, (T_*)out));
         return (int)hipGetLastError();
     }
     BQ_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(stage_u8_kernel<bf16_t>, dim3(n), dim3(512), 0, s, tiles, px, (bf16_t*)out),
-                  hipLaunchKernelGGL(stage_u8_kernel<float>, dim3(n), dim3(512), 0, s, tiles, px, (float*)out));
+                  hipLaunchKernelGGL(stage_u8_kernel<T_>, dim3(n), dim3(512), 0, s, tiles, px, (T_*)out));
     return (int)hipGetLastError();
 }
 
@@ -443,10 +456,8 @@ int launch_stage_f32(const float* tiles, int n, int px, void* out, int dtype, hi
     if (n <= 0) return 0;
     const long long total = (long long)n * px * px;
     BQ_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(stage_f32_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     tiles, total, px * px, (bf16_t*)out),
-                  hipLaunchKernelGGL(stage_f32_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     tiles, total, px * px, (float*)out));
+                  hipLaunchKernelGGL(stage_f32_kernel<T_>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     tiles, total, px * px, (T_*)out));
     return (int)hipGetLastError();
 }
 
@@ -455,10 +466,8 @@ int launch_stem1(const void* in, int n, const float* w, const float* scale, cons
     const int px = 299, po = 149;
     const long long total = (long long)n * po * po;
     BQ_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(stem1_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     (const bf16_t*)in, n, px, w, scale, bias, (bf16_t*)out),
-                  hipLaunchKernelGGL(stem1_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     (const float*)in, n, px, w, scale, bias, (float*)out));
+                  hipLaunchKernelGGL(stem1_kernel<T_>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const T_*)in, n, px, w, scale, bias, (T_*)out));
     return (int)hipGetLastError();
 }
 
@@ -469,6 +478,10 @@ int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, in
         const long long total = (long long)n * Ho * Wo * (C / 8);
         hipLaunchKernelGGL((pool_add_kernel<bf16_t, 8>), dim3(grid_for(total, 256)), dim3(256), 0, s,
                            (const bf16_t*)y, (const bf16_t*)res, (bf16_t*)out, n, Hi, Wi, Ho, Wo, C);
+    } else if (dtype == 2) {
+        const long long total = (long long)n * Ho * Wo * (C / 8);
+        hipLaunchKernelGGL((pool_add_kernel<f16_t, 8>), dim3(grid_for(total, 256)), dim3(256), 0, s,
+                           (const f16_t*)y, (const f16_t*)res, (f16_t*)out, n, Hi, Wi, Ho, Wo, C);
     } else {
         const long long total = (long long)n * Ho * Wo * (C / 4);
         hipLaunchKernelGGL((pool_add_kernel<float, 4>), dim3(grid_for(total, 256)), dim3(256), 0, s,
@@ -480,10 +493,8 @@ int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, in
 int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s) {
     const long long total = (long long)n * C;
     BQ_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(gap_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     (const bf16_t*)x, n, HW, C, ld, feat),
-                  hipLaunchKernelGGL(gap_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     (const float*)x, n, HW, C, ld, feat));
+                  hipLaunchKernelGGL(gap_kernel<T_>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const T_*)x, n, HW, C, ld, feat));
     return (int)hipGetLastError();
 }
 
@@ -519,20 +530,16 @@ int launch_slide_finish(const long long* acc_pred, const long long* acc_unc, con
 int launch_to_f32_nhwc(const void* x, long long rows, int C, int ld, float* out, int dtype, hipStream_t s) {
     const long long total = rows * C;
     BQ_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(to_f32_nhwc_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     (const bf16_t*)x, rows, C, ld, out),
-                  hipLaunchKernelGGL(to_f32_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     (const float*)x, rows, C, ld, out));
+                  hipLaunchKernelGGL(to_f32_nhwc_kernel<T_>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                                     (const T_*)x, rows, C, ld, out));
     return (int)hipGetLastError();
 }
 
 int launch_nchw_to_f32_nhwc(const void* x, int n, int C, int HW, float* out, int dtype, hipStream_t s) {
     const long long total = (long long)n * C * HW;
     BQ_DISPATCH_T(dtype,
-                  hipLaunchKernelGGL(nchw_to_f32_nhwc_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0,
-                                     s, (const bf16_t*)x, n, C, HW, out),
-                  hipLaunchKernelGGL(nchw_to_f32_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0,
-                                     s, (const float*)x, n, C, HW, out));
+                  hipLaunchKernelGGL(nchw_to_f32_nhwc_kernel<T_>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                     s, (const T_*)x, n, C, HW, out));
     return (int)hipGetLastError();
 }
 

@@ -31,15 +31,17 @@ constexpr int A_STR = KC * 2 + 16; // 144 B: odd number of 16-byte slots -> conf
 // Raw staging registers as three named values (an array here ends up in scratch).
 struct Raw3 { uint4 a, b, c, d, e; };   // up to 5 staging slots (NRAW of them used)
 
+typedef unsigned short h16_t;   // either 16-bit storage type, for address arithmetic
+
 template <int NT>
-__device__ __forceinline__ uint4 raw_load1(const bf16_t* __restrict__ in, int ldi, int coff, int row, int p_lo, int M) {
+__device__ __forceinline__ uint4 raw_load1(const h16_t* __restrict__ in, int ldi, int coff, int row, int p_lo, int M) {
     int prow = p_lo + row;
     prow = prow < 0 ? 0 : (prow >= M ? M - 1 : prow);
     return *reinterpret_cast<const uint4*>(in + (size_t)prow * ldi + coff);
 }
 
 template <int NT, int NRAW>
-__device__ __forceinline__ Raw3 raw_load(const bf16_t* __restrict__ in, int ldi, int c, int K, int jch, int tid,
+__device__ __forceinline__ Raw3 raw_load(const h16_t* __restrict__ in, int ldi, int c, int K, int jch, int tid,
                                          int p_lo, int M) {
     // Branch-free (clamped) so the loads stay in flight: rows outside the tensor and pieces
     // past K load valid-but-unused data.
@@ -54,13 +56,9 @@ __device__ __forceinline__ Raw3 raw_load(const bf16_t* __restrict__ in, int ldi,
     return r;
 }
 
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-// ReLU on two packed bf16: as signed 16-bit integers negative floats (and -0) are negative,
+// ReLU on two packed bf16 / f16: as signed 16-bit integers negative floats (and -0) are negative,
 // so max(x, 0) per half is exactly ReLU -- one v_pk_max_i16 per dword.
-__device__ __forceinline__ unsigned relu_bf16x2(unsigned x) {
-    const s16x2 z = {0, 0};
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), z));
-}
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned x) { return relu_pk16(x); }
 
 template <int NT, bool RELU>
 __device__ __forceinline__ void raw_store1(uint4 v, unsigned char* smem, int raw_off, int jch, int row,
@@ -88,7 +86,7 @@ __device__ __forceinline__ void raw_store(const Raw3& r, unsigned char* smem, in
 // was already applied to the raw rows as they were staged.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NT, int MT, int NITEM>
+template <typename T, int NT, int MT, int NITEM>
 __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int a_off, int wl_off, int c, int K,
                                           int W, int jch, int tid, const unsigned (&item_mask)[NITEM]) {
     if (c * KC + jch * 8 >= K) {                   // padded channel tail of the last chunk: A = 0 (the matrix
@@ -117,18 +115,27 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
                 for (int dx = 0; dx < 3; ++dx) {
                     const uint4 v = *reinterpret_cast<const uint4*>(smem + rowoff + (dx - 1) * RAW_ROW);
                     const bool ok = (mrow >> dx) & 1u;
-                    const unsigned sl = ok ? 0x01000c0cu : 0x0c0c0c0cu;   // low bf16  -> f32 bits (<< 16)
-                    const unsigned sh = ok ? 0x03020c0cu : 0x0c0c0c0cu;   // high bf16 -> f32 bits (& 0xffff0000)
                     const float4 w0 = *reinterpret_cast<const float4*>(smem + woff + dx * K * 4);
                     const float4 w1 = *reinterpret_cast<const float4*>(smem + woff + dx * K * 4 + 16);
-                    const f32x2 lo01 = {__uint_as_float(__builtin_amdgcn_perm(0u, v.x, sl)),
-                                        __uint_as_float(__builtin_amdgcn_perm(0u, v.y, sl))};   // ch 0, 2
-                    const f32x2 hi01 = {__uint_as_float(__builtin_amdgcn_perm(0u, v.x, sh)),
-                                        __uint_as_float(__builtin_amdgcn_perm(0u, v.y, sh))};   // ch 1, 3
-                    const f32x2 lo23 = {__uint_as_float(__builtin_amdgcn_perm(0u, v.z, sl)),
-                                        __uint_as_float(__builtin_amdgcn_perm(0u, v.w, sl))};   // ch 4, 6
-                    const f32x2 hi23 = {__uint_as_float(__builtin_amdgcn_perm(0u, v.z, sh)),
-                                        __uint_as_float(__builtin_amdgcn_perm(0u, v.w, sh))};   // ch 5, 7
+                    f32x2 lo01, hi01, lo23, hi23;
+                    if constexpr (H16<T>::F16) {
+                        // f16: the padding mask is a select on the packed dwords, then one conversion per half
+                        typedef H16<T> F;
+                        const unsigned vx = ok ? v.x : 0u, vy = ok ? v.y : 0u, vz = ok ? v.z : 0u, vw = ok ? v.w : 0u;
+                        lo01 = (f32x2){F::lo(vx), F::lo(vy)}; hi01 = (f32x2){F::hi(vx), F::hi(vy)};
+                        lo23 = (f32x2){F::lo(vz), F::lo(vw)}; hi23 = (f32x2){F::hi(vz), F::hi(vw)};
+                    } else {
+                        const unsigned sl = ok ? 0x01000c0cu : 0x0c0c0c0cu;   // low bf16  -> f32 bits (<< 16)
+                        const unsigned sh = ok ? 0x03020c0cu : 0x0c0c0c0cu;   // high bf16 -> f32 bits (& 0xffff0000)
+                        lo01 = (f32x2){__uint_as_float(__builtin_amdgcn_perm(0u, v.x, sl)),
+                                       __uint_as_float(__builtin_amdgcn_perm(0u, v.y, sl))};   // ch 0, 2
+                        hi01 = (f32x2){__uint_as_float(__builtin_amdgcn_perm(0u, v.x, sh)),
+                                       __uint_as_float(__builtin_amdgcn_perm(0u, v.y, sh))};   // ch 1, 3
+                        lo23 = (f32x2){__uint_as_float(__builtin_amdgcn_perm(0u, v.z, sl)),
+                                       __uint_as_float(__builtin_amdgcn_perm(0u, v.w, sl))};   // ch 4, 6
+                        hi23 = (f32x2){__uint_as_float(__builtin_amdgcn_perm(0u, v.z, sh)),
+                                       __uint_as_float(__builtin_amdgcn_perm(0u, v.w, sh))};   // ch 5, 7
+                    }
                     aA = __builtin_elementwise_fma((f32x2){w0.x, w0.y}, lo01, aA);
                     aB = __builtin_elementwise_fma((f32x2){w0.z, w0.w}, hi01, aB);
                     aC = __builtin_elementwise_fma((f32x2){w1.x, w1.y}, lo23, aC);
@@ -136,7 +143,7 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
                 }
             }
             const float acc[8] = {aA.x, aB.x, aA.y, aB.y, aC.x, aD.x, aC.y, aD.y};
-            *reinterpret_cast<uint4*>(smem + a_off + r * A_STR + jch * 16) = pack<bf16_t>(acc);
+            *reinterpret_cast<uint4*>(smem + a_off + r * A_STR + jch * 16) = pack<T>(acc);
         }
     }
 }
@@ -145,7 +152,7 @@ __device__ __forceinline__ void depthwise(unsigned char* smem, int raw_off, int 
 // Straight-line on purpose: all k-blocks of a chunk always run (k-blocks past K multiply zero rows of A by
 // a valid, unused weight block).  A load under a branch makes the number of outstanding loads
 // path-dependent, and the compiler then waits vmcnt(0) - the whole ring - before every k-block.
-template <int MF, int RN, int PF, int KBC>
+template <typename T, int MF, int RN, int PF, int KBC>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
                                           int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot) {
 #pragma unroll
@@ -158,7 +165,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF]
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
+            for (int j = 0; j < RN; ++j) mma<T>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
         const int nx = kb + PF;
         const int idx = nx < KB ? nx : KB - 1;
 #pragma unroll
@@ -172,7 +179,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF]
 // copied into the staging rows by LDS-DMA (`residual_dma`) -- each lane then reads back exactly the 8 bytes it
 // is about to overwrite.  With the loads in the branches the compiler waited vmcnt(0) after every one of them:
 // 24 (scale/bias) + 36 (residual) serialised L2/HBM round trips, 11 k and 30 k cycles of a 117-146 k tile.
-template <int MF, int RN>
+template <typename T, int MF, int RN>
 __device__ __forceinline__ void pipe_epilogue_to_lds(const GemmParams& p, const f32x16 (&acc)[MF][RN], int nfb,
                                                      int row_local0, int r32, int h, unsigned char* smem,
                                                      const float* sb, int nfp32, bool res_in_lds) {
@@ -201,12 +208,12 @@ __device__ __forceinline__ void pipe_epilogue_to_lds(const GemmParams& p, const 
                     float v3 = fmaf(acc[i][j][g * 4 + 3], sc.w, bi.w);
                     if (res_in_lds) {
                         const uint2 u = *slot;
-                        v0 += __uint_as_float(u.x << 16); v1 += __uint_as_float(u.x & 0xffff0000u);
-                        v2 += __uint_as_float(u.y << 16); v3 += __uint_as_float(u.y & 0xffff0000u);
+                        v0 = H16<T>::add_lo(v0, u.x); v1 = H16<T>::add_hi(v1, u.x);
+                        v2 = H16<T>::add_lo(v2, u.y); v3 = H16<T>::add_hi(v3, u.y);
                     }
                     uint2 o;
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+                    o.x = H16<T>::pack2(v0, v1);
+                    o.y = H16<T>::pack2(v2, v3);
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
                     *slot = o;
@@ -271,7 +278,7 @@ __device__ __forceinline__ void residual_dma_row_asm(const GemmParams& p, int m0
 // are the input bytes).  One instruction = 8 halo pixels x 128 B, contiguous in LDS; instructions k = first,
 // first + step, ... are this wave's.  Rows outside the tensor stay stale (their taps are masked to zero bytes by
 // the depthwise stage's permutes), pieces past K re-read the last valid piece, like the register path.
-__device__ __forceinline__ void halo_dma_asm(const bf16_t* __restrict__ in, int ldi, int c, int K, int p_lo, int M,
+__device__ __forceinline__ void halo_dma_asm(const h16_t* __restrict__ in, int ldi, int c, int K, int p_lo, int M,
                                              int HP, int lane, int first, int step, unsigned lds_raw) {
     int coff = c * KC + (lane & 7) * 8;
     coff = coff < K - 8 ? coff : K - 8;
@@ -280,7 +287,7 @@ __device__ __forceinline__ void halo_dma_asm(const bf16_t* __restrict__ in, int 
         const int prow = p_lo + row;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_raw + (unsigned)k * 1024u);
         if (row < HP && prow >= 0 && prow < M) {
-            const bf16_t* g = in + (size_t)prow * ldi + coff;
+            const h16_t* g = in + (size_t)prow * ldi + coff;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
@@ -290,7 +297,7 @@ __device__ __forceinline__ void halo_dma_asm(const bf16_t* __restrict__ in, int 
 
 // The same stage with the A fragments of k-block d+1 read from LDS before the MFMAs of k-block d (12 more live
 // registers: only for instances that have them to spare).
-template <int MF, int RN, int PF, int KBC>
+template <typename T, int MF, int RN, int PF, int KBC>
 __device__ __forceinline__ void mma_chunk_pre(f32x16 (&acc)[MF][RN], uint4 (&bq)[PF][RN], const unsigned char* smem,
                                               int a_base, const uint4* __restrict__ bp0, int c, int KB, int KBtot) {
     uint4 a[MF];
@@ -307,7 +314,7 @@ __device__ __forceinline__ void mma_chunk_pre(f32x16 (&acc)[MF][RN], uint4 (&bq)
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) mma<bf16_t>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
+            for (int j = 0; j < RN; ++j) mma<T>(acc[i][j], bq[d & (PF - 1)][j], a[i]);
         const int nx = kb + PF;
         const int idx = nx < KB ? nx : KB - 1;
 #pragma unroll
@@ -322,8 +329,9 @@ __device__ __forceinline__ void mma_chunk_pre(f32x16 (&acc)[MF][RN], uint4 (&bq)
 // WM = 2 (16 waves, 192-row tiles) is for the 256-wide layers on large maps: a 74-wide map needs 150 halo
 // pixels around ANY flattened tile, so twice the rows per tile means 30 % less halo traffic per pixel, the
 // weights are streamed once per 192 rows, and the 1024-thread workgroup runs 4 waves per SIMD.
-template <bool RELU, int MF, int WN, int RN, int NRAW, int WM>
+template <typename T, bool RELU, int MF, int WN, int RN, int NRAW, int WM>
 __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmParams p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int NT = 64 * WN * WM;
     constexpr int MT = 32 * MF * WM;
     constexpr int NITEM = (MT * CPR + NT - 1) / NT;
@@ -365,7 +373,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     const int K = p.K;                             // padded input channels (multiple of 16)
     const int KB = K / 16;
     const int NC = (K + KC - 1) / KC;
-    const bf16_t* __restrict__ in = reinterpret_cast<const bf16_t*>(p.in);
+    const h16_t* __restrict__ in = reinterpret_cast<const h16_t*>(p.in);
     const int ldi = p.ldi;
 
     const int jch = tid & (CPR - 1);               // this thread's 16-byte piece (8 channels)
@@ -474,7 +482,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
     }
     __syncthreads();                               // raw[0] and the taps are visible
     if constexpr (HDMA) halo_dma_asm(in, ldi, 1, K, p_lo, p.M, HP, lane, wave_u, NT / 64, lds_raw0 + raw_bytes);
-    depthwise<NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
+    depthwise<T, NT, MT, NITEM>(smem, 0, a_off0, wl_off, 0, K, W, jch, tid, item_mask);
     if constexpr (HDMA) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -519,13 +527,13 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
             }
             for (int r = dma_lo + wave_u; r < dma_hi; r += NT / 64) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, r);
             if (do_d)
-                depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
+                depthwise<T, NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask);
         }
         if constexpr (RN == 3) {
-            mma_chunk_pre<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+            mma_chunk_pre<T, MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
         } else {
-            mma_chunk<MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
+            mma_chunk<T, MF, RN, PF, KBC>(acc, bq, smem, a_base, bp0, c, KB, p.KBtot);
         }
         if (!first_half) {
             if constexpr (!HDMA) {
@@ -533,7 +541,7 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
             }
             for (int r = dma_lo + wave_u; r < dma_hi; r += NT / 64) residual_dma_row_asm<NT, MT>(p, m0, tid, lds_base, r);
             if (do_d)
-                depthwise<NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
+                depthwise<T, NT, MT, NITEM>(smem, nxt * raw_bytes, a_off0 + nxt * MT * A_STR, wl_off, c + 1, K, W, jch,
                                          tid, item_mask);
         }
         if constexpr (HDMA) {
@@ -552,19 +560,19 @@ __global__ void __launch_bounds__(64 * WN * WM) sepconv_pipe_kernel(const GemmPa
             residual_dma<NT, MT>(p, m0, tid, smem0, n2, MT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the in-loop asm copies too
             __syncthreads();                       // (waits for this wave's DMA, then for everyone's)
-            pipe_epilogue_to_lds<MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, true);
+            pipe_epilogue_to_lds<T, MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, true);
         } else {
-            pipe_epilogue_to_lds<MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, false);
+            pipe_epilogue_to_lds<T, MF, RN>(p, acc, nfb, wm * MF * 32, r32, h, smem0, sb, nfp32, false);
         }
         __syncthreads();
         lds_rows_to_global<bf16_t, NT, MT>(p, m0, tid, smem0);
     }
 }
 
-template <bool RELU, int RN, int NRAW, int WM>
+template <typename T, bool RELU, int RN, int NRAW, int WM>
 int launch_pipe(const GemmParams& p, hipStream_t s) {
     constexpr int MF = 3, WN = 8;
-    auto kern = sepconv_pipe_kernel<RELU, MF, WN, RN, NRAW, WM>;
+    auto kern = sepconv_pipe_kernel<T, RELU, MF, WN, RN, NRAW, WM>;
     const int MT = 32 * MF * WM;
     const int HP = MT + 2 * (p.W + 1);
     size_t lds = (size_t)2 * HP * RAW_ROW + 2 * MT * A_STR + (size_t)9 * p.K * 4;
@@ -596,7 +604,7 @@ static int pipe_variant(int nfp, int W) {
 }
 
 bool pipe_supported(int dtype, int prod, int nfp, int W, int K) {
-    if (dtype != 1 || (prod != PROD_DW && prod != PROD_DW_RELU) || K % 16 != 0) return false;
+    if (dtype == 0 || (prod != PROD_DW && prod != PROD_DW_RELU) || K % 16 != 0) return false;
     if (pipe_variant(nfp, W) < 0) return false;
     const int HP = 96 + 2 * (W + 1);
     const size_t lds = (size_t)2 * HP * RAW_ROW + 2 * 96 * A_STR + (size_t)9 * K * 4;
@@ -604,13 +612,20 @@ bool pipe_supported(int dtype, int prod, int nfp, int W, int K) {
     return lds + sbb <= 160 * 1024 && (size_t)96 * (nfp * 64 + 16) + sbb <= 160 * 1024;
 }
 
-int launch_sepconv_pipe(int prod, const GemmParams& p, hipStream_t s) {
+namespace {
+template <typename T>
+int launch_sepconv_pipe_t(int prod, const GemmParams& p, hipStream_t s) {
     const bool relu = prod == PROD_DW_RELU;
-    if (pipe_variant(p.NFp, p.W) == 0) return relu ? launch_pipe<true, 3, 3, 1>(p, s) : launch_pipe<false, 3, 3, 1>(p, s);
+    if (pipe_variant(p.NFp, p.W) == 0) return relu ? launch_pipe<T, true, 3, 3, 1>(p, s) : launch_pipe<T, false, 3, 3, 1>(p, s);
     // 256-wide: 192-row tiles on 16 waves where the halo of a 96-row tile is larger than the tile itself
     static const bool no_wide = bq_exp_env("BQ_PIPE_NO_WM2") != nullptr;
     const size_t lds2 = (size_t)2 * (192 + 2 * (p.W + 1)) * RAW_ROW + 2 * 192 * A_STR + (size_t)9 * p.K * 4;
     if (!no_wide && p.W >= 48 && lds2 + (size_t)p.NFp * 32 * 8 + 16 <= 160 * 1024 && (192 + 2 * (p.W + 1)) * CPR <= 3 * 1024)
-        return relu ? launch_pipe<true, 1, 3, 2>(p, s) : launch_pipe<false, 1, 3, 2>(p, s);
-    return relu ? launch_pipe<true, 1, 4, 1>(p, s) : launch_pipe<false, 1, 4, 1>(p, s);
+        return relu ? launch_pipe<T, true, 1, 3, 2>(p, s) : launch_pipe<T, false, 1, 3, 2>(p, s);
+    return relu ? launch_pipe<T, true, 1, 4, 1>(p, s) : launch_pipe<T, false, 1, 4, 1>(p, s);
+}
+}  // namespace
+
+int launch_sepconv_pipe(int dtype, int prod, const GemmParams& p, hipStream_t s) {
+    return dtype == 2 ? launch_sepconv_pipe_t<f16_t>(prod, p, s) : launch_sepconv_pipe_t<bf16_t>(prod, p, s);
 }

@@ -21,19 +21,22 @@ constexpr int RP_PIX = 64;              // pooled pixels per workgroup
 constexpr int RP_NC = 128;              // channels per workgroup (one 32-wide fragment per wave)
 constexpr int RP_STR = RP_NC * 2 + 16;  // LDS row stride of the shortcut tile: 272 B (odd number of 16-byte slots)
 
+template <typename T>
 struct RespoolParams {
-    const bf16_t* x;        // [n][Hi][Wi][ldx]
+    const T* x;             // [n][Hi][Wi][ldx]
     const uint4* wp;        // shortcut weights in 32x32x16 fragment order [K/16][nf32][64] x 16 B
     const float* scale;     // [nf32 * 32] folded BN
     const float* bias;
-    const bf16_t* y;        // [n][Hi][Wi][ld]
-    bf16_t* out;            // [n][Ho][Wo][ld]
+    const T* y;             // [n][Hi][Wi][ld]
+    T* out;                 // [n][Ho][Wo][ld]
     int n, Hi, Wi, Ho, Wo, K, ldx, ld, nf32;
 };
 
 constexpr int RP_KCH = 256;             // input channels staged in LDS at a time
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) respool_kernel(const RespoolParams p) {
+template <typename T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) respool_kernel(const RespoolParams<T> p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // x chunk [64][kc * 2 + 16], then the shortcut tile
     unsigned char* res = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     // ---- phase A: shortcut of pixels [gp0, gp0 + 64) x channels [32 nf, 32 nf + 32) ---------------------------------
     // x goes through LDS in chunks of up to 256 channels: thread = (pixel tid >> 2, every 4th 16-byte piece of its row),
     // so a pixel's row is read in 64-byte runs, once per workgroup
-    const bf16_t* xrow;
+    const T* xrow;
     {
         long long gp = gp0 + (tid >> 2);
         gp = gp < total ? gp : total - 1;                       // past the end: a valid pixel, result never used
@@ -78,8 +81,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             const uint4 bn = wk[(ks + 1 < kc / 16 ? ks + 1 : ks) * wstep];
             const uint4 a0 = *reinterpret_cast<const uint4*>(a0p + ks * 32);
             const uint4 a1 = *reinterpret_cast<const uint4*>(a1p + ks * 32);
-            mma<bf16_t>(acc[0], b, a0);
-            mma<bf16_t>(acc[1], b, a1);
+            mma<T>(acc[0], b, a0);
+            mma<T>(acc[1], b, a1);
             b = bn;
         }
     }
@@ -95,7 +98,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
             const float v0 = fmaf(acc[m][4 * g + 0], sc.x, bi.x), v1 = fmaf(acc[m][4 * g + 1], sc.y, bi.y);
             const float v2 = fmaf(acc[m][4 * g + 2], sc.z, bi.z), v3 = fmaf(acc[m][4 * g + 3], sc.w, bi.w);
             *reinterpret_cast<uint2*>(res + (m * 32 + l31) * RP_STR + (wave * 32 + g * 8 + h * 4) * 2) =
-                make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                make_uint2(H16<T>::pack2(v0, v1), H16<T>::pack2(v2, v3));
         }
     }
     __syncthreads();
@@ -124,17 +127,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
                 const int xx = 2 * xo + dx - pl;
                 if ((unsigned)xx >= (unsigned)p.Wi) continue;
                 const uint4 u = *reinterpret_cast<const uint4*>(p.y + ((size_t)(img * p.Hi + yy) * p.Wi + xx) * p.ld + c0);
-                const bf16_t* e = reinterpret_cast<const bf16_t*>(&u);
+                const T* e = reinterpret_cast<const T*>(&u);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], (float)e[j]);
             }
         }
         const uint4 ru = *reinterpret_cast<const uint4*>(res + px * RP_STR + ck * 16);
-        const bf16_t* re = reinterpret_cast<const bf16_t*>(&ru);
+        const T* re = reinterpret_cast<const T*>(&ru);
         uint4 ou;
-        bf16_t* oe = reinterpret_cast<bf16_t*>(&ou);
+        T* oe = reinterpret_cast<T*>(&ou);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) oe[j] = (bf16_t)(mx[j] + (float)re[j]);
+        for (int j = 0; j < 8; ++j) oe[j] = (T)(mx[j] + (float)re[j]);
         *reinterpret_cast<uint4*>(p.out + (size_t)gp * p.ld + c0) = ou;
     }
 }
@@ -143,23 +146,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
 
 // x: the block's input, sampled at even pixels; wp32: shortcut weights in 32x32x16 fragment order ("<layer>/wp32");
 // y: the tensor to pool.  K and ldx multiples of 16, ld a multiple of 8, nf32 * 32 >= ld rounded up to 128.
-int launch_respool(const void* x, const void* wp32, const float* scale, const float* bias, const void* y, void* out,
-                   int n, int Hi, int Wi, int K, int ldx, int ld, int nf32, hipStream_t s) {
+namespace {
+template <typename T>
+int launch_respool_t(const void* x, const void* wp32, const float* scale, const float* bias, const void* y, void* out,
+                     int n, int Hi, int Wi, int K, int ldx, int ld, int nf32, hipStream_t s) {
     const int ncb = (ld + RP_NC - 1) / RP_NC;                   // 128-channel blocks (grid.y)
     if (K % 16 || ldx % 8 || ld % 8 || nf32 * 32 < ncb * RP_NC || !wp32 || !scale || !bias) return (int)hipErrorInvalidValue;
-    RespoolParams p;
-    p.x = reinterpret_cast<const bf16_t*>(x);
+    RespoolParams<T> p;
+    p.x = reinterpret_cast<const T*>(x);
     p.wp = reinterpret_cast<const uint4*>(wp32);
     p.scale = scale; p.bias = bias;
-    p.y = reinterpret_cast<const bf16_t*>(y);
-    p.out = reinterpret_cast<bf16_t*>(out);
+    p.y = reinterpret_cast<const T*>(y);
+    p.out = reinterpret_cast<T*>(out);
     p.n = n; p.Hi = Hi; p.Wi = Wi; p.Ho = (Hi + 1) / 2; p.Wo = (Wi + 1) / 2;
     p.K = K; p.ldx = ldx; p.ld = ld; p.nf32 = nf32;
     const long long total = (long long)n * p.Ho * p.Wo;
     if (total <= 0) return 0;
     const int kc = K < RP_KCH ? K : RP_KCH;
     const int xs = RP_PIX * (kc * 2 + 16), rs = RP_PIX * RP_STR;
-    hipLaunchKernelGGL(respool_kernel, dim3((unsigned)((total + RP_PIX - 1) / RP_PIX), (unsigned)ncb),
+    hipLaunchKernelGGL(respool_kernel<T>, dim3((unsigned)((total + RP_PIX - 1) / RP_PIX), (unsigned)ncb),
                        dim3(256), xs > rs ? xs : rs, s, p);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+int launch_respool(int dtype, const void* x, const void* wp32, const float* scale, const float* bias, const void* y,
+                   void* out, int n, int Hi, int Wi, int K, int ldx, int ld, int nf32, hipStream_t s) {
+    return dtype == 2 ? launch_respool_t<f16_t>(x, wp32, scale, bias, y, out, n, Hi, Wi, K, ldx, ld, nf32, s)
+                      : launch_respool_t<bf16_t>(x, wp32, scale, bias, y, out, n, Hi, Wi, K, ldx, ld, nf32, s);
 }

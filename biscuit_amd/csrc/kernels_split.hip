@@ -21,21 +21,16 @@
 namespace {
 using namespace bqk;
 
-typedef float f32x2s __attribute__((ext_vector_type(2)));
-typedef short s16x2s __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned relu2s(unsigned x) {
-    const s16x2s z = {0, 0};
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2s, x), z));
-}
+__device__ __forceinline__ unsigned relu2s(unsigned x) { return relu_pk16(x); }
 
 // ------------------------------------------------------------------ depthwise 3x3
 // One thread = one 16-byte piece (8 channels) of one image column: it walks down the rows
 // with a 3x3 window of vectors in registers, so every output costs 3 new 16-byte loads
 // instead of 9.  Lanes run over pieces of a pixel first: a wave touches contiguous memory.
-template <bool RELU>
-__global__ void __launch_bounds__(256) dw3x3_kernel(const bf16_t* __restrict__ in, const float* __restrict__ dw,
-                                                    bf16_t* __restrict__ out, int n, int H, int W, int C) {
+template <typename T, bool RELU>
+__global__ void __launch_bounds__(256) dw3x3_kernel(const T* __restrict__ in, const float* __restrict__ dw,
+                                                    T* __restrict__ out, int n, int H, int W, int C) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
     const int ppp = C / 8;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)n * W * ppp) return;
@@ -50,15 +45,15 @@ __global__ void __launch_bounds__(256) dw3x3_kernel(const bf16_t* __restrict__ i
         w[t][0] = a.x; w[t][1] = a.y; w[t][2] = a.z; w[t][3] = a.w;
         w[t][4] = b.x; w[t][5] = b.y; w[t][6] = b.z; w[t][7] = b.w;
     }
-    const bf16_t* base = in + ((size_t)img * H * W) * C + piece * 8;
-    bf16_t* obase = out + ((size_t)img * H * W) * C + piece * 8;
+    const T* base = in + ((size_t)img * H * W) * C + piece * 8;
+    T* obase = out + ((size_t)img * H * W) * C + piece * 8;
     const bool xl = x > 0, xr = x + 1 < W;
     const uint4 zero = make_uint4(0, 0, 0, 0);
     auto load_row = [&](int y, uint4 (&r)[3]) {
         // branch-free: clamp the row, load, then zero what lies outside the image
         const bool vy = y >= 0 && y < H;
         const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
-        const bf16_t* p = base + ((size_t)yc * W + x) * C;
+        const T* p = base + ((size_t)yc * W + x) * C;
         r[1] = *reinterpret_cast<const uint4*>(p);
         r[0] = *reinterpret_cast<const uint4*>(xl ? p - C : p);
         r[2] = *reinterpret_cast<const uint4*>(xr ? p + C : p);
@@ -83,17 +78,17 @@ __global__ void __launch_bounds__(256) dw3x3_kernel(const bf16_t* __restrict__ i
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             float f[8];
-            unpack<bf16_t>(r0[dx], f);
+            unpack<T>(r0[dx], f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[dx][j], f[j], acc[j]);
-            unpack<bf16_t>(r1[dx], f);
+            unpack<T>(r1[dx], f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[3 + dx][j], f[j], acc[j]);
-            unpack<bf16_t>(r2[dx], f);
+            unpack<T>(r2[dx], f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(w[6 + dx][j], f[j], acc[j]);
         }
-        *reinterpret_cast<uint4*>(obase + ((size_t)y * W + x) * C) = pack<bf16_t>(acc);
+        *reinterpret_cast<uint4*>(obase + ((size_t)y * W + x) * C) = pack<T>(acc);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; }
     }
@@ -105,8 +100,9 @@ constexpr int A_ROW = BK * 2 + 16;        // 144 B: 9 slots, conflict-free ds_re
 constexpr int A_BUF = BM * A_ROW;         // 18 KB
 constexpr int ST_ROW = BN * 2 + 16;       // staging row of the output tile
 
-template <int PF>
+template <typename T, int PF>
 __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -116,7 +112,7 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
     const int mt = tile / ntn, nt = tile - mt * ntn;
     const int m0 = mt * BM;
     const int K = p.K, KB = K / 16, NC = (K + BK - 1) / BK;
-    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.in);
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.in);
 
     // A staging: 4 pieces per thread and chunk; row = idx >> 3, piece = idx & 7
     const int jp = tid & 7;
@@ -174,7 +170,7 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma<bf16_t>(acc[i][j], bq[d % PF][j], a[i]);
+                for (int j = 0; j < 2; ++j) mma<T>(acc[i][j], bq[d % PF][j], a[i]);
             const int nx = kb + PF;
             const int idx = nx < KB ? nx : KB - 1;   // clamped: blocks past K meet zero A columns
 #pragma unroll
@@ -188,7 +184,7 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
     }
 
     // ---- epilogue: folded BN, residual, ReLU in registers -> LDS -> whole 256-byte row segments
-    const bf16_t* __restrict__ res = reinterpret_cast<const bf16_t*>(p.residual);
+    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -213,7 +209,7 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[i][j][g * 4 + e], sc[e], bi[e]);
                 if (res && m < p.M && n0 < p.Nstore) {
                     float rv[4];
-                    load4<bf16_t>(res + (size_t)m * p.ldo + n0, rv);
+                    load4<T>(res + (size_t)m * p.ldo + n0, rv);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rv[e];
                 }
@@ -221,7 +217,7 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(smem + (size_t)rl * ST_ROW) + nl, v);
+                store4<T>(reinterpret_cast<T*>(smem + (size_t)rl * ST_ROW) + nl, v);
             }
         }
     __syncthreads();
@@ -242,21 +238,31 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
 
 }  // namespace
 
-int launch_dw3x3(const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s) {
+namespace {
+template <typename T>
+int launch_dw3x3_t(const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s) {
     const long long total = (long long)n * W * (C / 8);
     const int grid = (int)((total + 255) / 256);
     if (relu)
-        hipLaunchKernelGGL(dw3x3_kernel<true>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, dw, (bf16_t*)out, n, H, W, C);
+        hipLaunchKernelGGL((dw3x3_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const T*)in, dw, (T*)out, n, H, W, C);
     else
-        hipLaunchKernelGGL(dw3x3_kernel<false>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, dw, (bf16_t*)out, n, H, W, C);
+        hipLaunchKernelGGL((dw3x3_kernel<T, false>), dim3(grid), dim3(256), 0, s, (const T*)in, dw, (T*)out, n, H, W, C);
     return (int)hipGetLastError();
 }
+}  // namespace
 
-// p.in = depthwise result [M][ldi]; p.NFp multiple of 4; bf16 only
-int launch_gemm_tile(const GemmParams& p, hipStream_t s) {
+// dtype: 1 = bf16, 2 = f16 (the two-kernel form only exists for the 16-bit types)
+int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s) {
+    return dtype == 2 ? launch_dw3x3_t<f16_t>(in, dw, out, n, H, W, C, relu, s)
+                      : launch_dw3x3_t<bf16_t>(in, dw, out, n, H, W, C, relu, s);
+}
+
+// p.in = depthwise result [M][ldi]; p.NFp multiple of 4; 16-bit types only
+int launch_gemm_tile(int dtype, const GemmParams& p, hipStream_t s) {
     if (p.NFp % 4 != 0 || p.K % 16 != 0) return (int)hipErrorInvalidValue;
     const size_t lds = 2 * A_BUF > BM * ST_ROW ? 2 * A_BUF : BM * ST_ROW;
     const int grid = ((p.M + BM - 1) / BM) * (p.NFp / 4);
-    hipLaunchKernelGGL(gemm_tile_kernel<4>, dim3(grid), dim3(256), lds, s, p);
+    if (dtype == 2) hipLaunchKernelGGL((gemm_tile_kernel<f16_t, 4>), dim3(grid), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((gemm_tile_kernel<bf16_t, 4>), dim3(grid), dim3(256), lds, s, p);
     return (int)hipGetLastError();
 }

@@ -28,20 +28,17 @@ constexpr int TH = 8, TW = 16, RH = TH + 2, RW = TW + 2, RPIX = RH * RW;   // 18
 enum { MODE_CONV3 = 0, MODE_SEP = 1 };
 
 typedef float f32x2t __attribute__((ext_vector_type(2)));
-typedef short s16x2t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned relu2(unsigned x) {   // ReLU on two packed bf16 (v_pk_max_i16)
-    const s16x2t z = {0, 0};
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2t, x), z));
-}
+__device__ __forceinline__ unsigned relu2(unsigned x) { return relu_pk16(x); }   // ReLU on two packed bf16 / f16
 
+template <typename T>
 struct TileParams {
-    const bf16_t* in;      // NHWC [n][Hi][Wi][CIN]
+    const T* in;           // NHWC [n][Hi][Wi][CIN]
     const uint4* wp;       // fragment-packed weights [NF][KB][64] x 16 B
     const float* dw;       // [9][CIN] fp32 (MODE_SEP)
     const float* scale;    // [NF*32]
     const float* bias;
-    bf16_t* out;           // NHWC [n][H][W][NF*32]; tile_sep2p_kernel: [n][H][W][ldo]
+    T* out;                // NHWC [n][H][W][NF*32]; tile_sep2p_kernel: [n][H][W][ldo]
     int n, H, W, Hi, Wi;   // output / input maps
     int tyn, txn;          // tiles per image
     int relu;
@@ -52,9 +49,10 @@ struct TileParams {
 
 // WPE = waves per SIMD the register budget is set for (= persistent workgroups per CU): measured 0.68 -> 0.57 ms
 // for the 64 -> 128 layer at 3 (its LDS footprint allows 3 workgroups); the 128 -> 128 layer's LDS allows 2.
-template <int MODE, int CIN, int NF, bool RELU_IN, int WPE>
+template <typename T, int MODE, int CIN, int NF, bool RELU_IN, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-tile_conv_kernel(const TileParams p) {
+tile_conv_kernel(const TileParams<T> p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int NT = 256;
     constexpr int CC = CIN < 64 ? CIN : 64;            // channels staged per pass (<= 64)
     constexpr int NPASS = CIN / CC;
@@ -183,22 +181,23 @@ tile_conv_kernel(const TileParams p) {
                         const uint4 v = *reinterpret_cast<const uint4*>(smem + rbase + (t / 3) * RP + (t % 3) * PS);
                         const float4 w0 = *reinterpret_cast<const float4*>(smem + wbase + t * CIN * 4);
                         const float4 w1 = *reinterpret_cast<const float4*>(smem + wbase + t * CIN * 4 + 16);
-                        const f32x2t lo01 = {__uint_as_float(v.x << 16), __uint_as_float(v.y << 16)};
-                        const f32x2t hi01 = {__uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y & 0xffff0000u)};
-                        const f32x2t lo23 = {__uint_as_float(v.z << 16), __uint_as_float(v.w << 16)};
-                        const f32x2t hi23 = {__uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w & 0xffff0000u)};
+                        typedef H16<T> F;
+                        const f32x2t lo01 = {F::lo(v.x), F::lo(v.y)};
+                        const f32x2t hi01 = {F::hi(v.x), F::hi(v.y)};
+                        const f32x2t lo23 = {F::lo(v.z), F::lo(v.w)};
+                        const f32x2t hi23 = {F::hi(v.z), F::hi(v.w)};
                         aA = __builtin_elementwise_fma((f32x2t){w0.x, w0.y}, lo01, aA);
                         aB = __builtin_elementwise_fma((f32x2t){w0.z, w0.w}, hi01, aB);
                         aC = __builtin_elementwise_fma((f32x2t){w1.x, w1.y}, lo23, aC);
                         aD = __builtin_elementwise_fma((f32x2t){w1.z, w1.w}, hi23, aD);
                     }
                     const float a8[8] = {aA.x, aB.x, aA.y, aB.y, aC.x, aD.x, aC.y, aD.y};
-                    opnd = pack<bf16_t>(a8);
+                    opnd = pack<T>(a8);
                 }
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((j * KB + kb) * 64 + lane) * 16);
-                    mma<bf16_t>(acc[j], wf, opnd);
+                    mma<T>(acc[j], wf, opnd);
                 }
             }
         }
@@ -222,8 +221,8 @@ tile_conv_kernel(const TileParams p) {
                     const float v0 = fmaf(acc[j][g * 4 + 0], sc.x, bi.x), v1 = fmaf(acc[j][g * 4 + 1], sc.y, bi.y);
                     const float v2 = fmaf(acc[j][g * 4 + 2], sc.z, bi.z), v3 = fmaf(acc[j][g * 4 + 3], sc.w, bi.w);
                     uint2 o;
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+                    o.x = H16<T>::pack2(v0, v1);
+                    o.y = H16<T>::pack2(v2, v3);
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
                     *reinterpret_cast<uint2*>(row + ng * 2) = o;
@@ -247,8 +246,8 @@ tile_conv_kernel(const TileParams p) {
     }
 }
 
-template <int MODE, int CIN, int NF, bool RELU_IN, int WPE>
-int launch_tile(const TileParams& p, int num_cus, hipStream_t s) {
+template <typename T, int MODE, int CIN, int NF, bool RELU_IN, int WPE>
+int launch_tile(const TileParams<T>& p, int num_cus, hipStream_t s) {
     constexpr int KB = (MODE == MODE_CONV3 ? 9 * CIN : CIN) / 16;
     constexpr size_t W_BYTES = (size_t)NF * KB * 1024;
     constexpr size_t TAP_BYTES = MODE == MODE_SEP ? 9 * CIN * 4 : 0;
@@ -256,7 +255,7 @@ int launch_tile(const TileParams& p, int num_cus, hipStream_t s) {
     constexpr size_t STAGE_BYTES = (size_t)TH * TW * (NF * 64 + 16);
     constexpr size_t lds = W_BYTES + TAP_BYTES + (WPE < 3 ? (size_t)NF * 32 * 8 : 0) + (RAW_BYTES > STAGE_BYTES ? RAW_BYTES : STAGE_BYTES);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
-    auto kern = tile_conv_kernel<MODE, CIN, NF, RELU_IN, WPE>;
+    auto kern = tile_conv_kernel<T, MODE, CIN, NF, RELU_IN, WPE>;
     static BqLdsAttr attr;
     if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
@@ -284,8 +283,9 @@ int launch_tile(const TileParams& p, int num_cus, hipStream_t s) {
 // epilogue are the ones above.  8 waves, 16 x 16-pixel tiles (halo 18 x 18), one workgroup per CU.
 constexpr int T2 = 16, R2 = T2 + 2;                    // tile edge, halo edge
 
-template <int CIN, int NF, bool RELU_IN>
-__global__ void __launch_bounds__(512) tile_sep2_kernel(const TileParams p) {
+template <typename T, int CIN, int NF, bool RELU_IN>
+__global__ void __launch_bounds__(512) tile_sep2_kernel(const TileParams<T> p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int NT = 512;
     constexpr int CC = 64;                             // channels per pass
     constexpr int NPASS = CIN / CC;
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(512) tile_sep2_kernel(const TileParams p) {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const unsigned u = *reinterpret_cast<const unsigned*>(smem + raw_lane + dy * RP + col * PS);
-                    dst[dy] = (f32x2t){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+                    dst[dy] = (f32x2t){H16<T>::lo(u), H16<T>::hi(u)};
                 }
             };
             f32x2t c0[3], c1[3], c2[3];
@@ -409,8 +409,7 @@ __global__ void __launch_bounds__(512) tile_sep2_kernel(const TileParams p) {
                     a = __builtin_elementwise_fma(tap[dy * 3 + 1], c1[dy], a);
                     a = __builtin_elementwise_fma(tap[dy * 3 + 2], c2[dy], a);
                 }
-                unsigned o;
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(a.x), "v"(a.y));
+                const unsigned o = H16<T>::pack2(a.x, a.y);
                 *reinterpret_cast<unsigned*>(priv + a_write + x * AST) = o;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) { c0[dy] = c1[dy]; c1[dy] = c2[dy]; }
@@ -424,7 +423,7 @@ __global__ void __launch_bounds__(512) tile_sep2_kernel(const TileParams p) {
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((j * KB + kb) * 64 + lane) * 16);
-                    mma<bf16_t>(acc[j], wf, opnd);
+                    mma<T>(acc[j], wf, opnd);
                 }
             }
         }
@@ -444,8 +443,8 @@ __global__ void __launch_bounds__(512) tile_sep2_kernel(const TileParams p) {
                     const float v0 = fmaf(acc[j][g * 4 + 0], sc.x, bi.x), v1 = fmaf(acc[j][g * 4 + 1], sc.y, bi.y);
                     const float v2 = fmaf(acc[j][g * 4 + 2], sc.z, bi.z), v3 = fmaf(acc[j][g * 4 + 3], sc.w, bi.w);
                     uint2 o;
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+                    o.x = H16<T>::pack2(v0, v1);
+                    o.y = H16<T>::pack2(v2, v3);
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
                     *reinterpret_cast<uint2*>(row + ng * 2) = o;
@@ -477,8 +476,9 @@ __global__ void __launch_bounds__(512) tile_sep2_kernel(const TileParams p) {
 // pass and requests (tile + grid, pass) right after (tile, pass) went to LDS -- a whole tile's work ahead of its
 // use -- with branch-free loads: 128->128 0.75 -> 0.70 ms.  On the 64-channel layer the second form measured
 // 0.43 -> 0.55 ms (same instruction counts, a worse schedule), so it keeps the first.
-template <int CIN, int NF, bool RELU_IN>
-__global__ void __launch_bounds__(512) tile_sep2p_kernel(const TileParams p) {
+template <typename T, int CIN, int NF, bool RELU_IN>
+__global__ void __launch_bounds__(512) tile_sep2p_kernel(const TileParams<T> p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int NT = 512;
     constexpr int CC = 64;                             // channels per pass
     constexpr int NPASS = CIN / CC;
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(512) tile_sep2p_kernel(const TileParams p) {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const unsigned u = *reinterpret_cast<const unsigned*>(smem + raw_lane + dy * RP + col * PS);
-                    dst[dy] = (f32x2t){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+                    dst[dy] = (f32x2t){H16<T>::lo(u), H16<T>::hi(u)};
                 }
             };
             f32x2t c0[3], c1[3], c2[3];
@@ -611,8 +611,7 @@ __global__ void __launch_bounds__(512) tile_sep2p_kernel(const TileParams p) {
                     a = __builtin_elementwise_fma(tap[dy * 3 + 1], c1[dy], a);
                     a = __builtin_elementwise_fma(tap[dy * 3 + 2], c2[dy], a);
                 }
-                unsigned o;
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(a.x), "v"(a.y));
+                const unsigned o = H16<T>::pack2(a.x, a.y);
                 *reinterpret_cast<unsigned*>(priv + a_write + x * AST) = o;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) { c0[dy] = c1[dy]; c1[dy] = c2[dy]; }
@@ -626,7 +625,7 @@ __global__ void __launch_bounds__(512) tile_sep2p_kernel(const TileParams p) {
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((j * KB + kb) * 64 + lane) * 16);
-                    mma<bf16_t>(acc[j], wf, opnd);
+                    mma<T>(acc[j], wf, opnd);
                 }
             }
         }
@@ -646,8 +645,8 @@ __global__ void __launch_bounds__(512) tile_sep2p_kernel(const TileParams p) {
                     const float v0 = fmaf(acc[j][g * 4 + 0], sc.x, bi.x), v1 = fmaf(acc[j][g * 4 + 1], sc.y, bi.y);
                     const float v2 = fmaf(acc[j][g * 4 + 2], sc.z, bi.z), v3 = fmaf(acc[j][g * 4 + 3], sc.w, bi.w);
                     uint2 o;
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+                    o.x = H16<T>::pack2(v0, v1);
+                    o.y = H16<T>::pack2(v2, v3);
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
                     *reinterpret_cast<uint2*>(row + ng * 2) = o;
@@ -674,13 +673,13 @@ __global__ void __launch_bounds__(512) tile_sep2p_kernel(const TileParams p) {
     }
 }
 
-template <int CIN, int NF, bool RELU_IN>
-int launch_tile_sep2(TileParams p, int num_cus, hipStream_t s) {
+template <typename T, int CIN, int NF, bool RELU_IN>
+int launch_tile_sep2(TileParams<T> p, int num_cus, hipStream_t s) {
     constexpr int KB = CIN / 16, N = NF * 32;
     constexpr size_t lds = (size_t)NF * KB * 1024 + 9 * CIN * 4 + 2 * N * 4 + (size_t)R2 * (R2 * 128 + 128) +
                            (size_t)8 * 32 * (N * 2 + 16);
     static_assert(lds <= 160 * 1024, "tile kernel LDS budget");
-    auto kern = CIN > 64 ? tile_sep2p_kernel<CIN, NF, RELU_IN> : tile_sep2_kernel<CIN, NF, RELU_IN>;
+    auto kern = CIN > 64 ? tile_sep2p_kernel<T, CIN, NF, RELU_IN> : tile_sep2_kernel<T, CIN, NF, RELU_IN>;
     static BqLdsAttr attr;
     if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     p.tyn = (p.H + T2 - 1) / T2;
@@ -692,44 +691,52 @@ int launch_tile_sep2(TileParams p, int num_cus, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-}  // namespace
-
 // kind: 0 = 3x3 valid conv 32->64 (block1_conv2); 1 = sepconv 64->128; 2 = sepconv 128->128;
 // 3 = sepconv 128->256 with ReLU on the input.  Returns <0 if the combination is not built.
-int launch_tile_conv(int kind, const void* in, const void* wp, const float* dw, const float* scale,
-                     const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
-                     hipStream_t s) {
-    TileParams p;
-    p.in = reinterpret_cast<const bf16_t*>(in);
+template <typename T>
+int launch_tile_conv_t(int kind, const void* in, const void* wp, const float* dw, const float* scale,
+                       const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
+                       hipStream_t s) {
+    TileParams<T> p;
+    p.in = reinterpret_cast<const T*>(in);
     p.wp = reinterpret_cast<const uint4*>(wp);
     p.dw = dw; p.scale = scale; p.bias = bias;
-    p.out = reinterpret_cast<bf16_t*>(out);
+    p.out = reinterpret_cast<T*>(out);
     p.ldo = 0;                                         // (only the split launches of kind 3 set it)
     p.n = n; p.H = H; p.W = W; p.Hi = Hi; p.Wi = Wi;
     p.tyn = (H + TH - 1) / TH; p.txn = (W + TW - 1) / TW;
     p.relu = relu;
     static const bool sep2 = bq_exp_env("BQ_TILE_SEP1") == nullptr;   // the lane = channel-pair form (default)
-    if (sep2 && kind == 1) return launch_tile_sep2<64, 4, false>(p, num_cus, s);
-    if (sep2 && kind == 2) { p.ldo = 128; return launch_tile_sep2<128, 4, false>(p, num_cus, s); }
+    if (sep2 && kind == 1) return launch_tile_sep2<T, 64, 4, false>(p, num_cus, s);
+    if (sep2 && kind == 2) { p.ldo = 128; return launch_tile_sep2<T, 128, 4, false>(p, num_cus, s); }
     if (sep2 && kind == 3) {
         // 128 -> 256 (block3_sepconv1, 74x74): the 128 -> 128 kernel twice, each launch its half of the output channels
         // (weights, scale and bias of a half are contiguous; the pixel rows of the output are 256 channels apart).
         // The depthwise stage and the input read are done twice -- 0.58 ms on the pipelined kernel against 2 x 0.2 ms.
         p.ldo = 256;
         for (int half = 0; half < 2; ++half) {
-            TileParams q = p;
+            TileParams<T> q = p;
             q.wp = p.wp + (size_t)half * 4 * (128 / 16) * 64;
             q.scale = p.scale + half * 128; q.bias = p.bias + half * 128;
             q.out = p.out + half * 128;
-            if (const int e = launch_tile_sep2<128, 4, true>(q, num_cus, s)) return e;
+            if (const int e = launch_tile_sep2<T, 128, 4, true>(q, num_cus, s)) return e;
         }
         return 0;
     }
     switch (kind) {
-        case 0: return launch_tile<MODE_CONV3, 32, 2, false, 2>(p, num_cus, s);
-        case 1: return launch_tile<MODE_SEP, 64, 4, false, 3>(p, num_cus, s);
-        case 2: return launch_tile<MODE_SEP, 128, 4, false, 2>(p, num_cus, s);
-        case 3: return launch_tile<MODE_SEP, 128, 8, true, 1>(p, num_cus, s);
+        case 0: return launch_tile<T, MODE_CONV3, 32, 2, false, 2>(p, num_cus, s);
+        case 1: return launch_tile<T, MODE_SEP, 64, 4, false, 3>(p, num_cus, s);
+        case 2: return launch_tile<T, MODE_SEP, 128, 4, false, 2>(p, num_cus, s);
+        case 3: return launch_tile<T, MODE_SEP, 128, 8, true, 1>(p, num_cus, s);
     }
     return -1;
+}
+
+}  // namespace
+
+int launch_tile_conv(int dtype, int kind, const void* in, const void* wp, const float* dw, const float* scale,
+                     const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
+                     hipStream_t s) {
+    return dtype == 2 ? launch_tile_conv_t<f16_t>(kind, in, wp, dw, scale, bias, out, n, H, W, Hi, Wi, relu, num_cus, s)
+                      : launch_tile_conv_t<bf16_t>(kind, in, wp, dw, scale, bias, out, n, H, W, Hi, Wi, relu, num_cus, s);
 }

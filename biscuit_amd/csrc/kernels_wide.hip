@@ -84,14 +84,16 @@ struct Geo {
     static_assert(NRES1 <= NCH, "the residual prefetch needs one loop iteration per instruction");
 };
 
+typedef unsigned short h16_t;   // either 16-bit storage type (the kernel only forms byte addresses from these)
+
 struct WideParams {
-    const bf16_t* in;       // [n*361][736]
+    const h16_t* in;        // [n*361][736]
     const uint4* wp;        // pointwise weights in 16x16x32 fragment order [23 k-steps][48][64] x 16 B
     const float* dw;        // [9][736] depthwise taps
     const float* scale;     // [768] folded BN
     const float* bias;      // [768]
-    const bf16_t* residual; // [n*361][736] or null
-    bf16_t* out;            // [n*361][736]
+    const h16_t* residual;  // [n*361][736] or null
+    h16_t* out;             // [n*361][736]
     int n;                  // images
     int relu;               // ReLU in the epilogue
 #ifdef BQ_EXPERIMENTS
@@ -125,11 +127,7 @@ __device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned
         : "memory", "scc");
 }
 
-__device__ __forceinline__ unsigned relu2(unsigned x) {      // ReLU on two packed bf16: signed 16-bit max with 0
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    const s16x2 z = {0, 0};
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, x), z));
-}
+__device__ __forceinline__ unsigned relu2(unsigned x) { return relu_pk16(x); }   // ReLU on two packed bf16 / f16
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -149,18 +147,45 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int NPRIME = 9;
 constexpr int NDW = NPRIME + 14 * NSTEP;
 
+// The window holds what the taps multiply: bf16 -> the two channels unpacked to fp32 (shift / mask, two instructions per
+// dword); f16 -> the packed dword itself, and each tap is ONE v_fma_mix_f32 that takes its half straight out of it (the
+// product of the exact values, one rounding: bit-identical to convert-then-fma), so the six unpack instructions per
+// pixel do not exist in the f16 instance (a ReLU in front is one v_pk_max_i16 per dword in both).
+template <typename T> struct Win;
+template <> struct Win<bf16_t> { typedef float2 type; };
+template <> struct Win<f16_t> { typedef unsigned type; };
+
+template <typename T>
 struct DwState {
     float2 tw[9];
-    float2 c[3][3];         // [window column slot][row]: column j of the lane's run lives in slot (j + 1) % 3
+    typename Win<T>::type c[3][3];   // [window column slot][row]: column j of the lane's run lives in slot (j + 1) % 3
     unsigned d[3];          // dwords of the column being brought in
     unsigned x[2][3];       // dwords of columns -1, 0 (prime only)
     float o0, o1;
 };
 
-template <bool RELU>
-__device__ __forceinline__ float2 unpack2(unsigned d) {
+template <typename T, bool RELU>
+__device__ __forceinline__ typename Win<T>::type unpack2(unsigned d) {
     if (RELU) d = relu2(d);
-    return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u));
+    if constexpr (H16<T>::F16) return d;
+    else return make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u));
+}
+
+// one tap of the lane's two channels: o = tw * window (+ o)
+template <typename T, bool FIRST>
+__device__ __forceinline__ void tap2(float& o0, float& o1, const float2& tw, const typename Win<T>::type& w) {
+    if constexpr (H16<T>::F16) {
+        if constexpr (FIRST) {
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(o0) : "v"(w), "v"(tw.x));
+            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(o1) : "v"(w), "v"(tw.y));
+        } else {
+            o0 = H16<T>::fma_lo(w, tw.x, o0);
+            o1 = H16<T>::fma_hi(w, tw.y, o1);
+        }
+    } else {
+        o0 = fmaf(tw.x, w.x, FIRST ? 0.f : o0);
+        o1 = fmaf(tw.y, w.y, FIRST ? 0.f : o1);
+    }
 }
 
 template <int PW>
@@ -168,8 +193,8 @@ __device__ __forceinline__ unsigned raw_dword(const unsigned char* smem, int raw
     return *reinterpret_cast<const unsigned*>(smem + raw_addr + ((j + 1) + r * PW) * 128);
 }
 
-template <bool RELU, int PW, int M>
-__device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[NSTEP]) {
+template <typename T, bool RELU, int PW, int M>
+__device__ __forceinline__ void dw_op(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[NSTEP]) {
     if constexpr (M < 3) {
 #pragma unroll
         for (int t = 3 * M; t < 3 * M + 3; ++t) st.tw[t] = *reinterpret_cast<const float2*>(smem + tap_addr + t * KP * 4);
@@ -181,10 +206,10 @@ __device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_
         for (int r = 0; r < 3; ++r) st.d[r] = raw_dword<PW>(smem, raw_addr, 1, r);
     } else if constexpr (M < 8) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) st.c[M - 6][r] = unpack2<RELU>(st.x[M - 6][r]);
+        for (int r = 0; r < 3; ++r) st.c[M - 6][r] = unpack2<T, RELU>(st.x[M - 6][r]);
     } else if constexpr (M == 8) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) st.c[2][r] = unpack2<RELU>(st.d[r]);
+        for (int r = 0; r < 3; ++r) st.c[2][r] = unpack2<T, RELU>(st.d[r]);
     } else {
         constexpr int S = (M - NPRIME) / 14, K = (M - NPRIME) % 14;
         if constexpr (K == 7) {
@@ -193,24 +218,21 @@ __device__ __forceinline__ void dw_op(DwState& st, unsigned char* smem, int raw_
                 for (int r = 0; r < 3; ++r) st.d[r] = raw_dword<PW>(smem, raw_addr, S + 2, r);
             }
         } else if constexpr (K < 10) {
-            constexpr int T = K < 7 ? K : K - 1, R = T / 3, DX = T % 3;
-            st.o0 = fmaf(st.tw[T].x, st.c[(S + DX) % 3][R].x, T == 0 ? 0.f : st.o0);
-            st.o1 = fmaf(st.tw[T].y, st.c[(S + DX) % 3][R].y, T == 0 ? 0.f : st.o1);
+            constexpr int TP = K < 7 ? K : K - 1, R = TP / 3, DX = TP % 3;
+            tap2<T, TP == 0>(st.o0, st.o1, st.tw[TP], st.c[(S + DX) % 3][R]);
         } else if constexpr (K == 10) {
-            unsigned pk;
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(st.o0), "v"(st.o1));
-            *reinterpret_cast<unsigned*>(smem + aw[S]) = pk;
+            *reinterpret_cast<unsigned*>(smem + aw[S]) = H16<T>::pack2(st.o0, st.o1);
         } else {
-            if constexpr (S + 1 < NSTEP) st.c[S % 3][K - 11] = unpack2<RELU>(st.d[K - 11]);
+            if constexpr (S + 1 < NSTEP) st.c[S % 3][K - 11] = unpack2<T, RELU>(st.d[K - 11]);
         }
     }
 }
 
-template <bool RELU, int PW, int LO, int HI>
-__device__ __forceinline__ void dw_ops(DwState& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[NSTEP]) {
+template <typename T, bool RELU, int PW, int LO, int HI>
+__device__ __forceinline__ void dw_ops(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[NSTEP]) {
     if constexpr (LO < HI) {
-        dw_op<RELU, PW, LO>(st, smem, raw_addr, tap_addr, aw);
-        dw_ops<RELU, PW, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
+        dw_op<T, RELU, PW, LO>(st, smem, raw_addr, tap_addr, aw);
+        dw_ops<T, RELU, PW, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
     }
 }
 
@@ -235,16 +257,26 @@ static_assert(dw_before(NSLOTQ) == NDW && dw_before(8) == NPRIME, "micro-operati
 // after the loop; (2) the wait states between a VALU write of an A/B operand register and the MFMA reading it -- the
 // operands here come straight from ds_read / global_load, and `make` runs check_wide.py over the generated assembly
 // to prove that no VALU instruction writes an operand within two instructions of its MFMA.
+template <typename T>
 __device__ __forceinline__ void mfma16(f32x4v& acc, const uint4& b, const uint4& a) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
-                 : "+a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
+    if constexpr (H16<T>::F16)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0"
+                     : "+a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                     : "+a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
 }
 // The very first k-step of a tile: C is the constant 0, the accumulators need no initialisation (120 writes per wave).
+template <typename T>
 __device__ __forceinline__ void mfma16_first(f32x4v& acc, const uint4& b, const uint4& a) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0"
-                 : "=a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
+    if constexpr (H16<T>::F16)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0"
+                     : "=a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0"
+                     : "=a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
 }
 
 // An LDS base address the compiler must take as it is: offsets beyond the 16-bit immediate of ds_* would otherwise be
@@ -262,8 +294,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <bool RELU, typename G>
+template <typename T, bool RELU, typename G>
 __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int IW = G::IW, IH = G::IH, TR = G::TR, TPI = G::TPI, PW = G::PW, NSLOT = G::NSLOT, HPW = G::HPW;
     constexpr int RAW_BYTES = G::RAW_BYTES, OFF_RAW = G::OFF_RAW, OFF_A = G::OFF_A, OFF_TAPS = G::OFF_TAPS;
     constexpr int STG_R1 = G::STG_R1, STG_W1 = G::STG_W1, STG_W2 = G::STG_W2, NRES1 = G::NRES1, NRES2 = G::NRES2;
@@ -373,11 +406,11 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     __syncthreads();
     WSTAMP(3);
     {   // D(0): the first A chunk, nothing to overlap it with
-        DwState st;
+        DwState<T> st;
         int aw0[NSTEP];
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) aw0[s] = opaque(OFF_A + aw[s]);
-        dw_ops<RELU, PW, 0, NDW>(st, smem, OFF_RAW + raw_lane, opaque(tap_lane), aw0);
+        dw_ops<T, RELU, PW, 0, NDW>(st, smem, OFF_RAW + raw_lane, opaque(tap_lane), aw0);
     }
     WSTAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // halo chunk 1
@@ -419,7 +452,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         for (int s = 0; s < NSTEP; ++s) awn[s] = opaque(OFF_A + NXT * A_BYTES + aw[s]);
         // taps of chunk c+1; the last chunk has 32 channels: pairs 16..31 read a clamped (valid, unused) address
         const int tap_addr = opaque(((c + 1 == NCH - 1 && cp >= 16) ? tap_lane - 128 : tap_lane) + (c + 1) * (KC * 4));
-        DwState st;
+        DwState<T> st;
         uint4 a[MF];
         const int ks0 = c * (KC / 32);
         static_for<0, KSC * MF * RN>([&](auto qc) {
@@ -430,11 +463,11 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                 for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR);
             }
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
-            if constexpr (DO_D) dw_ops<RELU, PW, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
+            if constexpr (DO_D) dw_ops<T, RELU, PW, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
-            if constexpr (FIRST && D == 0) mfma16_first(acc[I][J], bq[J], a[I]);
-            else mfma16(acc[I][J], bq[J], a[I]);
+            if constexpr (FIRST && D == 0) mfma16_first<T>(acc[I][J], bq[J], a[I]);
+            else mfma16<T>(acc[I][J], bq[J], a[I]);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 1))          // 1 = weights stay in registers
             if constexpr (I == MF - 1) {                        // the fragment is dead: fetch it for the next k-step
@@ -510,12 +543,12 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             float v2 = fmaf(acc[i][j][2], sc[j].z, bi[j].z);
             float v3 = fmaf(acc[i][j][3], sc[j].w, bi[j].w);
             if (has_res) {
-                v0 += __uint_as_float(u[j].x << 16); v1 += __uint_as_float(u[j].x & 0xffff0000u);
-                v2 += __uint_as_float(u[j].y << 16); v3 += __uint_as_float(u[j].y & 0xffff0000u);
+                v0 = H16<T>::add_lo(v0, u[j].x); v1 = H16<T>::add_hi(v1, u[j].x);
+                v2 = H16<T>::add_lo(v2, u[j].y); v3 = H16<T>::add_hi(v3, u[j].y);
             }
             uint2 o;
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.x) : "v"(v0), "v"(v1));
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o.y) : "v"(v2), "v"(v3));
+            o.x = H16<T>::pack2(v0, v1);
+            o.y = H16<T>::pack2(v2, v3);
             asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
             asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
             *reinterpret_cast<uint2*>(rowp + j * 32) = o;
@@ -543,31 +576,34 @@ using G19 = Geo<19, 4>;     // blocks 5-12 and block13_sepconv1: 5 tiles of 4 (t
 using G37 = Geo<37, 2>;     // block4_sepconv2: 19 tiles of 2 (the last: 1) rows per image
 
 bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo) {
-    return dtype == 1 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == W && (W == G19::IW || W == G37::IW) &&
+    return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == W && (W == G19::IW || W == G37::IW) &&
            K == KP && Nstore == KP && ldi == KP && ldo == KP;
 }
 
 // wp16: the layer's pointwise weights in 16x16x32 fragment order (blob entry "<layer>/wp16")
-int launch_sepconv_wide(int prod, const GemmParams& g, const void* wp16, hipStream_t s) {
+int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp16, hipStream_t s) {
     const bool big = g.W == G37::IW;
     const int hw = g.H * g.W;
     if ((g.W != G19::IW && !big) || g.H != g.W || g.M % hw != 0 || g.k_off != 0 || !g.scale || !g.bias || !wp16)
         return (int)hipErrorInvalidValue;
     WideParams p;
-    p.in = reinterpret_cast<const bf16_t*>(g.in);
+    p.in = reinterpret_cast<const h16_t*>(g.in);
     p.wp = reinterpret_cast<const uint4*>(wp16);
     p.dw = g.dw; p.scale = g.scale; p.bias = g.bias;
-    p.residual = reinterpret_cast<const bf16_t*>(g.residual);
-    p.out = reinterpret_cast<bf16_t*>(g.out);
+    p.residual = reinterpret_cast<const h16_t*>(g.residual);
+    p.out = reinterpret_cast<h16_t*>(g.out);
     p.n = g.M / hw;
     p.relu = g.relu;
     const bool relu_in = prod == PROD_DW_RELU;
-    void (*const kerns[4])(const WideParams) = {sepconv_wide_kernel<false, G19>, sepconv_wide_kernel<true, G19>,
-                                                sepconv_wide_kernel<false, G37>, sepconv_wide_kernel<true, G37>};
-    const int ki = (big ? 2 : 0) + (relu_in ? 1 : 0);
+    void (*const kerns[8])(const WideParams) = {
+        sepconv_wide_kernel<bf16_t, false, G19>, sepconv_wide_kernel<bf16_t, true, G19>,
+        sepconv_wide_kernel<bf16_t, false, G37>, sepconv_wide_kernel<bf16_t, true, G37>,
+        sepconv_wide_kernel<f16_t, false, G19>, sepconv_wide_kernel<f16_t, true, G19>,
+        sepconv_wide_kernel<f16_t, false, G37>, sepconv_wide_kernel<f16_t, true, G37>};
+    const int ki = (dtype == 2 ? 4 : 0) + (big ? 2 : 0) + (relu_in ? 1 : 0);
     auto kern = kerns[ki];
     const int tpi = big ? G37::TPI : G19::TPI;
-    static BqLdsAttr attr[4];
+    static BqLdsAttr attr[8];
     if (const int e = attr[ki].ensure(reinterpret_cast<const void*>(kern), LDS_TOTAL)) return e;
 #ifdef BQ_EXPERIMENTS
     // BQ_STAMPS_WIDE=<file>: in-kernel s_memtime stamps of the first launch with (BQ_STAMPS_NORES: without) a residual

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .hp import ModelParams, nature2022
-from .weights import pack_blob
+from .weights import DTYPE_CODE, pack_blob
 
 TILE_PX = 299
 
@@ -43,8 +43,9 @@ class Engine:
     """One MC-dropout inference context on one GPU.
 
     weights: dict of numpy arrays in Keras layout (``biscuit_amd.weights``).
-    dtype: 'bf16' (matrix-core bf16 backbone, fp32 accumulate/head) or 'f32' (exact
-    fp32 matrix-core path, the parity mode).
+    dtype: storage / matrix-core type of the backbone -- 'f16' (IEEE half: the throughput mode that holds the 1e-3
+    tolerance; saturates beyond +-65504), 'bf16' (same rate, 8x coarser rounding) or 'f32' (exact fp32 matrix-core
+    path, the parity mode).  Accumulation, folded BN and the MC head are fp32 in all three.
     """
 
     def __init__(self, weights, hp: ModelParams = None, dtype='bf16', max_batch=256, max_mc=30,
@@ -56,7 +57,9 @@ class Engine:
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
         self.max_batch, self.max_mc = int(max_batch), int(max_mc)
         self._lib = _lib.lib
-        cfg = _lib.BqConfig(_lib.BQ_DTYPE_BF16 if dtype == 'bf16' else _lib.BQ_DTYPE_F32,
+        if dtype not in DTYPE_CODE:
+            raise ValueError(f'dtype must be one of {sorted(DTYPE_CODE)}, not {dtype!r}')
+        cfg = _lib.BqConfig(DTYPE_CODE[dtype],
                             self.hp.tile_px, 2, float(self.hp.dropout), self.max_batch, self.max_mc)
         self._ctx = self._lib.bq_create(self.device.index, C.byref(cfg))
         if not self._ctx:
@@ -65,7 +68,7 @@ class Engine:
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         self._check(self._lib.bq_load_weights(self._ctx, C.cast(buf, C.c_void_p), len(blob)))
         self._ws = None
-        self._elt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+        self._elt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtype]
 
     # ------------------------------------------------------------------ utils
     def close(self):

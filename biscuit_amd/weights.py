@@ -201,6 +201,16 @@ def f32_to_bf16_bits(a):
     return r.astype(np.uint16)
 
 
+def f32_to_f16_bits(a):
+    """Round-to-nearest-even float32 -> IEEE half bit patterns (uint16); values beyond +-65504 saturate, as the
+    device's conversions do (MODE.FP16_OVFL)."""
+    a = np.clip(np.ascontiguousarray(a, dtype=np.float32), -65504.0, 65504.0)
+    return a.astype(np.float16).view(np.uint16)
+
+
+DTYPE_CODE = {'f32': 0, 'bf16': 1, 'f16': 2}      # BQ_DTYPE_* of include/biscuit_hip.h
+
+
 def nfrags_padded(n):
     nf = (n + 31) // 32
     return nf if nf <= 8 else (nf + 7) // 8 * 8
@@ -266,8 +276,10 @@ def _padvec(v, n):
 
 def pack_blob(w, dtype='bf16'):
     """Fold BN and serialise every tensor the device needs into one BQW1 blob."""
-    assert dtype in ('bf16', 'f32')
-    vec = 8 if dtype == 'bf16' else 4
+    assert dtype in DTYPE_CODE
+    half = dtype != 'f32'                       # a 16-bit matrix-core type
+    vec = 8 if half else 4
+    to_bits = {'bf16': f32_to_bf16_bits, 'f16': f32_to_f16_bits}.get(dtype)
     entries = []
 
     def add(name, arr):
@@ -275,7 +287,7 @@ def pack_blob(w, dtype='bf16'):
 
     def add_mat(name, wkn, kpad):
         p = pack_fragments(wkn, kpad, vec)
-        add(name + '/wp', f32_to_bf16_bits(p) if dtype == 'bf16' else p)
+        add(name + '/wp', to_bits(p) if half else p)
         return p.shape[0] * 32
 
     def add_affine(name, s, b, npad):
@@ -292,9 +304,9 @@ def pack_blob(w, dtype='bf16'):
     add_affine('block1_conv2', s, b, npad)
     for name, cin, cout in residual_plan():
         npad = add_mat(name, w[name + '_conv/kernel'].reshape(cin, cout), pad_channels(cin))
-        if dtype == 'bf16' and npad % 128 == 0 and cin <= 128:   # kernels_respool.hip: shortcut conv + max-pool + add
+        if half and npad % 128 == 0 and cin <= 128:   # kernels_respool.hip: shortcut conv + max-pool + add
             # in one kernel (blocks 2 and 3; the wider shortcuts measured faster as two kernels)
-            add(name + '/wp32', f32_to_bf16_bits(pack_fragments32(w[name + '_conv/kernel'].reshape(cin, cout),
+            add(name + '/wp32', to_bits(pack_fragments32(w[name + '_conv/kernel'].reshape(cin, cout),
                                                                   pad_channels(cin), npad)))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)
@@ -305,8 +317,8 @@ def pack_blob(w, dtype='bf16'):
         dw[:, :cin] = w[name + '/depthwise_kernel'].reshape(9, cin)
         add(name + '/dw', dw)
         npad = add_mat(name, w[name + '/pointwise_kernel'].reshape(cin, cout), cp)
-        if dtype == 'bf16' and name in wide and cp % 32 == 0:
-            add(name + '/wp16', f32_to_bf16_bits(pack_fragments16(w[name + '/pointwise_kernel'].reshape(cin, cout), cp, npad)))
+        if half and name in wide and cp % 32 == 0:
+            add(name + '/wp16', to_bits(pack_fragments16(w[name + '/pointwise_kernel'].reshape(cin, cout), cp, npad)))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)
     # head stays fp32 regardless of the backbone dtype (MC std ~1e-2 must not be
@@ -331,7 +343,7 @@ def pack_blob(w, dtype='bf16'):
         pad = (-len(raw)) % 256
         payload.append(raw + b'\0' * pad)
         off += len(raw) + pad
-    head = struct.pack('<4sIII', MAGIC, 1, len(entries), 1 if dtype == 'bf16' else 0)
+    head = struct.pack('<4sIII', MAGIC, 1, len(entries), DTYPE_CODE[dtype])
     blob = head + b''.join(directory)
     blob += b'\0' * ((-len(blob)) % 256)
     return blob + b''.join(payload)

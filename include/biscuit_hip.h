@@ -37,7 +37,10 @@ extern "C" {
 typedef struct bq_ctx bq_ctx;
 typedef void* bq_stream_t; /* hipStream_t */
 
-enum { BQ_DTYPE_F32 = 0, BQ_DTYPE_BF16 = 1 };
+/* Storage / matrix-core type of the backbone activations and weights (accumulation, folded BN, the MC head and
+ * every statistic are fp32 in all three).  F16 = IEEE half: the matrix-core rate of BF16 with 8x finer rounding;
+ * values beyond +-65504 saturate (MODE.FP16_OVFL) instead of overflowing to inf. */
+enum { BQ_DTYPE_F32 = 0, BQ_DTYPE_BF16 = 1, BQ_DTYPE_F16 = 2 };
 enum { BQ_MC_HEAD = 0, BQ_MC_FULL = 1 };
 
 enum {

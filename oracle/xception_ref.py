@@ -42,9 +42,20 @@ EXIT13 = [728, 1024]
 EXIT14 = [1536, 2048]
 
 
+F16_MAX = 65504.0
+
+
 def _q(x, on):
-    """Round to bfloat16 (RNE) and back when emulating the bf16 path."""
-    return x.to(torch.bfloat16).to(torch.float32) if on else x
+    """Round to the storage type of the 16-bit HIP paths (RNE) and back.
+
+    ``on`` is False/None (fp32), True/'bf16' (bfloat16) or 'f16' (IEEE half; the device
+    runs with MODE.FP16_OVFL set, so an overflow saturates at +-65504 instead of inf).
+    """
+    if not on:
+        return x
+    if on == 'f16':
+        return x.clamp(-F16_MAX, F16_MAX).to(torch.float16).to(torch.float32)
+    return x.to(torch.bfloat16).to(torch.float32)
 
 
 def _t(a):
@@ -70,10 +81,13 @@ def standardize(tiles_u8):
 
 
 class XceptionOracle:
-    def __init__(self, weights, dropout=0.1, emulate_bf16=False, threads=None):
+    def __init__(self, weights, dropout=0.1, emulate_bf16=False, threads=None, emulate=None):
         self.w = weights
         self.rate = float(dropout)
-        self.bf = bool(emulate_bf16)
+        # storage type emulated: None (fp32, THE parity oracle), 'bf16' or 'f16'
+        if emulate not in (None, 'bf16', 'f16'):
+            raise ValueError(f'emulate must be None, "bf16" or "f16", not {emulate!r}')
+        self.bf = emulate if emulate else ('bf16' if emulate_bf16 else None)
         if threads:
             torch.set_num_threads(int(threads))
 
