@@ -62,7 +62,7 @@ def main(argv=None):
     ap.add_argument('--mc', type=int, default=None, help='MC-dropout passes (default: uq_n of the model, 30)')
     ap.add_argument('--seed', type=int, default=1234)
     ap.add_argument('--batch', type=int, default=256)
-    ap.add_argument('--dtype', default='bf16', choices=['f16', 'bf16', 'f32'])
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'bf16', 'f32'])
     ap.add_argument('--streams', type=int, default=1,
                     help='batches in flight, each on its share of the chip (1 measured fastest through evaluate(): 25.8 k vs 25.4 k tiles/s)')
     ap.add_argument('--params', help="Slideflow params.json: its norm_fit switches on the reinhard_fast stain normaliser (hp.py:19)")

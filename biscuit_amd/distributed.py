@@ -34,17 +34,18 @@ def global_tile_offsets(tile_counts):
     return np.concatenate([[0], np.cumsum(counts)[:-1]]) if len(counts) else counts
 
 
-def init_from_env(device_type='cuda'):
-    """Initialise torch.distributed from torchrun's environment (RANK/WORLD_SIZE/...)."""
+def init_from_env(device_type='cuda', backend=None, local_device=None):
+    """Initialise torch.distributed from the launcher's rendezvous variables (torchrun's contract: RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_ADDR, MASTER_PORT -- the only environment this package reads).
+
+    backend: None = "nccl" (RCCL) for cuda, "gloo" for cpu; local_device: None = LOCAL_RANK.  Both are explicit
+    arguments so that a caller -- a test running two ranks on one GPU -- states them itself."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    # test hooks: several ranks on one GPU (BQ_LOCAL_DEVICE) need a non-RCCL backend (BQ_DIST_BACKEND=gloo)
-    if 'BQ_LOCAL_DEVICE' in os.environ:
-        local = int(os.environ['BQ_LOCAL_DEVICE'])
+    local = int(os.environ.get('LOCAL_RANK', '0')) if local_device is None else int(local_device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = os.environ.get('BQ_DIST_BACKEND') or ('nccl' if device_type == 'cuda' else 'gloo')
+        backend = backend or ('nccl' if device_type == 'cuda' else 'gloo')
         if device_type == 'cuda':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

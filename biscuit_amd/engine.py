@@ -48,7 +48,7 @@ class Engine:
     path, the parity mode).  Accumulation, folded BN and the MC head are fp32 in all three.
     """
 
-    def __init__(self, weights, hp: ModelParams = None, dtype='bf16', max_batch=256, max_mc=30,
+    def __init__(self, weights, hp: ModelParams = None, dtype='f16', max_batch=256, max_mc=30,
                  device=None):
         if not torch.cuda.is_available():
             raise BiscuitHipError('no HIP device visible: the MI355X path has no CPU fallback')
@@ -270,9 +270,8 @@ class EnginePool:
         # out of phase -- one's HBM-bound prologues/epilogues under the other's compute -- instead of
         # interleaving workgroups on every CU.  Measured at batch 256: 12.6-12.8 ms per batch vs 13.0 on one
         # stream and a bimodal 12.8 / 15.3 with two unmasked streams.  cu_split: 'contig' (default),
-        # 'xcd', 'interleave' (experiments) or None / BQ_CU_SPLIT=none for plain streams.
-        split = os.environ.get('BQ_CU_SPLIT', cu_split)
-        split = None if split in (None, '', 'none', '0') else split
+        # 'xcd', 'interleave' (experiments) or None / 'none' for plain streams.
+        split = None if cu_split in (None, '', 'none', '0') else cu_split
         self.device = dev
         self.hp = self.engines[0].hp
         self.cu_split = split

@@ -8,7 +8,9 @@ Inputs are not stored: tiles and weights are regenerated from seeds
 (``biscuit_amd.synthetic.make_slides(16, 64, seed=0)``, ``synthetic_weights(1)``, Philox
 seed 1234); the fixture holds the expected per-tile mean/std and per-slide means.
 
-usage: python oracle/make_producer_golden.py      (about 4 CPU-minutes on 8 cores)
+usage: python oracle/make_producer_golden.py [tag ...]     (about 2 CPU-minutes per tag on 8 cores)
+tags: f32 (the parity oracle), bf16emu, f16emu (the oracle with the 16-bit paths' rounding points).  Without arguments
+all three are generated; with arguments only the named ones are recomputed and the others kept from the existing file.
 """
 import os
 import sys
@@ -30,8 +32,14 @@ def main():
     w = synthetic_weights(CFG1['weight_seed'])
     t = time.time()
     res = {}
-    for tag, bf in (('f32', False), ('bf16emu', True)):
-        orc = XceptionOracle(w, emulate_bf16=bf)
+    modes = {'f32': None, 'bf16emu': 'bf16', 'f16emu': 'f16'}
+    want = sys.argv[1:] or list(modes)
+    if os.path.exists(out):                      # keep what is not being regenerated
+        old = np.load(out)
+        assert np.uint64(tiles.astype(np.uint64).sum()) == old['tile_checksum']
+        res = {k: old[k] for k in old.files if k.split('_')[-1] in modes and k.split('_')[-1] not in want}
+    for tag in want:
+        orc = XceptionOracle(w, emulate=modes[tag])
         mean, std = orc.mc_predict(tiles, CFG1['mc_n'], CFG1['dropout_seed'], mode='head', batch=32)
         res[f'mean_{tag}'] = mean.astype(np.float32)
         res[f'std_{tag}'] = std.astype(np.float32)

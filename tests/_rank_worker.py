@@ -1,6 +1,6 @@
 """Child process of the multi-rank GPU tests: one rank of ``inference.evaluate`` with the real ``Engine``
-(several ranks may share one GPU: BQ_LOCAL_DEVICE=0 and a gloo process group).  Writes its view of the
-result to ``argv[1]``.rank{r}.npz."""
+(several ranks may share one GPU: argv[6] = local device, argv[7] = process-group backend, e.g. "0 gloo").  Writes its
+view of the result to ``argv[1]``.rank{r}.npz."""
 import os
 import sys
 
@@ -19,11 +19,13 @@ def build_slides(counts):
 def main():
     out, dtype, mc_n, batch = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
     counts = [int(x) for x in sys.argv[5].split(',')]
+    local_device = int(sys.argv[6]) if len(sys.argv) > 6 else None
+    backend = sys.argv[7] if len(sys.argv) > 7 else None
     from biscuit_amd import distributed as D
     from biscuit_amd.engine import Engine
     from biscuit_amd.inference import evaluate
     from biscuit_amd.weights import synthetic_weights
-    rank, world, local = D.init_from_env('cuda')
+    rank, world, local = D.init_from_env('cuda', backend=backend, local_device=local_device)
     eng = Engine(synthetic_weights(1), dtype=dtype, max_batch=batch, max_mc=mc_n, device=local)
     res = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch, rank=rank, world=world)
     np.savez(f'{out}.rank{rank}.npz', slide_pred=res.slide_pred, slide_unc=res.slide_unc, slide_count=res.slide_count,

@@ -1,7 +1,7 @@
 """BASELINE.json configs 3, 4 and 5 and the parity stress set, on the MI355X (``-m gpu``).
 
 * config 3 (slides sharded over ranks, one gather): two ranks on ONE GPU -- the real ``Engine`` in each,
-  ``BQ_LOCAL_DEVICE=0`` + a gloo process group -- must reproduce the single-rank result exactly; and
+  an explicit local device 0 + a gloo process group -- must reproduce the single-rank result exactly; and
   ``bench.py --gpus 2`` must start its own two ranks.
 * config 4 (MC sweep N in {1,5,10,30,50}): the fused on-device Welford ('head') is bit-identical to N separate
   complete passes ('full') at every N, and matches the CPU oracle at N <= 10.
@@ -49,9 +49,9 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), BQ_LOCAL_DEVICE='0', BQ_DIST_BACKEND='gloo')
+                   MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_rank_worker.py'), out, 'bf16',
-                                       str(mc_n), str(batch), ','.join(map(str, counts))], env=env, cwd=ROOT))
+                                       str(mc_n), str(batch), ','.join(map(str, counts)), '0', 'gloo'], env=env, cwd=ROOT))
     assert [p.wait(timeout=600) for p in procs] == [0, 0]
     eng = Engine(synthetic_weights(1), dtype='bf16', max_batch=batch, max_mc=mc_n)
     single = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch)
@@ -76,16 +76,17 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
 
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the parent spawns two ranks before touching the
-    GPU and relays rank 0's JSON line (here both ranks share GPU 0 through the gloo hook)."""
+    GPU and relays rank 0's JSON line (here both ranks share GPU 0: --local-device 0 --dist-backend gloo)."""
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
-    env.update(BQ_LOCAL_DEVICE='0', BQ_DIST_BACKEND='gloo')
-    common = ['--steps', '2', '--warmup', '1', '--batch', '16', '--mc', '5', '--streams', '1', '--no-extras',
+    common = ['--local-device', '0', '--dist-backend', 'gloo', '--steps', '2', '--warmup', '1', '--batch', '16', '--mc', '5', '--streams', '1', '--no-extras',
               '--no-cpu-baseline', '--no-profile']
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + common, env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0 and line['steps'] == 2
+    # the collective really spanned both ranks (gloo here, so it is not counted as RCCL)
+    assert line['collective'] == {'backend': 'gloo', 'ranks_seen': 2, 'rccl_ranks': 0} and line['rccl_ranks'] == 0
     # the strong-scaling form of config 3 (scaled down): slides LPT-sharded through inference.evaluate
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'cfg3', '--slides', '6',
                         '--tiles-per-slide', '40'] + common, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -104,7 +105,8 @@ def test_bench_starts_its_own_ranks():
 def sweep_engines():
     from biscuit_amd.engine import Engine
     w = synthetic_weights(1)
-    e = {'f32': Engine(w, dtype='f32', max_batch=8, max_mc=50), 'bf16': Engine(w, dtype='bf16', max_batch=8, max_mc=50)}
+    e = {'f32': Engine(w, dtype='f32', max_batch=8, max_mc=50), 'bf16': Engine(w, dtype='bf16', max_batch=8, max_mc=50),
+         'f16': Engine(w, dtype='f16', max_batch=8, max_mc=50)}
     yield e
     for x in e.values():
         x.close()
@@ -114,7 +116,7 @@ def sweep_engines():
 def test_mc_sweep_fused_equals_separate_passes(sweep_engines, mc_n):
     tiles = make_tiles(5, seed=31)
     d = dev(tiles)
-    for dtype in ('f32', 'bf16'):
+    for dtype in ('f32', 'bf16', 'f16'):
         eng = sweep_engines[dtype]
         m_h, s_h = eng.mc_infer(d, mc_n, 1234, tile_idx0=40, mc_mode='head')
         m_f, s_f = eng.mc_infer(d, mc_n, 1234, tile_idx0=40, mc_mode='full')
@@ -164,14 +166,14 @@ def test_config5_harness_tfrecords_checkpoint_cli_threshold(tmp_path):
     assert list(df.columns[:2]) == ['slide', 'cohort-y_true0'] or 'cohort-y_pred1' in df.columns
     # the in-memory path on the same tiles, the same model hyper-parameters (dropout 0.2 from params.json)
     from biscuit_amd.hp import ModelParams
-    eng = Engine(w, hp=ModelParams(dropout=0.2), dtype='bf16', max_batch=16, max_mc=8)
+    eng = Engine(w, hp=ModelParams(dropout=0.2), dtype='f16', max_batch=16, max_mc=8)
     slides = [Slide(f's{i}', tiles[sidx == i], per, y_true=int(y[i])) for i in range(n_slides)]
     mem = evaluate(eng, slides, outcome='cohort', mc_n=8, seed=1234, batch=16, norm_fit=fit)
     np.testing.assert_allclose(df['cohort-y_pred1'].to_numpy(), mem.tile_df['cohort-y_pred1'].to_numpy(), rtol=0, atol=1e-7)
     np.testing.assert_allclose(df['cohort-uncertainty1'].to_numpy(), mem.tile_df['cohort-uncertainty1'].to_numpy(), rtol=0, atol=1e-7)
     assert list(df['slide']) == list(mem.tile_df['slide'])
     # dropout 0.2 really was used: the default-rate engine gives other uncertainties
-    eng01 = Engine(w, dtype='bf16', max_batch=16, max_mc=8)
+    eng01 = Engine(w, dtype='f16', max_batch=16, max_mc=8)
     other = evaluate(eng01, slides, outcome='cohort', mc_n=8, seed=1234, batch=16, norm_fit=fit)
     assert not np.allclose(other.tile_df['cohort-uncertainty1'].to_numpy(), df['cohort-uncertainty1'].to_numpy(), atol=1e-4)
     # consumer: the CSV through the reference's surface
@@ -194,9 +196,9 @@ def hard():
     from oracle.xception_ref import XceptionOracle
     w = synthetic_weights(1, hard=True)
     e = {'w': w, 'f32': Engine(w, dtype='f32', max_batch=64, max_mc=30), 'bf16': Engine(w, dtype='bf16', max_batch=64, max_mc=30),
-         'oracle': XceptionOracle(w)}
+         'f16': Engine(w, dtype='f16', max_batch=64, max_mc=30), 'oracle': XceptionOracle(w)}
     yield e
-    e['f32'].close(); e['bf16'].close()
+    e['f32'].close(); e['bf16'].close(); e['f16'].close()
 
 
 def test_hard_weights_fp32_kernels_against_both_oracles(hard):
@@ -227,26 +229,40 @@ def test_hard_weights_every_layer_fp32(hard):
         assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), name
 
 
-def test_hard_weights_bf16_kernels_reported(hard):
-    """bf16 kernels vs the exact fp32 kernels (= both oracles to 2e-5) on the stress set, 64 tiles, MC = 30.
-    HONEST FIGURE: with O(1) logits the bf16 path does NOT stay inside the 1e-3 north-star tolerance at tile
-    level (measured 2.7e-3 on mean, 1.3e-3 on std, 1.5e-3 on the slide mean of 16 tiles); the error is bf16
-    rounding of every activation, depthwise result and weight (relative 2^-9 each, features off by 3e-3 rms), not
-    a kernel defect -- the fp32 kernels are the parity mode (test above) and `bench.py` reports their rate next
-    to the bf16 one.  The bounds below only guard against a regression of that figure."""
+def _hard_deltas(hard, dtype):
+    """16-bit kernels against the exact fp32 kernels (= both oracles to 2e-5) on the stress set: 4 slides x 16 tiles,
+    MC = 30.  Returns tile max|d mean|, tile max|d std|, slide max|d pred|, slide max|d unc|."""
     tiles, sidx, _ = make_slides(4, 16, seed=7)
     d = dev(tiles)
     m32, s32 = hard['f32'].mc_infer(d, 30, 1234)
-    m16, s16 = hard['bf16'].mc_infer(d, 30, 1234)
-    dm, ds = float((m32 - m16).abs().max()), float((s32 - s16).abs().max())
+    m16, s16 = hard[dtype].mc_infer(d, 30, 1234)
     sl = dev(sidx).long()
 
     def smean(x):
         return torch.zeros(4, device='cuda', dtype=torch.float64).index_add_(0, sl, x.double()) / 16
-    dsp = float((smean(m32[:, 1]) - smean(m16[:, 1])).abs().max())
-    dsu = float((smean(s32[:, 1]) - smean(s16[:, 1])).abs().max())
+    return (float((m32 - m16).abs().max()), float((s32 - s16).abs().max()),
+            float((smean(m32[:, 1]) - smean(m16[:, 1])).abs().max()), float((smean(s32[:, 1]) - smean(s16[:, 1])).abs().max()))
+
+
+def test_hard_weights_throughput_mode_holds_tolerance(hard):
+    """THE parity claim of the headline mode.  BASELINE.json north_star: tile- and slide-level mean and sigma within
+    1e-3 of the reference.  f16 storage + f16 MFMAs (fp32 accumulation, fp32 folded BN, fp32 head) on weights with O(1)
+    logits and BatchNorm statistics far from the identity: measured 2.5e-4 / 1.0e-4 at tile level, 1.0e-4 / 1.1e-5 at
+    slide level -- a quarter of the budget."""
+    dm, ds, dsp, dsu = _hard_deltas(hard, 'f16')
+    print(f'hard weights, f16 vs fp32 kernels: tile max|dmean|={dm:.3e} max|dstd|={ds:.3e}; slide pred {dsp:.3e} unc {dsu:.3e}')
+    assert dm < NORTH_STAR_TOL and ds < NORTH_STAR_TOL and dsp < NORTH_STAR_TOL and dsu < NORTH_STAR_TOL
+
+
+def test_hard_weights_bf16_kernels_reported(hard):
+    """The same figure for the bf16 mode, which BASELINE config 2 names: with O(1) logits it does NOT stay inside 1e-3
+    (measured 2.7e-3 on the tile mean, 9e-4 on the tile std, 1.4e-3 on the slide mean of 16 tiles): the error is the
+    2^-9 relative rounding of every activation, depthwise result and weight, not a kernel defect -- which is why the
+    headline mode is f16 (test above).  The bounds below only guard against a regression of that figure."""
+    dm, ds, dsp, dsu = _hard_deltas(hard, 'bf16')
     print(f'hard weights, bf16 vs fp32 kernels: tile max|dmean|={dm:.3e} max|dstd|={ds:.3e}; slide pred {dsp:.3e} unc {dsu:.3e}')
     assert dm < BF16_HARD_TILE_BOUND and ds < BF16_HARD_TILE_BOUND and dsp < 3e-3 and dsu < 1e-3
 
 
+NORTH_STAR_TOL = 1e-3
 BF16_HARD_TILE_BOUND = 5e-3

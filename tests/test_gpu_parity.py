@@ -4,8 +4,10 @@ through size-independent properties.  Run on the MI355X box with ``-m gpu``.
 
 Tolerances (BASELINE.json north_star: tile- and slide-level mean/std within 1e-3 in fp32):
   * fp32 path vs fp32 oracle ........ 1e-4 on probabilities (measured ~1e-7), 2e-4 on layers
-  * bf16 path vs bf16-emulating oracle (same rounding points) 1e-3
-  * bf16 path vs fp32 oracle ........ 1e-3 at tile and slide level (measured in the report)
+  * f16 / bf16 path vs the oracle emulating the same storage type (same rounding points): 3e-4 / 1e-3 on
+    probabilities; per layer a max-abs bound in units of the storage type's ulp at the layer's magnitude
+  * f16 path (the throughput mode) vs fp32 oracle ........ 1e-3 at tile and slide level; measured 1-3e-4
+  * bf16 path vs fp32 oracle ........ 1e-3 on the default weights only (tests/test_gpu_configs.py has the stress set)
   * integer / index work (masks, counts, slide order) ........ bit-exact
 """
 import os
@@ -39,13 +41,15 @@ def weights():
 def engines(weights):
     from biscuit_amd.engine import Engine
     return {'f32': Engine(weights, dtype='f32', max_batch=256, max_mc=50),
-            'bf16': Engine(weights, dtype='bf16', max_batch=256, max_mc=50)}
+            'bf16': Engine(weights, dtype='bf16', max_batch=256, max_mc=50),
+            'f16': Engine(weights, dtype='f16', max_batch=256, max_mc=50)}
 
 
 @pytest.fixture(scope='module')
 def oracles(weights):
     from oracle.xception_ref import XceptionOracle
-    return {'f32': XceptionOracle(weights), 'bf16': XceptionOracle(weights, emulate_bf16=True)}
+    return {'f32': XceptionOracle(weights), 'bf16': XceptionOracle(weights, emulate='bf16'),
+            'f16': XceptionOracle(weights, emulate='f16')}
 
 
 @pytest.fixture(scope='module')
@@ -64,40 +68,72 @@ def test_native_library_is_loaded():
     assert 'libbiscuit_hip.so' in maps and os.path.exists(_lib.LIB_PATH)
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_stage_exact(engines, tiles, dtype):
     from oracle.xception_ref import standardize
     ref = standardize(tiles)
-    if dtype == 'bf16':
-        ref = ref.to(torch.bfloat16).float()
+    if dtype != 'f32':
+        ref = ref.to(torch.bfloat16 if dtype == 'bf16' else torch.float16).float()
     got = engines[dtype].stage(dev(tiles)).float().cpu()
     assert torch.equal(got, ref)            # integer statistics -> bit-exact
     const = np.full((1, 299, 299, 3), 9, np.uint8)         # std = 0 edge case (floor 1/sqrt(N))
     assert torch.all(engines[dtype].stage(dev(const)).float() == 0)
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+# relative size of the last place of the storage types (half an ulp is 2^-9 / 2^-12 of the value's binade)
+ULP = {'bf16': 2.0 ** -8, 'f16': 2.0 ** -11}
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_every_layer_against_oracle(engines, oracles, tiles, dtype):
+    """Every tapped layer against the oracle that rounds at the same points.  16-bit types: identical rounding points,
+    only the fp32 accumulation order differs, which flips an occasional last place, and the flips travel on and
+    multiply with depth (measured, tools/layer_ulps.py: 0.01 % of the values differ after the stem, 40 % after block 4,
+    80 % after block 12).  The bounds are therefore per depth, MAX-ABS in units of one ulp at the layer's largest
+    magnitude plus a relative rms in ulps, both about twice what was measured on the default and the stress weights:
+    a wrong tap, a swapped channel or a missed ReLU in ANY one layer is off by whole values -- tens to hundreds of ulps --
+    where a rounding flip is one."""
     from oracle.xception_ref import standardize
     taps = {}
     t2 = tiles[:2]
     feat_ref = oracles[dtype].backbone(standardize(t2), taps)
     eng = engines[dtype]
     staged = eng.stage(dev(t2))
-    for name, shp in TAPS:
+    report = []
+    for k, (name, shp) in enumerate(TAPS):
         got = eng.debug_activation(name, staged, shp).cpu().numpy()
         ref = taps[name].permute(0, 2, 3, 1).numpy()
         d = np.abs(got - ref)
         if dtype == 'f32':
             assert d.max() < 2e-4, (name, d.max())
         else:
-            # identical rounding points; only fp32 accumulation order differs, which flips an
-            # occasional bf16 rounding (1 ulp = 2^-8 relative) and propagates
+            ulp = ULP[dtype] * np.abs(ref).max()
             rms = np.sqrt((d ** 2).mean()) / np.sqrt((ref ** 2).mean())
-            assert rms < 2e-2 and not np.isnan(got).any(), (name, rms)
+            report.append((name, d.max() / ulp, rms / ULP[dtype]))
+            assert not np.isnan(got).any(), name
+            assert d.max() < layer_maxabs_ulps(k) * ulp, (name, d.max() / ulp, layer_maxabs_ulps(k))
+            assert rms < layer_rms_ulps(k) * ULP[dtype], (name, rms / ULP[dtype], layer_rms_ulps(k))
+    if report:
+        print(dtype, 'per-layer max|d| in ulps at max|x| / rel. rms in ulps:',
+              ' '.join(f'{n}:{a:.2f}/{b:.3f}' for n, a, b in report))
     feat = eng.backbone(staged).cpu().numpy()
-    tol = 1e-4 if dtype == 'f32' else 3e-2
-    assert np.abs(feat - feat_ref.numpy()).max() < tol
+    fr = feat_ref.numpy()
+    tol = 1e-4 if dtype == 'f32' else FEAT_MAXABS_ULPS * ULP[dtype] * np.abs(fr).max()
+    assert np.abs(feat - fr).max() < tol
+
+
+def layer_maxabs_ulps(k):
+    """Bound for tap k of TAPS (0 = staged tile ... 25 = block14_sepconv2).  Measured (both weight sets, both types): staged
+    0, stem <= 1.5, block 2-4 <= 2.7, blocks 5-12 <= 4.1, exit flow <= 3.8."""
+    return 0.5 if k == 0 else 2.0 + 0.25 * k
+
+
+def layer_rms_ulps(k):
+    """Measured: 0.01-0.04 after the stem, 0.2 after block 2, 1.2 after block 4, 2.3 after block 12, 2.9 at the end."""
+    return 0.05 if k == 0 else 0.1 + 0.2 * k
+
+
+FEAT_MAXABS_ULPS = 1.0      # pooled features average 100 pixels: measured 0.3-0.4
 
 
 def test_mc_head_against_oracle(engines, oracles):
@@ -125,17 +161,41 @@ def test_end_to_end_fp32(engines, oracles, tiles):
     np.testing.assert_allclose(s[:, 0], s[:, 1], atol=1e-6)
 
 
-def test_end_to_end_bf16(engines, oracles, tiles):
-    m, s = engines['bf16'].mc_infer(dev(tiles), 5, 1234)
+@pytest.mark.parametrize('dtype,tol_emu,tol_f32', [('bf16', 1e-3, 1e-3), ('f16', 3e-4, 3e-4)])
+def test_end_to_end_16bit(engines, oracles, tiles, dtype, tol_emu, tol_f32):
+    m, s = engines[dtype].mc_infer(dev(tiles), 5, 1234)
     m, s = m.cpu().numpy(), s.cpu().numpy()
-    rm, rs = oracles['bf16'].mc_predict(tiles, 5, 1234, mode='head')
-    assert np.abs(m - rm).max() < 1e-3 and np.abs(s - rs).max() < 1e-3
+    rm, rs = oracles[dtype].mc_predict(tiles, 5, 1234, mode='head')
+    assert np.abs(m - rm).max() < tol_emu and np.abs(s - rs).max() < tol_emu
     fm, fs = oracles['f32'].mc_predict(tiles, 5, 1234, mode='head')
-    print('bf16 HIP vs fp32 oracle: max|dmean|=%.3e max|dstd|=%.3e' % (np.abs(m - fm).max(), np.abs(s - fs).max()))
-    assert np.abs(m - fm).max() < 1e-3 and np.abs(s - fs).max() < 1e-3
+    print('%s HIP vs fp32 oracle: max|dmean|=%.3e max|dstd|=%.3e; vs the %s-emulating oracle %.3e / %.3e' % (
+        dtype, np.abs(m - fm).max(), np.abs(s - fs).max(), dtype, np.abs(m - rm).max(), np.abs(s - rs).max()))
+    assert np.abs(m - fm).max() < tol_f32 and np.abs(s - fs).max() < tol_f32
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_f16_saturates_instead_of_overflowing(engines):
+    """IEEE half ends at 65504.  Every kernel that writes f16 runs with MODE.FP16_OVFL set: an overflow becomes
+    +-65504, never inf (and so never NaN downstream), in the scalar conversion (staging) and in the packed one (every
+    MFMA epilogue)."""
+    eng = engines['f16']
+    big = torch.full((2, 299, 299, 3), 1.0e6, dtype=torch.float32, device='cuda')
+    big[1] = -3.0e5
+    st = eng.stage_f32(big).float()
+    assert float(st[0].max()) == 65504.0 and float(st[1].min()) == -65504.0 and torch.isfinite(st).all()
+    x = torch.randn(2, 299, 299, 3, device='cuda') * 3.0e4          # conv outputs far beyond 65504
+    staged = eng.stage_f32(x)
+    for name, shp in (('block1_conv2', (147, 147, 64)), ('block2_sepconv1', (147, 147, 128)), ('block2_out', (74, 74, 128)),
+                      ('block4_out', (19, 19, 728)), ('block8_out', (19, 19, 728)), ('block14_sepconv2', (10, 10, 2048))):
+        a = eng.debug_activation(name, staged, shp)
+        assert torch.isfinite(a).all(), name
+        assert float(a.abs().max()) <= 65504.0, name
+    a = eng.debug_activation('block1_conv2', staged, (147, 147, 64))
+    assert int((a == 65504.0).sum()) > 0                              # the clamp was really exercised
+    feat = eng.backbone(staged)
+    assert torch.isfinite(feat).all()
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_full_mode_batching_and_determinism_bit_exact(engines, tiles, dtype):
     eng = engines[dtype]
     d = dev(tiles)
@@ -156,7 +216,7 @@ def test_ragged_batch_sizes(engines, oracles, n):
     """Batches that do not fill a pixel tile / a row fragment (n = 1: 361 pixels at 19x19) and odd n."""
     t = make_tiles(n, seed=77)
     rm, rs = oracles['f32'].mc_predict(t, 3, 5, mode='head')
-    for dtype, tol in (('f32', 1e-4), ('bf16', 1e-3)):
+    for dtype, tol in (('f32', 1e-4), ('bf16', 1e-3), ('f16', 3e-4)):
         m, s = engines[dtype].mc_infer(dev(t), 3, 5)
         assert np.abs(m.cpu().numpy() - rm).max() < tol and np.abs(s.cpu().numpy() - rs).max() < tol
 
@@ -168,7 +228,8 @@ def test_golden_config1(engines):
     assert np.uint64(tiles.astype(np.uint64).sum()) == g['tile_checksum']      # same inputs as the fixture
     assert np.array_equal(sidx, g['slide_idx'])
     d_sidx = dev(sidx)
-    for dtype, key, tol_tile, tol_slide in (('f32', 'f32', 1e-4, 1e-5), ('bf16', 'bf16emu', 1e-3, 3e-4)):
+    for dtype, key, tol_tile, tol_slide in (('f32', 'f32', 1e-4, 1e-5), ('bf16', 'bf16emu', 1e-3, 3e-4),
+                                            ('f16', 'f16emu', 3e-4, 1e-4)):
         eng = engines[dtype]
         means, stds = [], []
         for a in range(0, 1024, 256):
@@ -181,12 +242,13 @@ def test_golden_config1(engines):
         assert list(cnt.cpu().numpy()) == [64] * 16
         assert np.abs(mp.cpu().numpy() - g[f'slide_pred_{key}']).max() < tol_slide
         assert np.abs(mu.cpu().numpy() - g[f'slide_unc_{key}']).max() < tol_slide
-        if dtype == 'bf16':      # and the headline claim: bf16 kernels vs the fp32 oracle, slide level
+        if dtype != 'f32':       # and the headline claim: the 16-bit kernels vs the fp32 oracle, tile and slide level
             d_pred = np.abs(mp.cpu().numpy() - g['slide_pred_f32']).max()
             d_unc = np.abs(mu.cpu().numpy() - g['slide_unc_f32']).max()
-            d_tile = np.abs(m.cpu().numpy() - g['mean_f32']).max()
-            print('bf16 HIP vs fp32 golden: tile max|d|=%.3e slide pred %.3e unc %.3e' % (d_tile, d_pred, d_unc))
-            assert d_pred < 1e-3 and d_unc < 1e-3 and d_tile < 1e-3
+            d_tile = max(np.abs(m.cpu().numpy() - g['mean_f32']).max(), np.abs(s.cpu().numpy() - g['std_f32']).max())
+            print('%s HIP vs fp32 golden: tile max|d|=%.3e slide pred %.3e unc %.3e' % (dtype, d_tile, d_pred, d_unc))
+            bound = 3e-4 if dtype == 'f16' else 1e-3          # north star: 1e-3; f16 is the mode that is held to it
+            assert d_pred < bound and d_unc < bound and d_tile < bound
 
 
 def test_slide_reduce_against_reference_consumer(engines, consumer_cases):
@@ -431,7 +493,7 @@ def test_uncertainty_interface_graph_replay_bit_identical(engines):
     from biscuit_amd.engine import UncertaintyInterface
     rng = np.random.default_rng(2)
     xs = [torch.from_numpy(rng.normal(0, 1, (1, 299, 299, 3)).astype(np.float32)).cuda() for _ in range(4)]
-    for dtype in ('bf16', 'f32'):
+    for dtype in ('f16', 'bf16', 'f32'):
         eager = UncertaintyInterface(engines[dtype], uq_n=30, seed=5)
         want = [eager.device_call(x) for x in xs]
         itf = UncertaintyInterface(engines[dtype], uq_n=30, seed=5)

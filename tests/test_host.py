@@ -66,6 +66,40 @@ def test_bf16_rounding_bits():
     assert (W.f32_to_bf16_bits(x) == want).all()
 
 
+def test_f16_rounding_bits_and_saturation():
+    import torch
+    x = np.random.default_rng(2).normal(size=1000).astype(np.float32)
+    x[:8] = [65504.0, 65519.9, 65520.0, 1e6, -1e6, 6.0e-8, -5.9e-8, 0.0]      # max, just below / at the rounding
+    want = torch.from_numpy(np.clip(x, -65504, 65504)).to(torch.float16).view(torch.int16).numpy().astype(np.uint16)
+    got = W.f32_to_f16_bits(x)
+    assert (got == want).all()
+    back = got.view(np.float16).astype(np.float32)
+    assert list(back[:5]) == [65504.0, 65504.0, 65504.0, 65504.0, -65504.0] and np.isfinite(back).all()   # saturates, never inf
+    assert back[5] == np.float32(2.0 ** -24) and back[6] == -np.float32(2.0 ** -24)                     # subnormals are kept
+
+
+def test_f16_blob_has_the_layout_of_the_bf16_one():
+    """The f16 blob differs from the bf16 one only in the matrix-core weights' bit patterns and the dtype code."""
+    w = W.synthetic_weights(3)
+    a, b = W.pack_blob(w, 'bf16'), W.pack_blob(w, 'f16')
+    assert len(a) == len(b) and struct.unpack_from('<4sIII', b, 0) == (b'BQW1', 1, struct.unpack_from('<4sIII', a, 0)[2], 2)
+    n = struct.unpack_from('<4sIII', a, 0)[2]
+    for i in range(n):
+        ea, eb = (struct.unpack_from('<48sQQ', x, 16 + 64 * i) for x in (a, b))
+        assert ea == eb
+        nm, off, ln = ea
+        nm = nm.rstrip(b'\0').decode()
+        half = nm.endswith(('/wp', '/wp16', '/wp32')) and not nm.startswith(('hidden_', 'logits'))
+        if not half:
+            assert a[off:off + ln] == b[off:off + ln], nm           # fp32 entries: taps, folded BN, head
+        elif nm == 'block5_sepconv2/wp':
+            fa = (np.frombuffer(a, np.uint16, ln // 2, off).astype(np.uint32) << 16).view(np.float32)
+            fb = np.frombuffer(b, np.float16, ln // 2, off).astype(np.float32)
+            ref = W.pack_fragments(w['block5_sepconv2/pointwise_kernel'].reshape(728, 728), 736, 8).ravel()
+            assert np.abs(fa - ref).max() <= np.abs(ref).max() * 2.0 ** -8
+            assert np.abs(fb - ref).max() <= np.abs(ref).max() * 2.0 ** -11      # 8x finer than bf16
+
+
 def test_blob_directory_roundtrip():
     w = W.synthetic_weights(3)
     blob = W.pack_blob(w, 'bf16')

@@ -104,9 +104,23 @@ def test_population_std(weights):
     np.testing.assert_allclose(m, passes.mean(axis=0), atol=1e-6)
 
 
-def test_bf16_emulation_close(weights, tiles):
+def test_16bit_emulation_close(weights, tiles):
     x = standardize(tiles[:1])
     f32 = XceptionOracle(weights).backbone(x)
     bf = XceptionOracle(weights, emulate_bf16=True).backbone(x)
+    assert torch.equal(bf, XceptionOracle(weights, emulate='bf16').backbone(x))       # the two spellings
     rel = ((bf - f32).pow(2).mean().sqrt() / f32.pow(2).mean().sqrt()).item()
     assert 0 < rel < 2e-2
+    h = XceptionOracle(weights, emulate='f16').backbone(x)
+    rel16 = ((h - f32).pow(2).mean().sqrt() / f32.pow(2).mean().sqrt()).item()
+    assert 0 < rel16 < rel / 4                      # three more significand bits: ~8x finer
+    with pytest.raises(ValueError):
+        XceptionOracle(weights, emulate='fp8')
+
+
+def test_f16_emulation_saturates():
+    from oracle.xception_ref import _q
+    t = torch.tensor([1e6, -1e6, 65504.0, 70000.0, 1.0, 6e-8])
+    q = _q(t, 'f16')
+    assert q.tolist()[:4] == [65504.0, -65504.0, 65504.0, 65504.0] and torch.isfinite(q).all()
+    assert torch.equal(_q(t, None), t) and torch.equal(_q(t, False), t)

@@ -1,5 +1,6 @@
 """Condense rocprofv3 CSV output (tools/profile.sh) into a small markdown summary that is
-committed under profiles/.  usage: python tools/summarize_prof.py gpurun_out/prof_r01 profiles/r01_rocprof.md"""
+committed under profiles/.  usage: python tools/summarize_prof.py gpurun_out/prof_r01 profiles/r01_rocprof.md [dtype]
+(dtype = the --dtype the profiled bench ran with, default f16: the key of the figure in profiles/traffic.json)"""
 import csv
 import glob
 import os
@@ -10,16 +11,17 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
-    m = re.match(r'_ZN12_GLOBAL__N_1\d+(sepconv_wide_kernel)I(.*)EEvNS_10WideParamsE', name) or \
-        re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+)I(.*)EEv10GemmParams', name)
-    if m:
-        args = m.group(2).replace('DF16b', 'bf16,').replace('Li', '').replace('E', ',').replace('Lb', 'b')
+    m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+)I(.*)EEv(?:NS_)?\d*[A-Za-z]*Params', name)
+    if m:        # mangled template arguments -> readable: DF16b = __bf16, DF16_ = _Float16, Li<n>E ints, Lb<0|1>E bools
+        args = m.group(2).replace('DF16b', 'bf16,').replace('DF16_', 'f16,').replace('Li', '').replace('E', ',').replace('Lb', 'b')
         return f'{m.group(1)}<{args.strip(",")}>'
+    name = name.replace('__bf16', 'bf16').replace('_Float16', 'f16')
     return name[:90]
 
 
 def main():
     src, out = sys.argv[1], sys.argv[2]
+    dtype = sys.argv[3] if len(sys.argv) > 3 else 'f16'
     lines = [f'# rocprofv3 summary ({os.path.basename(src)})', '',
              'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 8 '
              '--warmup 2 --no-cpu-baseline --no-profile --no-extras` (the default: up to 4 batches in flight), the same with '
@@ -113,10 +115,21 @@ def main():
             nl = sum((d.get('FETCH_SIZE') or d.get('WRITE_SIZE'))[1] for _, d in dom)
             fetch = sum(d['FETCH_SIZE'][0] * d['FETCH_SIZE'][1] for _, d in dom if 'FETCH_SIZE' in d) / max(nl, 1)
             write = sum(d['WRITE_SIZE'][0] * d['WRITE_SIZE'][1] for _, d in dom if 'WRITE_SIZE' in d) / max(nl, 1)
-            js = {'sepconv_k728_n728_19x19': {'fetch_size_kib': fetch, 'write_size_kib': write,
-                                              'corrected_bytes_per_launch': (2 * fetch + write) * 1024,
-                                              'source': os.path.basename(out), 'launches': nl}}
-            json.dump(js, open(os.path.join(os.path.dirname(out), 'traffic.json'), 'w'), indent=1)
+            tpath = os.path.join(os.path.dirname(out), 'traffic.json')
+            try:
+                js = json.load(open(tpath))
+                if '_source' not in js:          # round-2 layout (one bf16 entry at top level)
+                    js = {'bf16': js}
+            except (OSError, ValueError):
+                js = {}
+            js['_source'] = ('rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over '
+                             '`bench.py --steps 8 --warmup 2 --dtype <key>` at batch 256 on one MI355X (tools/profile.sh); '
+                             'corrected = (2 x FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md; per-dtype `source` names '
+                             'the committed summary')
+            js.setdefault(dtype, {})['sepconv_k728_n728_19x19'] = {
+                'fetch_size_kib': fetch, 'write_size_kib': write, 'corrected_bytes_per_launch': (2 * fetch + write) * 1024,
+                'source': os.path.basename(out), 'launches': nl}
+            json.dump(js, open(tpath, 'w'), indent=1)
             lines += [f'Dominant kernel (1280 workgroups): FETCH_SIZE {fetch:.0f} KiB, WRITE_SIZE {write:.0f} KiB per launch '
                       f'-> corrected {(2 * fetch + write) * 1024 / 1e6:.1f} MB (algorithmic 270 MB incl. residual reads).', '']
     open(out, 'w').write('\n'.join(lines) + '\n')
