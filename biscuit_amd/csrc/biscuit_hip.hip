@@ -259,10 +259,10 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     }
     static const bool no_wide = bq_exp_env("BQ_NO_WIDE") != nullptr;
     if (!no_wide && nsplit == 1 && L.wp16 && a.H == a.Hi && a.W == a.Wi &&
-        wide_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, a.ldo, a.ldi, a.ldo) && p.M % (a.H * a.W) == 0) {
+        wide_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, a.ldo, a.ldi, a.ldo, p.M)) {
         p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
-        const int e = launch_sepconv_wide(dtype, a.prod, p, L.wp16, s);
+        const int e = launch_sepconv_wide(dtype, a.prod, p, L.wp16, c->num_cus, s);
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(wide) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;

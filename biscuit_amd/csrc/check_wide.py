@@ -4,8 +4,10 @@
 The kernel issues its MFMAs as inline asm (accumulators tied in place in the accumulator file) and its LDS-DMA as
 inline asm too, so hipcc neither pads their hazards nor counts their memory operations.  This script reads the
 generated assembly and fails the build unless, in every sepconv_wide*_kernel instance:
-  * nothing uses scratch (a spill reload is a vector-memory operation the loop's counted `s_waitcnt vmcnt(N)` does not
-    expect; it would also sit in the hot loop);
+  * nothing uses scratch between the first and the last MFMA, i.e. inside the K loop (a spill reload is a vector-memory
+    operation the loop's counted `s_waitcnt vmcnt(N)` does not expect; it would also sit in the hot loop).  The
+    persistent kernel's once-per-workgroup prologue and per-tile epilogue may park a few per-lane constants there (the
+    compiler counts those itself); more than 8 spilled dwords fail the build all the same;
   * every v_mfma keeps its accumulator in place (dst == C); a tile kept in ordinary registers is touched by no other
     instruction between the first and the last MFMA, and nothing but MFMAs touches the accumulator file in between;
   * no VALU instruction writes a register of an MFMA's A/B operands within the two instructions in front of it
@@ -15,8 +17,9 @@ generated assembly and fails the build unless, in every sepconv_wide*_kernel ins
 import re
 import sys
 
+warn_only = '--warn' in sys.argv          # experiments builds (in-kernel stamps cost registers): report, do not fail
 kernels = []
-for path in sys.argv[1:]:
+for path in [a for a in sys.argv[1:] if a != '--warn']:
     found = re.findall(r'^(_ZN\S*sepconv_wide\d*_kernel\S*):[^\n]*\n(.*?)s_endpgm', open(path).read(), re.S | re.M)
     if not found:
         sys.exit('check_wide: no sepconv_wide*_kernel instance found in ' + path)
@@ -37,8 +40,6 @@ def regs(tok):
 
 VALU = re.compile(r'^v_(?!mfma|accvgpr)')
 for name, body in kernels:
-    if 'scratch_' in body:
-        bad.append(f'{name}: scratch access ({body.count("scratch_")} instructions)')
     ins = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith((';', '.'))]
     n_mfma = 0
     first_mfma = last_mfma = None
@@ -62,6 +63,13 @@ for name, body in kernels:
     if n_mfma == 0:
         bad.append(f'{name}: no MFMA found')
         continue
+    in_loop = [ln for ln in ins[first_mfma:last_mfma + 1] if ln.startswith('scratch_')]
+    if in_loop:
+        bad.append(f'{name}: {len(in_loop)} scratch access(es) inside the K loop, e.g. {in_loop[0]!r}')
+    spilled = sum({'dword': 1, 'dwordx2': 2, 'dwordx3': 3, 'dwordx4': 4}.get(ln.split()[0].rsplit('_', 1)[-1], 4)
+                  for ln in ins if ln.startswith('scratch_store'))
+    if spilled > 8:
+        bad.append(f'{name}: {spilled} dwords spilled outside the K loop (limit 8)')
     for ln in ins[first_mfma:last_mfma]:
         if not ln.startswith('v_mfma') and ln.split(None, 1)[0][:2] in ('v_', 'ds', 'gl', 'bu', 'fl') and len(ln.split(None, 1)) > 1 \
                 and regs(ln.split(None, 1)[1]) & vacc:
@@ -109,8 +117,8 @@ for name, body in kernels:
         m = re.match(r's_nop\s+(\d+)', ln)
         states += int(m.group(1)) + 1 if m else 1
 if bad:
-    print('check_wide: FAILED', file=sys.stderr)
+    print('check_wide: FAILED' + (' (warning only)' if warn_only else ''), file=sys.stderr)
     for b in bad[:20]:
         print('  ' + b, file=sys.stderr)
-    sys.exit(1)
-print(f'check_wide: ok ({len(kernels)} instances: accumulators in place, no scratch, no VALU->MFMA operand hazard)')
+    sys.exit(0 if warn_only else 1)
+print(f'check_wide: ok ({len(kernels)} instances: accumulators in place, no scratch in the K loop, no VALU->MFMA operand hazard)')

@@ -50,11 +50,12 @@ constexpr int WN = 8, RN = 6, MF = 5;   // waves, 16-wide n-fragments per wave, 
 constexpr int NFT = WN * RN;            // 48 n-fragments of 16 output channels
 constexpr int CPW = RN * 16;            // 96 output channels per wave
 constexpr int TAPS_BYTES = 9 * KP * 4;
-constexpr int STG_ROW = CPW * 2 + 16;    // 13 pieces of 16 B: odd
-constexpr int STG_PPR = STG_ROW / 16;
 constexpr int SB_BYTES = 2 * 768 * 4;
-constexpr int LDS_TOTAL = 160 * 1024;
-constexpr int OFF_SB = LDS_TOTAL - SB_BYTES;
+constexpr int RES_ROWS = 32;             // residual rows that go through LDS (row fragments 0 and 1)
+constexpr int RES_PPR = CPW * 2 / 16 + 1; // 13 pieces of 16 B per row: odd
+constexpr int RES_STR = RES_PPR * 16;
+constexpr int NRES = (RES_ROWS * RES_PPR + 63) / 64;   // LDS-DMA instructions per wave: 7, one per chunk
+static_assert(NRES <= NCH - 2, "the residual prefetch needs one loop iteration of the tile's own per instruction");
 
 // Geometry of one instance: IW x IW maps, TR map rows per tile (TR * IW <= 80 pixels).
 template <int IW_, int TR_>
@@ -67,21 +68,22 @@ struct Geo {
     static constexpr int HPW = (NDMA + WN - 1) / WN;         // ... per wave
     static constexpr int RAW_BYTES = HPW * WN * 1024;
     static constexpr int SEG = 16 / TR;                      // depthwise runs per tile row (16 lane groups in all)
-    // LDS map.  Loop buffers first, the folded-BN table at the very top; the epilogue's staging tile (per wave 80 rows of
-    // its 96 channels) in two pieces: rows [0, STG_R1) above the loop's buffers (free while the loop runs: the residual
-    // tile's first rows are copied there under the loop), rows [STG_R1, 80) over the loop's buffers
-    static constexpr int OFF_RAW = 0;                        // 2 halo images (bf16, as they arrive)
-    static constexpr int OFF_A = OFF_RAW + 2 * RAW_BYTES;
+    // LDS map: the loop's buffers and the two tables.  Round 3: there is NO staging tile any more -- the epilogue goes
+    // from the accumulators straight to HBM (see the kernel), so nothing of a tile's end touches LDS and the next
+    // tile's halo, taps and first A chunk can be in place before the current tile's epilogue starts.
+    // (A chunks, taps and tables first: every address the K loop forms from them is a per-lane base plus an offset that
+    // fits the 16-bit immediate of ds_*; the halo images come last)
+    static constexpr int OFF_A = 0;
     static constexpr int OFF_TAPS = OFF_A + 2 * A_BYTES;
-    static constexpr int LOOP_END = OFF_TAPS + TAPS_BYTES;
-    static constexpr int STG_R1 = (OFF_SB - LOOP_END) / (WN * STG_ROW) < MT ? (OFF_SB - LOOP_END) / (WN * STG_ROW) : MT;
-    static constexpr int STG_W1 = STG_R1 * STG_ROW, STG_W2 = (MT - STG_R1) * STG_ROW;
-    static constexpr int NRES1 = (STG_R1 * STG_PPR + 63) / 64;          // LDS-DMA instructions per wave and piece
-    static constexpr int NRES2 = ((MT - STG_R1) * STG_PPR + 63) / 64;
-    static constexpr int OFF_STG1 = LOOP_END, OFF_STG2 = 0;
-    static_assert(OFF_STG1 + WN * STG_W1 <= OFF_SB && OFF_STG2 + WN * STG_W2 <= LOOP_END, "LDS budget");
+    static constexpr int OFF_SB = OFF_TAPS + TAPS_BYTES;
+    static constexpr int OFF_RAW = OFF_SB + SB_BYTES;        // 2 halo images (16-bit, as they arrive)
+    // the first RES_ROWS rows of a tile's residual input, per wave its 96 channels (RES_STR: 12 pieces + 1 of padding),
+    // copied in by LDS-DMA while the K loop runs; nothing else ever uses this region
+    static constexpr int OFF_RES = OFF_RAW + 2 * RAW_BYTES;
+    static constexpr int LDS_BYTES = OFF_RES + WN * RES_ROWS * RES_STR;
+    static_assert(OFF_RAW < 65536, "immediate offsets of the A / tap / table accesses");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(SEG * NSTEP >= IW && SEG * TR == 16 && TR * IW <= MT, "depthwise runs do not cover the tile");
-    static_assert(NRES1 <= NCH, "the residual prefetch needs one loop iteration per instruction");
 };
 
 typedef unsigned short h16_t;   // either 16-bit storage type (the kernel only forms byte addresses from these)
@@ -96,6 +98,7 @@ struct WideParams {
     h16_t* out;             // [n*361][736]
     int n;                  // images
     int relu;               // ReLU in the epilogue
+    int nwg;                // persistent workgroups launched (a multiple of 8)
 #ifdef BQ_EXPERIMENTS
     unsigned long long* stamps;   // s_memtime stamps [64 blocks from stamp_b0][wave][32] (diagnostic builds only)
     unsigned stamp_b0;
@@ -103,7 +106,8 @@ struct WideParams {
 };
 
 #ifdef BQ_EXPERIMENTS
-#define WSTAMP(ev) do { if (stp) stp[ev] = __builtin_amdgcn_s_memtime(); } while (0)
+constexpr int STAMP_TILES = 8;        // tiles of a workgroup that get a row of 32 stamps each
+#define WSTAMP(ev) do { if (stp && stamp_it < STAMP_TILES) stp[stamp_it * 32 + (ev)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WSTAMP(ev) do { } while (0)
 #endif
@@ -193,8 +197,24 @@ __device__ __forceinline__ unsigned raw_dword(const unsigned char* smem, int raw
     return *reinterpret_cast<const unsigned*>(smem + raw_addr + ((j + 1) + r * PW) * 128);
 }
 
-template <typename T, bool RELU, int PW, int M>
-__device__ __forceinline__ void dw_op(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[NSTEP]) {
+// where pixel s of a lane's run writes its result: base + s * A_STR (the offset folds into the ds_write), or one of the NT
+// explicit addresses of the run's last steps (see OOB0 in the kernel)
+template <int NT>
+struct AwAddr {
+    int base;
+    int dump;                       // the lane's slot in row 80
+    unsigned long long last;        // lanes whose run is the last of its map row (steps >= NSTEP - NT lie past the row)
+    template <int S> __device__ __forceinline__ int at() const {
+        if constexpr (S >= NSTEP - NT) {
+            int r;                  // a select on a scalar lane mask: no per-lane register per step kept across the K loop
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(base + S * A_STR), "v"(dump), "s"(last));
+            return r;
+        } else return base + S * A_STR;
+    }
+};
+
+template <typename T, bool RELU, int PW, int M, typename AW>
+__device__ __forceinline__ void dw_op(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const AW& aw) {
     if constexpr (M < 3) {
 #pragma unroll
         for (int t = 3 * M; t < 3 * M + 3; ++t) st.tw[t] = *reinterpret_cast<const float2*>(smem + tap_addr + t * KP * 4);
@@ -221,15 +241,15 @@ __device__ __forceinline__ void dw_op(DwState<T>& st, unsigned char* smem, int r
             constexpr int TP = K < 7 ? K : K - 1, R = TP / 3, DX = TP % 3;
             tap2<T, TP == 0>(st.o0, st.o1, st.tw[TP], st.c[(S + DX) % 3][R]);
         } else if constexpr (K == 10) {
-            *reinterpret_cast<unsigned*>(smem + aw[S]) = H16<T>::pack2(st.o0, st.o1);
+            *reinterpret_cast<unsigned*>(smem + aw.template at<S>()) = H16<T>::pack2(st.o0, st.o1);
         } else {
             if constexpr (S + 1 < NSTEP) st.c[S % 3][K - 11] = unpack2<T, RELU>(st.d[K - 11]);
         }
     }
 }
 
-template <typename T, bool RELU, int PW, int LO, int HI>
-__device__ __forceinline__ void dw_ops(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const int (&aw)[NSTEP]) {
+template <typename T, bool RELU, int PW, int LO, int HI, typename AW>
+__device__ __forceinline__ void dw_ops(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const AW& aw) {
     if constexpr (LO < HI) {
         dw_op<T, RELU, PW, LO>(st, smem, raw_addr, tap_addr, aw);
         dw_ops<T, RELU, PW, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
@@ -294,54 +314,58 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <typename T, bool RELU, typename G>
+// RES: the layer has a residual input (compile time: the epilogue's loads are then branch-free)
+template <typename T, bool RELU, bool RES, typename G>
 __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams p) {
     if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int IW = G::IW, IH = G::IH, TR = G::TR, TPI = G::TPI, PW = G::PW, NSLOT = G::NSLOT, HPW = G::HPW;
-    constexpr int RAW_BYTES = G::RAW_BYTES, OFF_RAW = G::OFF_RAW, OFF_A = G::OFF_A, OFF_TAPS = G::OFF_TAPS;
-    constexpr int STG_R1 = G::STG_R1, STG_W1 = G::STG_W1, STG_W2 = G::STG_W2, NRES1 = G::NRES1, NRES2 = G::NRES2;
-    constexpr int OFF_STG1 = G::OFF_STG1, OFF_STG2 = G::OFF_STG2;
+    constexpr int RAW_BYTES = G::RAW_BYTES, OFF_RAW = G::OFF_RAW, OFF_A = G::OFF_A, OFF_TAPS = G::OFF_TAPS, OFF_SB = G::OFF_SB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int img = tile / TPI, part = tile - img * TPI;
-    const int r0 = part * TR;                                   // first map row of the tile
-    const int npix = (IH - r0 < TR ? IH - r0 : TR) * IW;        // valid output pixels (76 or 57)
-    const int m0 = img * (IH * IW) + r0 * IW;                   // their first global pixel index
+    // Persistent: this workgroup walks the tiles xcd_tile(vb), vb = blockIdx.x, + nwg, + 2 nwg, ... (nwg is a multiple
+    // of 8, so all of them come from the XCD's own run of neighbouring tiles)
+    const int ntiles = p.n * TPI;
+    const int nwg = gridDim.x;
+    int vb = blockIdx.x;
 
 #ifdef BQ_EXPERIMENTS
-    unsigned long long* stp = (p.stamps && blockIdx.x >= p.stamp_b0 && blockIdx.x < p.stamp_b0 + 64 && lane == 0)
-                                  ? p.stamps + ((blockIdx.x - p.stamp_b0) * WN + wave) * 32 : nullptr;
+    // (a wave-uniform pointer: every lane stores the same stamp to the same address -- no per-lane registers)
+    unsigned long long* stp = (p.stamps && blockIdx.x >= p.stamp_b0 && blockIdx.x < p.stamp_b0 + 64)
+                                  ? p.stamps + ((blockIdx.x - p.stamp_b0) * WN + wave) * (32 * STAMP_TILES) : nullptr;
+    int stamp_it = 0;
 #endif
     WSTAMP(0);
-    // ---- per-lane constants -------------------------------------------------------------------------------
-    // halo DMA: instruction j = wave + 8t covers pieces [64j, 64j+64) of the padded image (piece = slot*8 + 16-byte part)
-    unsigned halo_off[HPW];
-    unsigned long long halo_mask[HPW];
-#pragma unroll
-    for (int t = 0; t < HPW; ++t) {
-        const int P = (wave + WN * t) * 64 + lane;
+    // ---- per-lane constants (none depends on the tile) ---------------------------------------------------------
+    // halo image: piece P = (wave + 8 t) * 64 + lane of the padded image (piece = slot * 8 + 16-byte part), i.e. LDS-DMA
+    // instruction wave + 8 t covers pieces [64 (wave + 8t), + 64); the same P is the piece this thread zeroes when its slot
+    // lies outside the map.  The slot geometry is recomputed once per tile (divisions by constants) rather than kept in
+    // registers across the K loop.
+    const unsigned voff = lane * 16;                            // (also the per-lane offset of the weight loads)
+    auto piece_geo = [&](int t, int& sy, unsigned& rel) {       // sy: slot row 0 .. TR+1, or -1 (pad column / past the image)
+        const int P = (wave + WN * t) * 64 + (opaque((int)voff) >> 4);   // opaque: recomputed per tile, not hoisted and kept
         const int slot = P >> 3, piece = P & 7;
-        const int sy = slot / PW, sx = slot - sy * PW;
-        const int row = r0 + sy - 1, x = sx - 1;
-        const bool ok = slot < NSLOT && (unsigned)x < (unsigned)IW && (unsigned)row < (unsigned)IH;
-        halo_off[t] = ok ? (unsigned)(((img * IH + row) * IW + x) * KP + piece * 8) * 2u : 0u;
-        halo_mask[t] = __builtin_amdgcn_ballot_w64(ok);
-    }
+        const int y = slot / PW, sx = slot - y * PW;
+        const int x = sx - 1;
+        const bool col_ok = slot < NSLOT && (unsigned)x < (unsigned)IW;
+        sy = col_ok ? y : -1;
+        rel = col_ok ? (unsigned)((y * IW + x) * KP + piece * 8) * 2u : 0u;   // bytes from the tile's map row r0 - 1, column 0
+    };
     const unsigned long long tail_lanes = 0x0F0F0F0F0F0F0F0Full;    // pieces 0..3: the 32 channels of the last chunk
 
-    // depthwise: channel pair cp, lane group grp (0..15) = tile row grp >> 2, pixels [5 (grp & 3), 5 (grp & 3) + 5) of it
+    // depthwise: channel pair cp, lane group grp (0..15) = tile row grp / SEG, pixels [5 (grp % SEG), + 5) of it
     const int cp = lane & 31;
     const int grp = wave * 2 + (lane >> 5);
     const int drow = grp / G::SEG, dx0 = (grp - drow * G::SEG) * NSTEP;
     const int raw_lane = (drow * PW + dx0) * 128 + cp * 4;      // slot (row - 1, x0 - 1) of the padded image: column -1, row -1
-    int aw[NSTEP];                                              // A-chunk address of each pixel's result (row 80: past the map row)
-#pragma unroll
-    for (int s = 0; s < NSTEP; ++s) aw[s] = (dx0 + s < IW ? drow * IW + dx0 + s : MT) * A_STR + cp * 4;
+    // A-chunk address of pixel s of the run: awb + s * A_STR, except where the run runs past the end of its map row (only
+    // the last run of a row, from step OOB0 on): those results go to row 80, which nobody reads
+    constexpr int OOB0 = IW - (G::SEG - 1) * NSTEP;             // first step of the last run that can lie past the row
+    const int awb = (drow * IW + dx0) * A_STR + cp * 4;
+    const unsigned long long last_run = __builtin_amdgcn_ballot_w64(dx0 + OOB0 >= IW);
     const int tap_lane = OFF_TAPS + cp * 8;
 
     // matrix stage: lane -> (row l&15 of a 16-row fragment, 16-byte k-group l>>4)
@@ -350,7 +374,6 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     // weights [k-step][48 n-fragments][64 lanes] x 16 B: a wave's 6 fragments of one k-step are 6 KiB in a row;
     // uniform base per k-step and 4 KiB (the immediate reaches 4 KiB) + one per-lane offset
     const unsigned char* __restrict__ wbase = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)nfb * 1024;
-    const unsigned voff = lane * 16;
     auto load_b = [&](int ks, int j) {
         // the base is uniform: hand it to the compiler as scalars so that the load takes the scalar-base form (no
         // 64-bit vector address arithmetic per fragment)
@@ -363,11 +386,52 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     const int a_lane = r16 * A_STR + kg * 16;
+    const int ch0 = wave * CPW;
 
-    // ---- prologue: every load the first stages need goes out before anything waits ---------------------------
+    // ---- per-tile state ------------------------------------------------------------------------------------------
     const unsigned char* inb = reinterpret_cast<const unsigned char*>(p.in);
+    unsigned halo_off[HPW];                 // byte offsets of this thread's halo pieces (0 where masked)
+    unsigned long long halo_mask[HPW];      // lanes of DMA instruction wave + 8t that lie inside the map
+    unsigned zero_bits = 0;                 // bit t: piece t of this thread is a map-row slot outside the map (wants zeros)
+    int t_m0 = 0, t_npix = 0;               // first global pixel and number of valid pixels of the tile being computed
+    auto tile_setup = [&](int v, int& m0, int& npix) {
+        const int tile = xcd_tile(v, ntiles);
+        const int img = tile / TPI, part = tile - img * TPI;
+        const int r0 = part * TR;                                   // first map row of the tile
+        npix = (IH - r0 < TR ? IH - r0 : TR) * IW;                  // valid output pixels (76 or 57)
+        m0 = img * (IH * IW) + r0 * IW;                             // their first global pixel index
+        const unsigned base = (unsigned)(m0 - IW) * (unsigned)(KP * 2);   // map row r0 - 1 (wraps for r0 = 0: only used where ok)
+        zero_bits = 0;
 #pragma unroll
-    for (int t = 0; t < HPW; ++t) dma16(inb, halo_off[t], lds0 + OFF_RAW + (wave + WN * t) * 1024, halo_mask[t]);
+        for (int t = 0; t < HPW; ++t) {
+            int sy; unsigned rel;
+            piece_geo(t, sy, rel);
+            const int row = r0 + sy - 1;
+            const bool ok = sy >= 0 && (unsigned)row < (unsigned)IH;
+            halo_off[t] = ok ? base + rel : 0u;
+            halo_mask[t] = __builtin_amdgcn_ballot_w64(ok);
+            zero_bits |= (sy >= 0 && !ok) ? (1u << t) : 0u;
+        }
+    };
+    // chunk cc of the tile the halo constants describe -> raw[buf]; rows of the padded image that lie outside the map
+    // are zeroed (a pad column never holds anything but the zeros written at the start)
+    auto halo_dma = [&](int cc, int buf) {
+        const unsigned long long tl = cc == NCH - 1 ? tail_lanes : ~0ull;
+#pragma unroll
+        for (int t = 0; t < HPW; ++t)
+            dma16(inb + cc * (KC * 2), halo_off[t], lds0 + OFF_RAW + buf * RAW_BYTES + (wave + WN * t) * 1024, halo_mask[t] & tl);
+    };
+    auto halo_zero = [&](int buf) {
+        const unsigned z = (unsigned)opaque(0);                 // (a zero vector kept across the K loop is four registers)
+#pragma unroll
+        for (int t = 0; t < HPW; ++t)
+            if ((zero_bits >> t) & 1u)
+                *reinterpret_cast<uint4*>(smem + OFF_RAW + buf * RAW_BYTES + (wave + WN * t) * 1024 + voff) = make_uint4(z, z, z, z);
+    };
+
+    // ---- prologue, once per workgroup: every load the first stages need goes out before anything waits --------
+    tile_setup(vb, t_m0, t_npix);
+    halo_dma(0, 0);
     {   // depthwise taps (26 496 B) and folded BN (2 x 3 072 B): plain copies, wave w takes instructions w, w+8, ...
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -382,20 +446,16 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     uint4 bq[RN];
 #pragma unroll
     for (int j = 0; j < RN; ++j) bq[j] = load_b(0, j);
-#pragma unroll
-    for (int t = 0; t < HPW; ++t)
-        dma16(inb + KC * 2, halo_off[t], lds0 + OFF_RAW + RAW_BYTES + (wave + WN * t) * 1024, halo_mask[t]);
-    // zero the slots the DMA never writes (pad columns, rows outside the map) in both halo buffers
+    halo_dma(1, 1);
+    // zero what the DMA never writes: pad columns and slots past the image once and for all, map rows outside the map
+    // for this tile (both halo buffers)
 #pragma unroll
     for (int t = 0; t < HPW; ++t) {
-        const int P = t * 512 + tid;
-        const int slot = P >> 3;
-        const int sy = slot / PW, sx = slot - sy * PW;
-        const int row = r0 + sy - 1, x = sx - 1;
-        const bool ok = slot < NSLOT && (unsigned)x < (unsigned)IW && (unsigned)row < (unsigned)IH;
-        if (!ok) {
-            *reinterpret_cast<uint4*>(smem + OFF_RAW + P * 16) = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(smem + OFF_RAW + RAW_BYTES + P * 16) = make_uint4(0u, 0u, 0u, 0u);
+        int sy; unsigned rel;
+        piece_geo(t, sy, rel);
+        if (sy < 0 || ((zero_bits >> t) & 1u)) {
+            *reinterpret_cast<uint4*>(smem + OFF_RAW + (wave + WN * t) * 1024 + voff) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(smem + OFF_RAW + RAW_BYTES + (wave + WN * t) * 1024 + voff) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     f32x4v acc[MF][RN];                                          // first written by the first k-step's MFMAs (C = 0)
@@ -405,12 +465,13 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     WSTAMP(2);
     __syncthreads();
     WSTAMP(3);
-    {   // D(0): the first A chunk, nothing to overlap it with
+    {   // D(0) of the first tile: nothing to overlap it with
         DwState<T> st;
-        int aw0[NSTEP];
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) aw0[s] = opaque(OFF_A + aw[s]);
-        dw_ops<T, RELU, PW, 0, NDW>(st, smem, OFF_RAW + raw_lane, opaque(tap_lane), aw0);
+        AwAddr<NSTEP - OOB0> aw0;
+        aw0.base = opaque(awb) + OFF_A;
+        aw0.dump = opaque(((tap_lane - OFF_TAPS) >> 1) + (OFF_A + MT * A_STR));
+        aw0.last = last_run;
+        dw_ops<T, RELU, PW, 0, NDW>(st, smem, opaque(opaque(raw_lane) + OFF_RAW), opaque(tap_lane), aw0);
     }
     WSTAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // halo chunk 1
@@ -418,40 +479,49 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     WSTAMP(5);
 
     // ---- K loop ------------------------------------------------------------------------------------------------
-    // iteration c: G(c) on A[c & 1], D(c+1) from raw[(c+1) & 1] into A[(c+1) & 1], DMA of halo chunk c+2 into raw[c & 1]
-    // and, in a layer with a residual input, one instruction of its copy into the staging rows above the loop's buffers
-    const int ch0 = wave * CPW;
+    // iteration c: G(c) on A[c & 1]; D(c+1) from raw[(c+1) & 1] into A[(c+1) & 1]; DMA of halo chunk c+2 into raw[c & 1].
+    // Chunk indices run on into the NEXT tile of this workgroup: in iteration NCH-2 the DMA fetches the next tile's chunk 0,
+    // in iteration NCH-1 its chunk 1 while D builds its first A chunk -- when a tile's epilogue starts, the next tile's
+    // whole prologue is already in LDS.
     const unsigned char* resb = reinterpret_cast<const unsigned char*>(p.residual);
-    const bool has_res = p.residual != nullptr;
-    // residual DMA, piece 1: instruction j covers linear pieces [64j, 64j+64) of rows [0, STG_R1); P = row * 13 + col, col 12 pads
-    auto res_dma = [&](int j, int row0, int rows, unsigned lds_base) {
-        const int P = j * 64 + lane;
-        const int row = P / STG_PPR, col = P - row * STG_PPR;
-        const bool ok = row < rows && col < STG_PPR - 1 && ch0 + col * 8 < KP && row0 + row < npix;
-        const unsigned off = ok ? (unsigned)((m0 + row0 + row) * KP + ch0 + col * 8) * 2u : 0u;
-        dma16(resb, off, lds_base + j * 1024, __builtin_amdgcn_ballot_w64(ok));
+    constexpr bool has_res = RES;
+    bool has_next = false;
+    // residual rows [0, RES_ROWS) of the tile being computed -> this wave's private LDS rows, instruction j of NRES:
+    // linear pieces [64 j, 64 j + 64), P = row * 13 + col (col 12 is padding)
+    auto res_dma = [&](int j) {
+        const int P = j * 64 + (int)(voff >> 4);
+        const int row = P / RES_PPR, col = P - row * RES_PPR;
+        const bool ok = row < RES_ROWS && col < RES_PPR - 1 && ch0 + col * 8 < KP && row < t_npix;
+        const unsigned off = ok ? (unsigned)((t_m0 + row) * KP + ch0 + col * 8) * 2u : 0u;
+        dma16(resb, off, lds0 + G::OFF_RES + wave * (RES_ROWS * RES_STR) + j * 1024, __builtin_amdgcn_ballot_w64(ok));
     };
-    auto chunk = [&](auto cur_c, auto ksc_c, auto do_d_c, auto first_c, int c) {
+    auto chunk = [&](auto cur_c, auto ksc_c, auto dmode_c, auto first_c, int c) {
         constexpr int CUR = decltype(cur_c)::value;             // c & 1
         constexpr bool FIRST = decltype(first_c)::value;        // chunk 0: its first k-step starts the accumulators
         constexpr int KSC = decltype(ksc_c)::value;             // k-steps of chunk c (2, or 1 for the last)
-        constexpr bool DO_D = decltype(do_d_c)::value;
+        constexpr int DMODE = decltype(dmode_c)::value;         // 0: no depthwise stage; 1: over 60 MFMA slots; 2: over 30
         constexpr int NXT = CUR ^ 1;
-        if (c + 2 < NCH) {
-            const unsigned long long tl = c + 2 == NCH - 1 ? tail_lanes : ~0ull;
-#pragma unroll
-            for (int t = 0; t < HPW; ++t)
-                dma16(inb + (c + 2) * (KC * 2), halo_off[t], lds0 + OFF_RAW + CUR * RAW_BYTES + (wave + WN * t) * 1024,
-                      halo_mask[t] & tl);
+        const int cd = c + 1 < NCH ? c + 1 : 0;                 // chunk the depthwise stage builds
+        {
+            const int cc = c + 2 < NCH ? c + 2 : c + 2 - NCH;   // chunk the DMA fetches (c >= NCH-2: of the next tile)
+            if (c + 2 < NCH || has_next) {
+                if (c + 2 >= NCH) halo_zero(CUR);
+                halo_dma(cc, CUR);
+            }
         }
-        if (has_res && c < NRES1) res_dma(c, 0, STG_R1, lds0 + OFF_STG1 + wave * STG_W1);
-        const int a_cur = opaque(OFF_A + CUR * A_BYTES + a_lane);
-        const int raw_addr = OFF_RAW + NXT * RAW_BYTES + raw_lane;
-        int awn[NSTEP];
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) awn[s] = opaque(OFF_A + NXT * A_BYTES + aw[s]);
-        // taps of chunk c+1; the last chunk has 32 channels: pairs 16..31 read a clamped (valid, unused) address
-        const int tap_addr = opaque(((c + 1 == NCH - 1 && cp >= 16) ? tap_lane - 128 : tap_lane) + (c + 1) * (KC * 4));
+        if constexpr (has_res) { if (c < NRES) res_dma(c); }
+        // LDS addresses: the per-lane constant goes through opaque() FIRST, so that base + constant is formed here (or
+        // folded into the instruction's immediate) instead of being hoisted out of the tile loop into one register per
+        // buffer and use; the halo image's base lies beyond the 16-bit immediate: one add, opaque again
+        const int a_cur = opaque(a_lane) + (OFF_A + CUR * A_BYTES);
+        const int raw_addr = opaque(opaque(raw_lane) + (OFF_RAW + NXT * RAW_BYTES));
+        AwAddr<NSTEP - OOB0> awn;
+        awn.base = opaque(awb) + (OFF_A + NXT * A_BYTES);
+        awn.dump = opaque(((opaque(tap_lane) - OFF_TAPS) >> 1) + (OFF_A + NXT * A_BYTES + MT * A_STR));   // cp * 4 + row 80
+        awn.last = last_run;
+        // taps of chunk cd; the last chunk has 32 channels: pairs 16..31 read a clamped (valid, unused) address
+        const int tap_l = opaque(tap_lane);
+        const int tap_addr = opaque(((cd == NCH - 1 && tap_l >= OFF_TAPS + 128) ? tap_l - 128 : tap_l) + cd * (KC * 4));   // (pairs cp >= 16)
         DwState<T> st;
         uint4 a[MF];
         const int ks0 = c * (KC / 32);
@@ -463,7 +533,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                 for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR);
             }
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
-            if constexpr (DO_D) dw_ops<T, RELU, PW, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
+            if constexpr (DMODE == 1) dw_ops<T, RELU, PW, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
+            if constexpr (DMODE == 2) dw_ops<T, RELU, PW, dw_before(2 * Q), dw_before(2 * Q + 2)>(st, smem, raw_addr, tap_addr, awn);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
             if constexpr (FIRST && D == 0) mfma16_first<T>(acc[I][J], bq[J], a[I]);
@@ -472,7 +543,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 1))          // 1 = weights stay in registers
             if constexpr (I == MF - 1) {                        // the fragment is dead: fetch it for the next k-step
                 const int nx = ks0 + D + 1;
-                bq[J] = load_b(nx < KST ? nx : KST - 1, J);     // branch-free: past the end re-load a valid, unused step
+                bq[J] = load_b(nx < KST ? nx : 0, J);           // past the end: k-step 0, the next tile's first
             }
 #endif
             if constexpr (J == RN - 1 && D + 1 < KSC)           // last use of this A fragment: fetch the next k-step's
@@ -483,91 +554,120 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RN) : "memory");
         __syncthreads();
     };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using K2 = std::integral_constant<int, 2>; using K1 = std::integral_constant<int, 1>;
-    chunk(I0{}, K2{}, std::true_type{}, std::true_type{}, 0);
-    chunk(I1{}, K2{}, std::true_type{}, std::false_type{}, 1);
-    for (int c = 2; c < NCH - 2; c += 2) {
-        chunk(I0{}, K2{}, std::true_type{}, std::false_type{}, c);
-        chunk(I1{}, K2{}, std::true_type{}, std::false_type{}, c + 1);
-    }
-    chunk(I0{}, K2{}, std::true_type{}, std::false_type{}, NCH - 2);
-    chunk(I1{}, K1{}, std::false_type{}, std::false_type{}, NCH - 1);
-
-    // The last MFMAs have to have written their accumulators before anything reads them (see mfma16), and hipcc must not
-    // move an accumulator read up in front of these wait states: every tile is an operand of one of the two statements
-    // (an asm statement takes 30 operands; a tied one counts twice).
-#define BQ_ACC_ROW(i) "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5])
-    static_assert(MF == 5 && RN == 6, "operand lists below");
-    asm volatile("s_nop 15\n\ts_nop 15" : BQ_ACC_ROW(0), BQ_ACC_ROW(1), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]));
-    asm volatile("" : "+a"(acc[2][3]), "+a"(acc[2][4]), "+a"(acc[2][5]), BQ_ACC_ROW(3), BQ_ACC_ROW(4));
-#undef BQ_ACC_ROW
-    // ---- epilogue: folded BN (+ residual) (+ ReLU), bf16, whole 384-byte row pieces to HBM ----------------------
-    // per wave a private staging tile of 80 rows x 192 channels (the loop's buffers are free: every wave is past the
-    // closing barrier); the residual tile is copied into it by LDS-DMA, every lane adds its accumulator crumbs in
-    // place, then the wave streams the rows out
-    // per wave a private staging tile of 80 rows x 96 channels in two pieces (see STG_R1); the residual tile's first rows
-    // were copied into piece 1 while the loop ran, the rest is copied into piece 2 now (the loop's buffers are free: every
-    // wave is past the closing barrier) and lands while the first two row fragments are finished
-    const int stg1 = OFF_STG1 + wave * STG_W1, stg2 = OFF_STG2 + wave * STG_W2;
-    if (has_res) {
-#pragma unroll
-        for (int j = 0; j < NRES2; ++j) res_dma(j, STG_R1, MT - STG_R1, lds0 + stg2);
-        WSTAMP(19);
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NRES2) : "memory");    // piece 1 (issued under the loop) has landed
-    }
-    WSTAMP(20);
-    const float* sb = reinterpret_cast<const float*>(smem + OFF_SB);
-    const unsigned lo2 = p.relu ? 0u : 0x80008000u;             // packed int16 max with 0 = ReLU, with -32768 = no-op
+    static_assert(NCH % 2 == 0 && (NCH - 1) * KC + 32 == KP, "chunk plan: an even number of chunks, the last of 32 channels");
     unsigned char* outb = reinterpret_cast<unsigned char*>(p.out);
-    float4 sc[RN], bi[RN];
-#pragma unroll
-    for (int j = 0; j < RN; ++j) {                               // 4 consecutive channels per lane and n-fragment
-        sc[j] = *reinterpret_cast<const float4*>(sb + ch0 + j * 16 + kg * 4);
-        bi[j] = *reinterpret_cast<const float4*>(sb + 768 + ch0 + j * 16 + kg * 4);
-    }
-    auto row_addr = [&](int row) { return row < STG_R1 ? stg1 + row * STG_ROW : stg2 + (row - STG_R1) * STG_ROW; };
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        if (i == 2 && has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // piece 2 (rows 43..79)
-        unsigned char* rowp = smem + row_addr(i * 16 + r16) + kg * 8;
-        uint2 u[RN];
-        if (has_res) {                                          // all reads of a row before its writes: one LDS round trip
-#pragma unroll
-            for (int j = 0; j < RN; ++j) u[j] = *reinterpret_cast<const uint2*>(rowp + j * 32);
+    // Output (and residual) layout of a lane.  The host packs the pointwise weights so that the two 16-wide n-fragments
+    // 2q, 2q+1 of a wave INTERLEAVE in groups of four channels (weights.py: pack_fragments16): fragment 2q's row m is
+    // channel 32q + 8 (m / 4) + m % 4, fragment 2q+1's row m is channel 32q + 8 (m / 4) + 4 + m % 4.  A lane (pixel
+    // l & 15, k-group l >> 4) then holds, for every pair, EIGHT consecutive channels 32q + 8 kg + (0..7) of its pixel:
+    // one 16-byte store, and one 16-byte load of the residual, per pair -- no LDS staging, no crumbs.
+
+    for (;;) {
+        has_next = vb + nwg < ntiles;
+        WSTAMP(18);
+        chunk(I0{}, K2{}, I1{}, std::true_type{}, 0);
+        chunk(I1{}, K2{}, I1{}, std::false_type{}, 1);
+        for (int c = 2; c < NCH - 2; c += 2) {
+            chunk(I0{}, K2{}, I1{}, std::false_type{}, c);
+            chunk(I1{}, K2{}, I1{}, std::false_type{}, c + 1);
         }
+        const int m0 = t_m0, npix = t_npix;                      // of the tile whose accumulators are being finished
+        if (has_next) tile_setup(vb + nwg, t_m0, t_npix);        // from here on the halo constants describe the next tile
+        chunk(I0{}, K2{}, I1{}, std::false_type{}, NCH - 2);
+        // (one instance whether or not a tile follows: two copies of the chunk under a branch make hipcc give the
+        // accumulator tiles different registers on the two paths and move them between -- a workgroup's very last tile
+        // builds an A chunk nobody reads)
+        chunk(I1{}, K1{}, I2{}, std::false_type{}, NCH - 1);
+
+        // The last MFMAs have to have written their accumulators before anything reads them (see mfma16), and hipcc must not
+        // move an accumulator read up in front of these wait states: every tile is an operand of one of the two statements
+        // (an asm statement takes 30 operands; a tied one counts twice).
+#define BQ_ACC_ROW(i) "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5])
+        static_assert(MF == 5 && RN == 6, "operand lists below");
+        asm volatile("s_nop 15\n\ts_nop 15" : BQ_ACC_ROW(0), BQ_ACC_ROW(1), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]));
+        asm volatile("" : "+a"(acc[2][3]), "+a"(acc[2][4]), "+a"(acc[2][5]), BQ_ACC_ROW(3), BQ_ACC_ROW(4));
+#undef BQ_ACC_ROW
+        WSTAMP(20);
+        // ---- epilogue: folded BN (+ residual) (+ ReLU), 16-bit, straight from the accumulators to HBM -----------------
+        {
+            const unsigned lo2 = p.relu ? 0u : 0x80008000u;     // packed int16 max with 0 = ReLU, with -32768 = no-op
+            const int er16 = (int)(voff >> 4) & 15, ekg = (int)(voff >> 8);   // lane & 15, lane >> 4 (not kept across the K loop)
+            const unsigned lane_ch = (unsigned)(ch0 + ekg * 8) * 2u;    // byte offset of the lane's first channel within a pixel row
+            // The folded-BN table address goes through opaque(): the table never changes, and hipcc would otherwise hoist
+            // its reads out of the tile loop and keep 48 registers across the K loop.
+            const int sb_lane = opaque(OFF_SB + (ch0 + ekg * 8) * 4);
+            // vmcnt retires in order and a store is only retired when it is acknowledged (~1.8 k cycles here), so a load
+            // issued BEHIND a store cannot be consumed before that: every load of the epilogue is issued before its first
+            // store.  Residual rows 0..31 are already in LDS (copied under the K loop), rows 32..79 (row fragments 2-4)
+            // are fetched now, 9 x 16 bytes per lane, and land while fragments 0 and 1 are finished.
+            uint4 rg[MF - 2][RN / 2];
+            if constexpr (has_res) {
+                const unsigned q2 = ch0 + 2 * 32 < KP ? 128u : 0u;   // wave 7's last pair is channel padding: any valid address
 #pragma unroll
-        for (int j = 0; j < RN; ++j) {
-            float v0 = fmaf(acc[i][j][0], sc[j].x, bi[j].x);
-            float v1 = fmaf(acc[i][j][1], sc[j].y, bi[j].y);
-            float v2 = fmaf(acc[i][j][2], sc[j].z, bi[j].z);
-            float v3 = fmaf(acc[i][j][3], sc[j].w, bi[j].w);
-            if (has_res) {
-                v0 = H16<T>::add_lo(v0, u[j].x); v1 = H16<T>::add_hi(v1, u[j].x);
-                v2 = H16<T>::add_lo(v2, u[j].y); v3 = H16<T>::add_hi(v3, u[j].y);
+                for (int i = 2; i < MF; ++i) {
+                    const int row = i * 16 + er16;
+                    const unsigned off = (unsigned)(m0 + (row < npix ? row : 0)) * (unsigned)(KP * 2) + lane_ch;
+                    rg[i - 2][0] = *reinterpret_cast<const uint4*>(resb + off);
+                    rg[i - 2][1] = *reinterpret_cast<const uint4*>(resb + off + 64);
+                    rg[i - 2][2] = *reinterpret_cast<const uint4*>(resb + off + q2);
+                }
             }
-            uint2 o;
-            o.x = H16<T>::pack2(v0, v1);
-            o.y = H16<T>::pack2(v2, v3);
-            asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
-            asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
-            *reinterpret_cast<uint2*>(rowp + j * 32) = o;
+            const int res_lane = opaque(G::OFF_RES + wave * (RES_ROWS * RES_STR) + er16 * RES_STR + ekg * 16);
+            // pair-major: the folded-BN constants of one pair are 16 registers (the next tile's weight fragments and every
+            // per-lane constant of the loop stay live across this epilogue)
+#pragma unroll
+            for (int q = 0; q < RN / 2; ++q) {
+                if (ch0 + q * 32 >= KP) continue;               // wave 7's last pair lies in the channel padding (wave-uniform)
+                const float4 s0 = *reinterpret_cast<const float4*>(smem + sb_lane + q * 128);
+                const float4 s1 = *reinterpret_cast<const float4*>(smem + sb_lane + q * 128 + 16);
+                const float4 b0 = *reinterpret_cast<const float4*>(smem + sb_lane + 3072 + q * 128);
+                const float4 b1 = *reinterpret_cast<const float4*>(smem + sb_lane + 3072 + q * 128 + 16);
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const int row = i * 16 + er16;
+                    // the accumulators are copied out HERE, tile by tile (volatile: hipcc otherwise copies the 40 registers of a
+                    // pair, or all 120, out up front and spills around them)
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x[e]) : "a"(acc[i][2 * q][e]));
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x[4 + e]) : "a"(acc[i][2 * q + 1][e]));
+                    }
+                    float v0 = fmaf(x[0], s0.x, b0.x), v1 = fmaf(x[1], s0.y, b0.y);
+                    float v2 = fmaf(x[2], s0.z, b0.z), v3 = fmaf(x[3], s0.w, b0.w);
+                    float v4 = fmaf(x[4], s1.x, b1.x), v5 = fmaf(x[5], s1.y, b1.y);
+                    float v6 = fmaf(x[6], s1.z, b1.z), v7 = fmaf(x[7], s1.w, b1.w);
+                    if constexpr (has_res) {
+                        uint4 u;
+                        if (i < 2) u = *reinterpret_cast<const uint4*>(smem + res_lane + i * 16 * RES_STR + q * 64);
+                        else u = rg[i < 2 ? 0 : i - 2][q];
+                        v0 = H16<T>::add_lo(v0, u.x); v1 = H16<T>::add_hi(v1, u.x);
+                        v2 = H16<T>::add_lo(v2, u.y); v3 = H16<T>::add_hi(v3, u.y);
+                        v4 = H16<T>::add_lo(v4, u.z); v5 = H16<T>::add_hi(v5, u.z);
+                        v6 = H16<T>::add_lo(v6, u.w); v7 = H16<T>::add_hi(v7, u.w);
+                    }
+                    uint4 o;
+                    o.x = H16<T>::pack2(v0, v1); o.y = H16<T>::pack2(v2, v3);
+                    o.z = H16<T>::pack2(v4, v5); o.w = H16<T>::pack2(v6, v7);
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.z) : "v"(o.z), "v"(lo2));
+                    asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.w) : "v"(o.w), "v"(lo2));
+                    if (row < npix)
+                        *reinterpret_cast<uint4*>(outb + (size_t)((unsigned)(m0 + row) * (unsigned)(KP * 2) + lane_ch + q * 64)) = o;
+                    __builtin_amdgcn_sched_barrier(0);          // (or hipcc copies all 120 accumulators out up front)
+                }
+            }
         }
+        WSTAMP(22);
+#ifdef BQ_EXPERIMENTS
+        ++stamp_it;
+#endif
+        if (!has_next) break;
+        vb += nwg;
     }
-    WSTAMP(21);
-    // rows out: 80 rows x 12 pieces of 16 B, 15 per lane; a row's 192 bytes are contiguous in HBM
-    {
-        int row = lane / 12, col = lane - (lane / 12) * 12;
-#pragma unroll 5
-        for (int t = 0; t < MT * 12 / 64; ++t) {
-            if (row < npix && ch0 + col * 8 < KP)
-                *reinterpret_cast<uint4*>(outb + ((size_t)(m0 + row) * KP + ch0 + col * 8) * 2) =
-                    *reinterpret_cast<const uint4*>(smem + row_addr(row) + col * 16);
-            col += 4; row += 5;                                   // 64 = 5 * 12 + 4
-            if (col >= 12) { col -= 12; row += 1; }
-        }
-    }
-    WSTAMP(22);
 }
 
 }  // namespace
@@ -575,16 +675,19 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
 using G19 = Geo<19, 4>;     // blocks 5-12 and block13_sepconv1: 5 tiles of 4 (the last: 3) rows per image
 using G37 = Geo<37, 2>;     // block4_sepconv2: 19 tiles of 2 (the last: 1) rows per image
 
-bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo) {
+// The kernel forms byte offsets into the activation tensors in 32 bits: n * H * W * KP * 2 must stay below 2^32
+// (n < 8 085 images at 19x19, n < 2 132 at 37x37 -- a larger batch falls back to the pipelined kernel).
+bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo, long long M) {
     return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == W && (W == G19::IW || W == G37::IW) &&
-           K == KP && Nstore == KP && ldi == KP && ldo == KP;
+           K == KP && Nstore == KP && ldi == KP && ldo == KP && M > 0 && M % (H * W) == 0 && M * KP * 2 < (1ll << 32);
 }
 
-// wp16: the layer's pointwise weights in 16x16x32 fragment order (blob entry "<layer>/wp16")
-int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp16, hipStream_t s) {
+// wp16: the layer's pointwise weights in 16x16x32 fragment order, n-fragment pairs interleaved (blob entry "<layer>/wp16")
+int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp16, int num_cus, hipStream_t s) {
     const bool big = g.W == G37::IW;
     const int hw = g.H * g.W;
-    if ((g.W != G19::IW && !big) || g.H != g.W || g.M % hw != 0 || g.k_off != 0 || !g.scale || !g.bias || !wp16)
+    if ((g.W != G19::IW && !big) || g.H != g.W || g.M % hw != 0 || g.k_off != 0 || !g.scale || !g.bias || !wp16 ||
+        (long long)g.M * KP * 2 >= (1ll << 32))
         return (int)hipErrorInvalidValue;
     WideParams p;
     p.in = reinterpret_cast<const h16_t*>(g.in);
@@ -595,16 +698,23 @@ int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp
     p.n = g.M / hw;
     p.relu = g.relu;
     const bool relu_in = prod == PROD_DW_RELU;
-    void (*const kerns[8])(const WideParams) = {
-        sepconv_wide_kernel<bf16_t, false, G19>, sepconv_wide_kernel<bf16_t, true, G19>,
-        sepconv_wide_kernel<bf16_t, false, G37>, sepconv_wide_kernel<bf16_t, true, G37>,
-        sepconv_wide_kernel<f16_t, false, G19>, sepconv_wide_kernel<f16_t, true, G19>,
-        sepconv_wide_kernel<f16_t, false, G37>, sepconv_wide_kernel<f16_t, true, G37>};
-    const int ki = (dtype == 2 ? 4 : 0) + (big ? 2 : 0) + (relu_in ? 1 : 0);
+#define BQ_WIDE_SET(T, RES) sepconv_wide_kernel<T, false, RES, G19>, sepconv_wide_kernel<T, true, RES, G19>, \
+                            sepconv_wide_kernel<T, false, RES, G37>, sepconv_wide_kernel<T, true, RES, G37>
+    void (*const kerns[16])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
+                                                 BQ_WIDE_SET(bf16_t, true), BQ_WIDE_SET(f16_t, true)};
+#undef BQ_WIDE_SET
+    const int ki = (p.residual ? 8 : 0) + (dtype == 2 ? 4 : 0) + (big ? 2 : 0) + (relu_in ? 1 : 0);
     auto kern = kerns[ki];
     const int tpi = big ? G37::TPI : G19::TPI;
-    static BqLdsAttr attr[8];
-    if (const int e = attr[ki].ensure(reinterpret_cast<const void*>(kern), LDS_TOTAL)) return e;
+    const int lds = big ? G37::LDS_BYTES : G19::LDS_BYTES;
+    static BqLdsAttr attr[16];
+    if (const int e = attr[ki].ensure(reinterpret_cast<const void*>(kern), lds)) return e;
+    // one persistent workgroup per CU (a multiple of 8: every workgroup stays inside its XCD's run of tiles)
+    const int ntiles = p.n * tpi;
+    int nwg = (num_cus > 0 ? num_cus : 256) & ~7;
+    if (nwg < 8) nwg = 8;
+    if (nwg > ntiles) nwg = ntiles;         // fewer tiles than CUs: one tile each (any count: nobody takes a second tile)
+    p.nwg = nwg;
 #ifdef BQ_EXPERIMENTS
     // BQ_STAMPS_WIDE=<file>: in-kernel s_memtime stamps of the first launch with (BQ_STAMPS_NORES: without) a residual
     static const char* stamp_file = bq_exp_env("BQ_STAMPS_WIDE");
@@ -614,16 +724,16 @@ int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp
     p.stamps = nullptr;
     p.stamp_b0 = bq_exp_env("BQ_STAMPS_B0") ? (unsigned)atoi(bq_exp_env("BQ_STAMPS_B0")) : 0u;
     if (stamp_file && state == 0 && (p.residual != nullptr) == want_res && p.n >= 64 &&
-        hipMalloc(&d_stamps, 64 * WN * 32 * 8) == hipSuccess) {
-        (void)hipMemsetAsync(d_stamps, 0, 64 * WN * 32 * 8, s);
+        hipMalloc(&d_stamps, 64 * WN * 32 * STAMP_TILES * 8) == hipSuccess) {
+        (void)hipMemsetAsync(d_stamps, 0, 64 * WN * 32 * STAMP_TILES * 8, s);
         p.stamps = d_stamps;
         state = 1;
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3(p.n * tpi), dim3(64 * WN), LDS_TOTAL, s, p);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WN), lds, s, p);
 #ifdef BQ_EXPERIMENTS
     if (state == 1) {
-        std::vector<unsigned long long> h(64 * WN * 32);
+        std::vector<unsigned long long> h(64 * WN * 32 * STAMP_TILES);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
         if (FILE* f = fopen(stamp_file, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }

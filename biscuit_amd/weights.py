@@ -230,14 +230,24 @@ def pack_fragments(wkn, kpad, vec):
     return np.ascontiguousarray(t).reshape(nfp, kb, 64, vec)
 
 
+def frag16_channel(nf, r):
+    """Output channel that row r of 16-wide n-fragment nf computes in kernels_wide.hip.  The two fragments 2q, 2q+1 of a
+    pair interleave in groups of four channels: the accumulator layout of v_mfma_f32_16x16x32 gives a lane (pixel l & 15,
+    group g = l >> 4) rows 4g .. 4g+3 of a fragment, so with this order it holds, over the pair, the EIGHT consecutive
+    channels 32q + 8g .. 32q + 8g + 7 of its pixel -- one 16-byte store per pair straight from the accumulators."""
+    return 32 * (nf // 2) + 8 * (r // 4) + 4 * (nf % 2) + (r % 4)
+
+
 def pack_fragments16(wkn, kpad, npad):
     """W[K][N] -> v_mfma_f32_16x16x32 fragment order [KS][NF16][64][8] float32 (zero padded): k-step ks, 16-wide
-    n-fragment nf, lane = kg*16 + r holds W[k = ks*32 + kg*8 + v][n = nf*16 + r] in element v.  All fragments of one
-    k-step are contiguous (48 KiB for 768 outputs), so a wave's 12 fragments are one 12 KiB run."""
+    n-fragment nf, lane = kg*16 + r holds W[k = ks*32 + kg*8 + v][n = frag16_channel(nf, r)] in element v.  All fragments of
+    one k-step are contiguous (48 KiB for 768 outputs), so a wave's 6 fragments are one 6 KiB run."""
     k, n = wkn.shape
-    assert kpad % 32 == 0 and kpad >= k and npad % 16 == 0 and npad >= n
+    assert kpad % 32 == 0 and kpad >= k and npad % 32 == 0 and npad >= n
     full = np.zeros((kpad, npad), np.float32)
     full[:k, :n] = wkn
+    nf, r = np.meshgrid(np.arange(npad // 16), np.arange(16), indexing='ij')
+    full = full[:, frag16_channel(nf, r).reshape(-1)]       # column nf*16 + r <- channel frag16_channel(nf, r)
     t = full.reshape(kpad // 32, 4, 8, npad // 16, 16)      # [ks][kg][v][nf][r]
     t = t.transpose(0, 3, 1, 4, 2)                          # [ks][nf][kg][r][v]
     return np.ascontiguousarray(t).reshape(kpad // 32, npad // 16, 64, 8)

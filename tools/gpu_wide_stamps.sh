@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 make -C biscuit_amd/csrc clean >/dev/null 2>&1
 make -C biscuit_amd/csrc -j16 EXPERIMENTS=1 EXPFLAGS=-DWIDE_ABLATE=${1:-0} 2>&1 | grep -E "error" | head -3
-BQ_STAMPS_B0=${2:-1100} BQ_STAMPS_WIDE=gpurun_out/stamps_wide.bin timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 4 --streams 1 2>/dev/null | python -c "
+BQ_STAMPS_B0=${2:-64} BQ_STAMPS_WIDE=gpurun_out/stamps_wide.bin timeout 300 python bench.py --no-extras --no-cpu-baseline --steps 4 --streams 1 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 for k in d['kernels']:

@@ -1,23 +1,29 @@
-"""Decode BQ_STAMPS_WIDE dumps (experiments build): per-phase cycles of kernels_wide.hip, median over blocks and waves."""
+"""Decode BQ_STAMPS_WIDE dumps (experiments build) of the persistent kernels_wide.hip: s_memtime stamps [64 workgroups][8 waves]
+[8 tiles][32 events]; per-phase ticks, median over workgroups and waves, tile by tile.
+events: 0-5 once per workgroup (constants, loads issued, wait, barrier, D(0), wait + barrier); per tile: 18 = tile start,
+6+c = end of chunk c (after its closing barrier), 20 = epilogue start (accumulators readable), 22 = epilogue end."""
 import sys
 import numpy as np
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(64, 8, 32).astype(np.int64)
-ok = a[:, :, 0] > 0
-names = ['const', 'issue', 'wait0', 'bar0', 'D(0)', 'wait1+bar'] + [f'chunk{c}' for c in range(12)] + ['(gap)', 'res-issue', 'res-wait', 'crumbs', 'rows-out']
-ev = list(range(0, 18)) + [19, 20, 21, 22]
-rows = []
-for b in range(64):
-    for w in range(8):
-        if ok[b, w]:
-            t = a[b, w]
-            seq = [t[e] for e in ev if t[e] > 0]
-            rows.append((t, seq))
-print('blocks*waves with stamps:', len(rows))
-t = np.array([r[0] for r in rows])
-def med(x): return int(np.median(x))
-print('total', med(t[:, 22] - t[:, 0]))
-prev = 0
-for e in range(1, 23):
-    if (t[:, e] > 0).all():
-        print(f'  ev{e:2d} +{med(t[:, e] - t[:, prev]):7d}   (since start {med(t[:, e] - t[:, 0])})')
-        prev = e
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(64, 8, 8, 32).astype(np.int64)
+ok = a[:, :, 0, 0] > 0
+print('workgroups x waves with stamps:', int(ok.sum()))
+t = a[ok]                       # [n, tile, ev]
+med = lambda x: int(np.median(x))
+print('prologue (once): issue %d, wait %d, barrier %d, D(0) %d, wait+barrier %d' % tuple(med(t[:, 0, e + 1] - t[:, 0, e]) for e in range(5)))
+for it in range(8):
+    if not (t[:, it, 22] > 0).all():
+        break
+    s = t[:, it]
+    chunks = [med(s[:, 6] - s[:, 18])] + [med(s[:, 6 + c] - s[:, 5 + c]) for c in range(1, 12)]
+    gap = med(s[:, 18] - t[:, it - 1, 22]) if it else med(s[:, 18] - s[:, 5])
+    print(f'tile {it}: total {med(s[:, 22] - s[:, 18])}  gap before {gap}  chunks {chunks}  nops {med(s[:, 20] - s[:, 17])}  epilogue {med(s[:, 22] - s[:, 20])}')
+    # spread over the waves of a workgroup: when does the last wave finish its epilogue after the first?
+w = a[:, :, :, :]
+blocks = [b for b in range(64) if (a[b, :, 0, 0] > 0).all()]
+for it in range(2):
+    sp = [a[b, :, it, 22].max() - a[b, :, it, 22].min() for b in blocks if (a[b, :, it, 22] > 0).all()]
+    if sp:
+        print(f'tile {it}: spread of the epilogue end over the 8 waves of a workgroup: median {int(np.median(sp))}')
+if blocks:
+    b = blocks[0]
+    print('whole workgroup 0: first stamp -> last stamp', int(a[b][a[b] > 0].max() - a[b][a[b] > 0].min()))
