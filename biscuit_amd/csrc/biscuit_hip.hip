@@ -259,7 +259,7 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     }
     static const bool no_wide = bq_exp_env("BQ_NO_WIDE") != nullptr;
     if (!no_wide && nsplit == 1 && L.wp16 && a.H == a.Hi && a.W == a.Wi &&
-        wide_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, a.ldo, a.ldi, a.ldo, p.M)) {
+        wide_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, a.ldo, a.ldi, a.ldo, p.M, a.residual != nullptr)) {
         p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
         const int e = launch_sepconv_wide(dtype, a.prod, p, L.wp16, c->num_cus, s);
@@ -543,7 +543,7 @@ int register_gemm_layer(bq_ctx* c, const std::string& name, int cin, int cout, i
     L.wp = w->second.p;
     auto w16 = c->entries.find(name + "/wp16");
     if (w16 != c->entries.end()) {
-        if (w16->second.n != (size_t)(kpad / 32) * ((size_t)L.nfp * 2) * 1024)
+        if (kpad % 32 || w16->second.n != (size_t)(kpad / 32) * ((size_t)L.nfp * 2) * 1024)
             return fail(c, BQ_ERR_WEIGHTS, "bad size for " + name + "/wp16");
         L.wp16 = w16->second.p;
     }

@@ -98,7 +98,7 @@ int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t
 int gemm_tile_rows(int shape);
 bool pipe_supported(int dtype, int prod, int nfp, int W, int K);
 int launch_sepconv_pipe(int dtype, int prod, const GemmParams& p, hipStream_t s);
-bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo, long long M);
+bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo, long long M, bool residual);
 int launch_sepconv_wide(int dtype, int prod, const GemmParams& p, const void* wp16, int num_cus, hipStream_t s);
 int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
 int launch_gemm_tile(int dtype, const GemmParams& p, hipStream_t s);

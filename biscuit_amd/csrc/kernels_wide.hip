@@ -37,10 +37,18 @@
 namespace {
 using namespace bqk;
 
-constexpr int KP = 736;                 // padded input channels (46 k-blocks of 16)
-constexpr int KST = KP / 32;             // 23 k-steps of 32 (one v_mfma_f32_16x16x32_bf16 deep)
+constexpr int NP = 736;                 // padded OUTPUT channels: every instance produces 728 (row stride 736)
+// Input side of an instance: KIN padded input channels (736: the 728 -> 728 layers; 256: block4_sepconv1), walked in
+// 64-channel chunks -- an even number of them, the last of 32 or 64 channels
+template <int KIN>
+struct KPlan {
+    static constexpr int KP = KIN;
+    static constexpr int KST = KIN / 32;                 // k-steps of 32 (one v_mfma_f32_16x16x32 deep)
+    static constexpr int NCH = (KIN + 63) / 64;          // chunks
+    static constexpr int LASTK = (KIN - (NCH - 1) * 64) / 32;   // k-steps of the last chunk: 1 or 2
+    static_assert(KIN % 32 == 0 && NCH % 2 == 0 && NCH >= 4 && (LASTK == 1 || LASTK == 2), "chunk plan");
+};
 constexpr int KC = 64;                  // channels per chunk
-constexpr int NCH = (KP + KC - 1) / KC; // 12 chunks: 11 whole ones and one of 32 channels
 constexpr int MT = 80;                  // MFMA rows per tile
 constexpr int A_STR = KC * 2 + 32;      // 160 B = 10 slots of 16 B: the 16x16x32 fragment read (lane -> row l&15, 16-byte
                                         // k-group l>>4) is conflict-free for ds_read_b128's lane groups iff slots/row = 2 (mod 4)
@@ -49,13 +57,12 @@ constexpr int NSTEP = 5;                // pixels per depthwise run
 constexpr int WN = 8, RN = 6, MF = 5;   // waves, 16-wide n-fragments per wave, 16-row m-fragments
 constexpr int NFT = WN * RN;            // 48 n-fragments of 16 output channels
 constexpr int CPW = RN * 16;            // 96 output channels per wave
-constexpr int TAPS_BYTES = 9 * KP * 4;
+constexpr int TAPS_BYTES = 9 * 736 * 4;  // LDS reserved for the depthwise taps (the widest instance's)
 constexpr int SB_BYTES = 2 * 768 * 4;
 constexpr int RES_ROWS = 32;             // residual rows that go through LDS (row fragments 0 and 1)
 constexpr int RES_PPR = CPW * 2 / 16 + 1; // 13 pieces of 16 B per row: odd
 constexpr int RES_STR = RES_PPR * 16;
 constexpr int NRES = (RES_ROWS * RES_PPR + 63) / 64;   // LDS-DMA instructions per wave: 7, one per chunk
-static_assert(NRES <= NCH - 2, "the residual prefetch needs one loop iteration of the tile's own per instruction");
 
 // Geometry of one instance: IW x IW maps, TR map rows per tile (TR * IW <= 80 pixels).
 template <int IW_, int TR_>
@@ -213,7 +220,7 @@ struct AwAddr {
     }
 };
 
-template <typename T, bool RELU, int PW, int M, typename AW>
+template <typename T, bool RELU, int PW, int KP, int M, typename AW>
 __device__ __forceinline__ void dw_op(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const AW& aw) {
     if constexpr (M < 3) {
 #pragma unroll
@@ -248,11 +255,11 @@ __device__ __forceinline__ void dw_op(DwState<T>& st, unsigned char* smem, int r
     }
 }
 
-template <typename T, bool RELU, int PW, int LO, int HI, typename AW>
+template <typename T, bool RELU, int PW, int KP, int LO, int HI, typename AW>
 __device__ __forceinline__ void dw_ops(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const AW& aw) {
     if constexpr (LO < HI) {
-        dw_op<T, RELU, PW, LO>(st, smem, raw_addr, tap_addr, aw);
-        dw_ops<T, RELU, PW, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
+        dw_op<T, RELU, PW, KP, LO>(st, smem, raw_addr, tap_addr, aw);
+        dw_ops<T, RELU, PW, KP, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
     }
 }
 
@@ -315,9 +322,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // RES: the layer has a residual input (compile time: the epilogue's loads are then branch-free)
-template <typename T, bool RELU, bool RES, typename G>
+template <typename T, bool RELU, bool RES, typename G, int KIN>
 __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams p) {
     if constexpr (H16<T>::F16) bq_f16_saturate();
+    constexpr int KP = KPlan<KIN>::KP, KST = KPlan<KIN>::KST, NCH = KPlan<KIN>::NCH, LASTK = KPlan<KIN>::LASTK;
+    static_assert(!RES || NRES <= NCH - 2, "the residual prefetch needs one loop iteration of the tile's own per instruction");
     constexpr int IW = G::IW, IH = G::IH, TR = G::TR, TPI = G::TPI, PW = G::PW, NSLOT = G::NSLOT, HPW = G::HPW;
     constexpr int RAW_BYTES = G::RAW_BYTES, OFF_RAW = G::OFF_RAW, OFF_A = G::OFF_A, OFF_TAPS = G::OFF_TAPS, OFF_SB = G::OFF_SB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -416,7 +425,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     // chunk cc of the tile the halo constants describe -> raw[buf]; rows of the padded image that lie outside the map
     // are zeroed (a pad column never holds anything but the zeros written at the start)
     auto halo_dma = [&](int cc, int buf) {
-        const unsigned long long tl = cc == NCH - 1 ? tail_lanes : ~0ull;
+        const unsigned long long tl = (LASTK == 1 && cc == NCH - 1) ? tail_lanes : ~0ull;
 #pragma unroll
         for (int t = 0; t < HPW; ++t)
             dma16(inb + cc * (KC * 2), halo_off[t], lds0 + OFF_RAW + buf * RAW_BYTES + (wave + WN * t) * 1024, halo_mask[t] & tl);
@@ -437,7 +446,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         for (int t = 0; t < 4; ++t) {
             const int j = wave + WN * t;
             const int byte = j * 1024 + lane * 16;
-            dma16(p.dw, (unsigned)byte, lds0 + OFF_TAPS + j * 1024, __builtin_amdgcn_ballot_w64(byte < TAPS_BYTES));
+            dma16(p.dw, (unsigned)byte, lds0 + OFF_TAPS + j * 1024, __builtin_amdgcn_ballot_w64(byte < 9 * KP * 4));
         }
         const int k3 = wave < 3 ? wave : wave - 3;              // waves 0..2: 1 KiB of scale each, waves 3..5: of bias
         dma16(wave < 3 ? p.scale : p.bias, (unsigned)(k3 * 1024 + lane * 16), lds0 + OFF_SB + (wave < 3 ? 0 : 3072) + k3 * 1024,
@@ -471,7 +480,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         aw0.base = opaque(awb) + OFF_A;
         aw0.dump = opaque(((tap_lane - OFF_TAPS) >> 1) + (OFF_A + MT * A_STR));
         aw0.last = last_run;
-        dw_ops<T, RELU, PW, 0, NDW>(st, smem, opaque(opaque(raw_lane) + OFF_RAW), opaque(tap_lane), aw0);
+        dw_ops<T, RELU, PW, KP, 0, NDW>(st, smem, opaque(opaque(raw_lane) + OFF_RAW), opaque(tap_lane), aw0);
     }
     WSTAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // halo chunk 1
@@ -491,8 +500,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     auto res_dma = [&](int j) {
         const int P = j * 64 + (int)(voff >> 4);
         const int row = P / RES_PPR, col = P - row * RES_PPR;
-        const bool ok = row < RES_ROWS && col < RES_PPR - 1 && ch0 + col * 8 < KP && row < t_npix;
-        const unsigned off = ok ? (unsigned)((t_m0 + row) * KP + ch0 + col * 8) * 2u : 0u;
+        const bool ok = row < RES_ROWS && col < RES_PPR - 1 && ch0 + col * 8 < NP && row < t_npix;
+        const unsigned off = ok ? (unsigned)((t_m0 + row) * NP + ch0 + col * 8) * 2u : 0u;
         dma16(resb, off, lds0 + G::OFF_RES + wave * (RES_ROWS * RES_STR) + j * 1024, __builtin_amdgcn_ballot_w64(ok));
     };
     auto chunk = [&](auto cur_c, auto ksc_c, auto dmode_c, auto first_c, int c) {
@@ -521,7 +530,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         awn.last = last_run;
         // taps of chunk cd; the last chunk has 32 channels: pairs 16..31 read a clamped (valid, unused) address
         const int tap_l = opaque(tap_lane);
-        const int tap_addr = opaque(((cd == NCH - 1 && tap_l >= OFF_TAPS + 128) ? tap_l - 128 : tap_l) + cd * (KC * 4));   // (pairs cp >= 16)
+        const int tap_addr = opaque(((LASTK == 1 && cd == NCH - 1 && tap_l >= OFF_TAPS + 128) ? tap_l - 128 : tap_l) + cd * (KC * 4));   // (pairs cp >= 16)
         DwState<T> st;
         uint4 a[MF];
         const int ks0 = c * (KC / 32);
@@ -533,8 +542,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                 for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR);
             }
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
-            if constexpr (DMODE == 1) dw_ops<T, RELU, PW, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
-            if constexpr (DMODE == 2) dw_ops<T, RELU, PW, dw_before(2 * Q), dw_before(2 * Q + 2)>(st, smem, raw_addr, tap_addr, awn);
+            if constexpr (DMODE == 1) dw_ops<T, RELU, PW, KP, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
+            if constexpr (DMODE == 2) dw_ops<T, RELU, PW, KP, dw_before(2 * Q), dw_before(2 * Q + 2)>(st, smem, raw_addr, tap_addr, awn);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
             if constexpr (FIRST && D == 0) mfma16_first<T>(acc[I][J], bq[J], a[I]);
@@ -556,7 +565,6 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     using K2 = std::integral_constant<int, 2>; using K1 = std::integral_constant<int, 1>;
-    static_assert(NCH % 2 == 0 && (NCH - 1) * KC + 32 == KP, "chunk plan: an even number of chunks, the last of 32 channels");
     unsigned char* outb = reinterpret_cast<unsigned char*>(p.out);
     // Output (and residual) layout of a lane.  The host packs the pointwise weights so that the two 16-wide n-fragments
     // 2q, 2q+1 of a wave INTERLEAVE in groups of four channels (weights.py: pack_fragments16): fragment 2q's row m is
@@ -579,7 +587,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         // (one instance whether or not a tile follows: two copies of the chunk under a branch make hipcc give the
         // accumulator tiles different registers on the two paths and move them between -- a workgroup's very last tile
         // builds an A chunk nobody reads)
-        chunk(I1{}, K1{}, I2{}, std::false_type{}, NCH - 1);
+        if constexpr (LASTK == 1) chunk(I1{}, K1{}, I2{}, std::false_type{}, NCH - 1);
+        else chunk(I1{}, K2{}, I1{}, std::false_type{}, NCH - 1);
 
         // The last MFMAs have to have written their accumulators before anything reads them (see mfma16), and hipcc must not
         // move an accumulator read up in front of these wait states: every tile is an operand of one of the two statements
@@ -604,11 +613,11 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             // are fetched now, 9 x 16 bytes per lane, and land while fragments 0 and 1 are finished.
             uint4 rg[MF - 2][RN / 2];
             if constexpr (has_res) {
-                const unsigned q2 = ch0 + 2 * 32 < KP ? 128u : 0u;   // wave 7's last pair is channel padding: any valid address
+                const unsigned q2 = ch0 + 2 * 32 < NP ? 128u : 0u;   // wave 7's last pair is channel padding: any valid address
 #pragma unroll
                 for (int i = 2; i < MF; ++i) {
                     const int row = i * 16 + er16;
-                    const unsigned off = (unsigned)(m0 + (row < npix ? row : 0)) * (unsigned)(KP * 2) + lane_ch;
+                    const unsigned off = (unsigned)(m0 + (row < npix ? row : 0)) * (unsigned)(NP * 2) + lane_ch;
                     rg[i - 2][0] = *reinterpret_cast<const uint4*>(resb + off);
                     rg[i - 2][1] = *reinterpret_cast<const uint4*>(resb + off + 64);
                     rg[i - 2][2] = *reinterpret_cast<const uint4*>(resb + off + q2);
@@ -619,7 +628,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             // per-lane constant of the loop stay live across this epilogue)
 #pragma unroll
             for (int q = 0; q < RN / 2; ++q) {
-                if (ch0 + q * 32 >= KP) continue;               // wave 7's last pair lies in the channel padding (wave-uniform)
+                if (ch0 + q * 32 >= NP) continue;               // wave 7's last pair lies in the channel padding (wave-uniform)
                 const float4 s0 = *reinterpret_cast<const float4*>(smem + sb_lane + q * 128);
                 const float4 s1 = *reinterpret_cast<const float4*>(smem + sb_lane + q * 128 + 16);
                 const float4 b0 = *reinterpret_cast<const float4*>(smem + sb_lane + 3072 + q * 128);
@@ -656,7 +665,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.z) : "v"(o.z), "v"(lo2));
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.w) : "v"(o.w), "v"(lo2));
                     if (row < npix)
-                        *reinterpret_cast<uint4*>(outb + (size_t)((unsigned)(m0 + row) * (unsigned)(KP * 2) + lane_ch + q * 64)) = o;
+                        *reinterpret_cast<uint4*>(outb + (size_t)((unsigned)(m0 + row) * (unsigned)(NP * 2) + lane_ch + q * 64)) = o;
                     __builtin_amdgcn_sched_barrier(0);          // (or hipcc copies all 120 accumulators out up front)
                 }
             }
@@ -675,19 +684,21 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
 using G19 = Geo<19, 4>;     // blocks 5-12 and block13_sepconv1: 5 tiles of 4 (the last: 3) rows per image
 using G37 = Geo<37, 2>;     // block4_sepconv2: 19 tiles of 2 (the last: 1) rows per image
 
-// The kernel forms byte offsets into the activation tensors in 32 bits: n * H * W * KP * 2 must stay below 2^32
+// The kernel forms byte offsets into the activation tensors in 32 bits: n * H * W * 736 * 2 must stay below 2^32
 // (n < 8 085 images at 19x19, n < 2 132 at 37x37 -- a larger batch falls back to the pipelined kernel).
-bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo, long long M) {
-    return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == W && (W == G19::IW || W == G37::IW) &&
-           K == KP && Nstore == KP && ldi == KP && ldo == KP && M > 0 && M % (H * W) == 0 && M * KP * 2 < (1ll << 32);
+// Instances: K = 736 (728 -> 728) on 19x19 and 37x37 maps, K = 256 (block4_sepconv1: 256 -> 728) on 37x37 maps.
+bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo, long long M, bool residual) {
+    const bool shape = (K == 736 && (W == G19::IW || W == G37::IW)) || (K == 256 && W == G37::IW && !residual);
+    return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == W && shape &&
+           Nstore == NP && ldi == K && ldo == NP && M > 0 && M % (H * W) == 0 && M * NP * 2 < (1ll << 32);
 }
 
 // wp16: the layer's pointwise weights in 16x16x32 fragment order, n-fragment pairs interleaved (blob entry "<layer>/wp16")
 int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp16, int num_cus, hipStream_t s) {
     const bool big = g.W == G37::IW;
     const int hw = g.H * g.W;
-    if ((g.W != G19::IW && !big) || g.H != g.W || g.M % hw != 0 || g.k_off != 0 || !g.scale || !g.bias || !wp16 ||
-        (long long)g.M * KP * 2 >= (1ll << 32))
+    if (!wide_supported(dtype, prod, g.NFp, g.H, g.W, g.K, g.Nstore, g.ldi, g.ldo, g.M, g.residual != nullptr) || g.k_off != 0 ||
+        !g.scale || !g.bias || !wp16)
         return (int)hipErrorInvalidValue;
     WideParams p;
     p.in = reinterpret_cast<const h16_t*>(g.in);
@@ -698,16 +709,21 @@ int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp
     p.n = g.M / hw;
     p.relu = g.relu;
     const bool relu_in = prod == PROD_DW_RELU;
-#define BQ_WIDE_SET(T, RES) sepconv_wide_kernel<T, false, RES, G19>, sepconv_wide_kernel<T, true, RES, G19>, \
-                            sepconv_wide_kernel<T, false, RES, G37>, sepconv_wide_kernel<T, true, RES, G37>
-    void (*const kerns[16])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
-                                                 BQ_WIDE_SET(bf16_t, true), BQ_WIDE_SET(f16_t, true)};
+#define BQ_WIDE_SET(T, RES) sepconv_wide_kernel<T, false, RES, G19, 736>, sepconv_wide_kernel<T, true, RES, G19, 736>, \
+                            sepconv_wide_kernel<T, false, RES, G37, 736>, sepconv_wide_kernel<T, true, RES, G37, 736>
+    void (*const kerns[20])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
+                                                 BQ_WIDE_SET(bf16_t, true), BQ_WIDE_SET(f16_t, true),
+                                                 sepconv_wide_kernel<bf16_t, false, false, G37, 256>,
+                                                 sepconv_wide_kernel<bf16_t, true, false, G37, 256>,
+                                                 sepconv_wide_kernel<f16_t, false, false, G37, 256>,
+                                                 sepconv_wide_kernel<f16_t, true, false, G37, 256>};
 #undef BQ_WIDE_SET
-    const int ki = (p.residual ? 8 : 0) + (dtype == 2 ? 4 : 0) + (big ? 2 : 0) + (relu_in ? 1 : 0);
+    const int ki = g.K == 256 ? 16 + (dtype == 2 ? 2 : 0) + (relu_in ? 1 : 0)
+                              : (p.residual ? 8 : 0) + (dtype == 2 ? 4 : 0) + (big ? 2 : 0) + (relu_in ? 1 : 0);
     auto kern = kerns[ki];
     const int tpi = big ? G37::TPI : G19::TPI;
     const int lds = big ? G37::LDS_BYTES : G19::LDS_BYTES;
-    static BqLdsAttr attr[16];
+    static BqLdsAttr attr[20];
     if (const int e = attr[ki].ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     // one persistent workgroup per CU (a multiple of 8: every workgroup stays inside its XCD's run of tiles)
     const int ntiles = p.n * tpi;

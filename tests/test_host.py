@@ -100,6 +100,23 @@ def test_f16_blob_has_the_layout_of_the_bf16_one():
             assert np.abs(fb - ref).max() <= np.abs(ref).max() * 2.0 ** -11      # 8x finer than bf16
 
 
+def test_fragment_pairs_interleave():
+    """kernels_wide.hip's 16x16x32 fragment order: over a pair of fragments a lane (group g of four accumulator rows) owns
+    the eight consecutive channels 32q + 8g .. + 7; the map is a bijection on the padded channels."""
+    ch = np.array([[W.frag16_channel(nf, r) for r in range(16)] for nf in range(48)])
+    assert sorted(ch.ravel()) == list(range(768))
+    for q in range(24):
+        for g in range(4):
+            lane = list(ch[2 * q, 4 * g:4 * g + 4]) + list(ch[2 * q + 1, 4 * g:4 * g + 4])
+            assert lane == list(range(32 * q + 8 * g, 32 * q + 8 * g + 8))
+    w = np.random.default_rng(0).normal(size=(40, 70)).astype(np.float32)
+    p = W.pack_fragments16(w, 64, 96)
+    assert p.shape == (2, 6, 64, 8)
+    for ks, nf, lane, v in ((0, 0, 0, 0), (1, 3, 37, 5), (0, 5, 63, 7), (1, 4, 20, 2)):
+        k, n = ks * 32 + (lane >> 4) * 8 + v, W.frag16_channel(nf, lane & 15)
+        assert p[ks, nf, lane, v] == (w[k, n] if (k < 40 and n < 70) else 0.0)
+
+
 def test_blob_directory_roundtrip():
     w = W.synthetic_weights(3)
     blob = W.pack_blob(w, 'bf16')
@@ -110,12 +127,13 @@ def test_blob_directory_roundtrip():
         nm, off, ln = struct.unpack_from('<48sQQ', blob, 16 + 64 * i)
         names[nm.rstrip(b'\0').decode()] = (off, ln)
         assert off % 256 == 0 and off + ln <= len(blob)
-    # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 26 wide layers and the 32x32x16
-    # copy of the two fused shortcuts (bf16 blobs only)
-    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 26 + 2
+    # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 27 wide layers and the 32x32x16
+    # copy of the two fused shortcuts (16-bit blobs only)
+    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 27 + 2
     assert names['block3_res/wp32'][1] == 8 * 8 * 64 * 8 * 2 and names['block2_res/wp32'][1] == 4 * 4 * 64 * 8 * 2
     assert 'block4_res/wp32' not in names and 'block13_res/wp32' not in names
-    assert names['block5_sepconv1/wp16'][1] == 23 * 48 * 64 * 8 * 2 and 'block4_sepconv2/wp16' in names and 'block4_sepconv1/wp16' not in names
+    assert names['block5_sepconv1/wp16'][1] == 23 * 48 * 64 * 8 * 2 and 'block4_sepconv2/wp16' in names and 'block3_sepconv2/wp16' not in names
+    assert names['block4_sepconv1/wp16'][1] == 8 * 48 * 64 * 8 * 2
     off, ln = names['block5_sepconv2/scale']
     s, b = W.fold_bn(w, 'block5_sepconv2_bn')
     got = np.frombuffer(blob, np.float32, ln // 4, off)
