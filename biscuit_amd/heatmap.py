@@ -72,8 +72,9 @@ class Heatmap:
     def from_region(cls, engine, region, tile_px=299, stride_div=1, **kw):
         """Heatmap of a slide region in memory: the stride-``tile_px // stride_div`` grid of ``tile_grid``."""
         tiles, grid = tile_grid(region, tile_px, stride_div)
-        stride = tile_px // stride_div
-        shape = ((region.shape[0] - tile_px) // stride + 1, (region.shape[1] - tile_px) // stride + 1)
+        if len(grid) == 0:
+            raise ValueError(f'region {tuple(region.shape[:2])} holds no {tile_px} x {tile_px} tile')
+        shape = (int(grid[:, 1].max()) + 1, int(grid[:, 0].max()) + 1)      # (gy, gx) of tile_grid's clamped grid
         return cls(engine, tiles, grid, grid_shape=shape, **kw)
 
     def mask_uncertain(self, tile_uq_thresh):

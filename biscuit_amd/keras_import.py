@@ -176,13 +176,30 @@ def _bind_by_name(layers, keys, kinds, names, reader):
     return out
 
 
-def from_bundle(prefix, verify=True):
-    """Canonical weight dict from a checkpoint prefix / ``variables`` directory / SavedModel directory."""
+_WEIGHT_LEAVES = ('kernel', 'depthwise_kernel', 'pointwise_kernel', 'bias') + tuple(_BN_VARS)
+
+
+def from_bundle(prefix, verify=True, strict=False):
+    """Canonical weight dict from a checkpoint prefix / ``variables`` directory / SavedModel directory.
+
+    Variables outside the ``layer_with_weights-N`` tree: a real Keras / Slideflow SavedModel can carry extra trackables
+    (metrics, step counters, custom attributes), so those are skipped with a warning -- unless one LOOKS like model weights
+    (a floating-point ``kernel`` / ``gamma`` / ``moving_*`` ... leaf), which would mean layers this importer did not see:
+    that, or any skipped variable with ``strict=True``, is an error."""
     reader = tf_bundle.BundleReader(prefix, verify=verify)
     layers, keys, skipped = _collect_layers(reader)
     if skipped:
-        raise ImportError_(f'{len(skipped)} variables outside the layer_with_weights-N tree (first: {skipped[0]}): '
-                           'not the hp.nature2022 classifier, or a layout this importer does not know')
+        def weight_like(key):
+            leaf = key[:-len(_SUFFIX)].split('/')[-1]
+            floating = reader.entries[key]['dtype'] in (1, 2, 14, 19)     # DT_FLOAT, DT_DOUBLE, DT_BFLOAT16, DT_HALF
+            return leaf in _WEIGHT_LEAVES and floating
+        suspicious = [k for k in skipped if weight_like(k)]
+        if suspicious or strict:
+            bad = suspicious or skipped
+            raise ImportError_(f'{len(bad)} variables outside the layer_with_weights-N tree (first: {bad[0]}): '
+                               'not the hp.nature2022 classifier, or a layout this importer does not know')
+        import warnings
+        warnings.warn(f'keras_import: ignoring {len(skipped)} variables outside the layer tree (first: {skipped[0]})')
     kinds = []
     for n, lv in enumerate(layers):
         k = _kind(lv, reader)

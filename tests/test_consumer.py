@@ -123,3 +123,20 @@ def test_error_behaviour(consumer_cv):
         th.process_group_predictions(frame(cv['folds'][0]).drop(columns=['uncertainty']), 0.5, 'slide')
     with pytest.raises(ValueError):
         th.from_cv([frame(cv['folds'][0]).drop(columns=['patient'])])
+
+
+def test_rename_cols_against_reference_goldens():
+    """The column contract: ``biscuit_amd.predictions.rename_cols`` leaves exactly the columns the
+    reference's own ``utils.rename_cols`` (utils.py:31-53) left on the same frames -- dash and underscore spellings in
+    every combination, the ``-y_true`` fallback, absent columns, explicit overrides, a non-string outcome
+    (fixture: oracle/make_rename_golden.py)."""
+    import json
+    import os
+    import pandas as pd
+    from biscuit_amd.predictions import rename_cols
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rename_cols.json')))
+    assert len(g['cases']) >= 90
+    for c in g['cases']:
+        df = pd.DataFrame({k: [0] for k in c['columns']})
+        rename_cols(df, c['outcome'], **c['kwargs'])
+        assert list(df.columns) == c['result'], c

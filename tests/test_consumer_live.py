@@ -66,3 +66,24 @@ def test_random_frames_match_reference(ref, seed):
                 np.testing.assert_allclose(g_df[c].to_numpy(), w_df[c].to_numpy(), atol=1e-12)
             for c in ('y_true', 'correct', 'incorrect', 'y_pred_bin'):
                 assert [int(x) for x in g_df[c]] == [int(x) for x in w_df[c]]
+
+
+def test_rename_cols_matches_reference_live():
+    """Random column sets through both ``rename_cols`` (reference: utils.py:31-53)."""
+    import pandas as pd
+    from oracle.make_consumer_golden import import_reference
+    from biscuit_amd.predictions import rename_cols
+    ref_utils = import_reference(REF)['utils']
+    rng = np.random.default_rng(7)
+    names = ['y_true0', 'y_true', 'y_pred0', 'y_pred1', 'uncertainty0', 'uncertainty1']
+    for _ in range(300):
+        outcome = str(rng.choice(['cohort', 'x-y', 'a_b', '7']))
+        cols = ['slide'] + [f'{outcome}{sep}{n}' for n in names for sep in '-_' if rng.random() < 0.45]
+        cols += [c for c in ('y_true', 'y_pred', 'label') if rng.random() < 0.15]
+        kw = {}
+        if rng.random() < 0.2:
+            kw['y_pred'] = str(rng.choice(cols))
+        a = pd.DataFrame({c: [0] for c in cols}); b = a.copy()
+        ref_utils.rename_cols(a, outcome, **kw)
+        rename_cols(b, outcome, **kw)
+        assert list(a.columns) == list(b.columns), (cols, outcome, kw)

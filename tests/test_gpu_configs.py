@@ -100,6 +100,62 @@ def test_bench_starts_its_own_ranks():
     assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr
 
 
+def test_config3_one_ranks_share_at_real_size():
+    """BASELINE.json config 3 at its real size, the part one GPU runs: rank 0's share of 1 600 slides x 1 000 tiles over 8
+    ranks = 200 slides x 1 000 tiles (200 000 tiles, batches of 256 that span slides), through ``inference.evaluate``
+    exactly as ``bench.py --workload cfg3`` drives it.  No oracle at this size: counts, the partition, bit-exact
+    re-run, independence of the batches in flight, and per-slide means equal to direct ``mc_infer`` calls with the
+    slide's global tile indices."""
+    from biscuit_amd import distributed as D
+    from biscuit_amd.engine import EnginePool
+    from biscuit_amd.inference import Slide, evaluate
+    S, T, world, B, mc_n = 1600, 1000, 8, 256, 30
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(3)
+    pool_t = torch.randint(0, 256, (1024, 299, 299, 3), dtype=torch.uint8, device=dev, generator=g)   # resident tiles, cycled
+
+    def tiles_of(i):
+        def load():
+            return pool_t.index_select(0, (torch.arange(T, device=dev) * 7 + i * 131) % pool_t.shape[0])
+        return load
+    slides = [Slide(f's{i:04d}', tiles_of(i), T, y_true=i % 2) for i in range(S)]
+    parts = D.partition_slides([T] * S, world)
+    assert [len(p) for p in parts] == [200] * world and sorted(sum(parts, [])) == list(range(S))
+    mine = parts[0]
+    pool = EnginePool(synthetic_weights(1), n_streams=2, dtype='f16', max_batch=B, max_mc=mc_n)
+    runs = []
+    for in_flight in (1, 2):
+        pool.set_in_flight(in_flight)
+        runs.append(evaluate(pool, slides, mc_n=mc_n, seed=1234, batch=B, keep_tiles=True, rank=0, world=world))
+        pool.synchronize()
+    a, b = runs
+    # the gather did not run (this process is one rank of eight): slides of other ranks are unreported
+    assert sorted(a.local_slides) == mine
+    cnt = np.asarray(a.slide_count)
+    assert cnt[mine].tolist() == [T] * 200 and int(cnt.sum()) == 200 * T
+    assert len(a.tile_df) == 200 * T and a.tile_df['slide'].nunique() == 200
+    # bit-exact whatever the number of batches in flight
+    assert np.array_equal(a.slide_pred[mine], b.slide_pred[mine]) and np.array_equal(a.slide_unc[mine], b.slide_unc[mine])
+    assert a.tile_df.equals(b.tile_df)
+    assert np.isfinite(a.slide_pred[mine]).all() and (a.slide_unc[mine] > 0).all()
+    yp = a.tile_df['cohort-y_pred1'].to_numpy(); un = a.tile_df['cohort-uncertainty1'].to_numpy()
+    assert np.allclose(a.tile_df['cohort-y_pred0'].to_numpy() + yp, 1.0, atol=1e-6) and (un > 0).all() and (un < 0.5).all()
+    # slide means = plain float64 means of the slide's tile rows (the consumer's groupby, threshold.py:191-192) ...
+    names = a.tile_df['slide'].to_numpy()
+    for si in (mine[0], mine[57], mine[-1]):
+        rows = names == f's{si:04d}'
+        assert rows.sum() == T
+        assert abs(a.slide_pred[si] - yp[rows].mean()) < 1e-9 and abs(a.slide_unc[si] - un[rows].mean()) < 1e-9
+    # ... and a slide's tile rows = direct calls on that slide alone with its GLOBAL tile indices (slide si starts at
+    # tile si * T of the dataset: batches that span slides and the sharding change nothing)
+    eng = pool.engines[0]
+    si = mine[57]
+    t = tiles_of(si)()
+    m = torch.cat([eng.mc_infer(t[o:o + B].contiguous(), mc_n, 1234, tile_idx0=si * T + o)[0] for o in range(0, T, B)])
+    assert np.array_equal(m[:, 1].double().cpu().numpy(), yp[names == f's{si:04d}'])
+    pool.close()
+
+
 # ------------------------------------------------------------------------------------------------ config 4
 @pytest.fixture(scope='module')
 def sweep_engines():

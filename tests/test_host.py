@@ -264,3 +264,15 @@ def test_heatmap_tile_grid_and_mask_golden():
     assert mask.tolist() == [[False, True, False], [True, False, True]]        # 0.020 is NOT masked (strict), the empty cell neither
     want = np.array([[[0.9, 0.1], [MASKED, MASKED], [0.6, 0.4]], [[MASKED, MASKED], [-1, -1], [MASKED, MASKED]]], np.float32)
     assert np.array_equal(hm.logits, want)
+
+
+def test_heatmap_region_smaller_than_a_tile():
+    """A region that holds no tile: tile_grid returns an empty grid, Heatmap.from_region says so (before it needs a GPU)."""
+    from biscuit_amd.heatmap import Heatmap, tile_grid
+    small = np.zeros((120, 400, 3), np.uint8)
+    tiles, grid = tile_grid(small)
+    assert tuple(tiles.shape) == (0, 299, 299, 3) and grid.shape == (0, 2)
+    with pytest.raises(ValueError, match='holds no 299 x 299 tile'):
+        Heatmap.from_region(None, small)
+    tiles, grid = tile_grid(np.zeros((299, 598, 3), np.uint8), stride_div=13)      # one row of cells at stride 23
+    assert grid[:, 1].max() == 0 and grid[:, 0].max() == (598 - 299) // 23

@@ -380,8 +380,20 @@ def test_layers_bound_by_name_when_the_savedmodel_names_them(tmp_path, synth):
         K.from_bundle(str(e))
 
 
-def test_variables_outside_the_layer_tree_are_an_error(tmp_path, synth):
+def test_variables_outside_the_layer_tree(tmp_path, synth):
+    """Something that looks like model weights outside the layer tree is an error; other trackables a real SavedModel
+    carries (counters, metric state) are skipped with a warning -- unless strict=True."""
     def edit(t):
         t['some_other_object/kernel/.ATTRIBUTES/VARIABLE_VALUE'] = np.zeros((3, 3), np.float32)
     with pytest.raises(K.ImportError_, match='outside the layer_with_weights'):
         K.from_bundle(_rewrite(tmp_path, synth, edit))
+
+    def extra(t):
+        t['metrics/0/total/.ATTRIBUTES/VARIABLE_VALUE'] = np.zeros((), np.float32)
+        t['layer-3/step_counter/.ATTRIBUTES/VARIABLE_VALUE'] = np.zeros((), np.int64)
+    path = _rewrite(tmp_path, synth, extra)
+    with pytest.warns(UserWarning, match='ignoring 2 variables'):
+        w = K.from_bundle(path)
+    assert W.pack_blob(w, 'f16') == W.pack_blob(synth, 'f16')
+    with pytest.raises(K.ImportError_, match='outside the layer_with_weights'):
+        K.from_bundle(path, strict=True)
