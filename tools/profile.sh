@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-profile --no-extras"
+BENCH="python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-profile --no-extras --dtype ${2:-f16}"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?" >> $OUT/trace.log
 # the same command on ONE stream: with two streams the kernels of the two batches in flight overlap and a

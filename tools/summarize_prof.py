@@ -73,11 +73,12 @@ def main():
                   '| kernel | workgroups | launches | avg us | total ms |', '|---|---:|---:|---:|---:|']
         for (kn, wg), (n, dur) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:16]:
             lines.append(f'| `{kn}` | {wg} | {n} | {dur/n/1e3:.1f} | {dur/1e6:.2f} |')
-        dom = [(n, dur) for (kn, wg), (n, dur) in acc.items() if 'sepconv_wide_kernel' in kn and wg == 1280]
+        # the 728 -> 728 @19x19 layer class = the Geo<19,4> instances with K = 736 (persistent: one workgroup per CU)
+        dom = [(n, dur) for (kn, wg), (n, dur) in acc.items() if 'sepconv_wide_kernel' in kn and 'GeoI19' in kn and kn.rstrip('>').endswith('736')]
         if dom:
             n = sum(x[0] for x in dom); dur = sum(x[1] for x in dom)
-            lines += ['', f'Dominant layer class (sepconv 728->728 @19x19, kernels_wide.hip, 1280 workgroups): {n} launches, '
-                          f'average {dur/n/1e3:.1f} us.']
+            lines += ['', f'Dominant layer class (sepconv 728->728 @19x19, kernels_wide.hip, all its instances: with / without a '
+                          f'residual input, with / without a ReLU in front): {n} launches, average {dur/n/1e3:.1f} us.']
         lines.append('')
     pmc = {}
     for key in ('pmc_fetch', 'pmc_write'):
@@ -109,7 +110,7 @@ def main():
             lines.append(f'| `{kn}` | {f[1] or w[1]} | {f[0]:.0f} | {w[0]:.0f} | {mb:.1f} | {(f[2] or w[2])/1e3:.1f} |')
         lines.append('')
         # the dominant kernel of bench.py (728 -> 728 separable conv at 19x19, n = 256 -> 963 workgroups)
-        dom = [(kn, d) for kn, d in names.items() if 'sepconv_wide_kernel' in kn and '[1280 wg]' in kn]
+        dom = [(kn, d) for kn, d in names.items() if 'sepconv_wide_kernel' in kn and 'GeoI19' in kn and kn.split(' [')[0].rstrip('>').endswith('736')]
         if dom:
             import json
             nl = sum((d.get('FETCH_SIZE') or d.get('WRITE_SIZE'))[1] for _, d in dom)
@@ -130,7 +131,7 @@ def main():
                 'fetch_size_kib': fetch, 'write_size_kib': write, 'corrected_bytes_per_launch': (2 * fetch + write) * 1024,
                 'source': os.path.basename(out), 'launches': nl}
             json.dump(js, open(tpath, 'w'), indent=1)
-            lines += [f'Dominant kernel (1280 workgroups): FETCH_SIZE {fetch:.0f} KiB, WRITE_SIZE {write:.0f} KiB per launch '
+            lines += [f'Dominant kernel (728 -> 728 @19x19, all instances): FETCH_SIZE {fetch:.0f} KiB, WRITE_SIZE {write:.0f} KiB per launch '
                       f'-> corrected {(2 * fetch + write) * 1024 / 1e6:.1f} MB (algorithmic 270 MB incl. residual reads).', '']
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines[:40]))

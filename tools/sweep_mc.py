@@ -1,5 +1,5 @@
 """BASELINE.json config 4: MC-dropout sweep N in {1,5,10,30,50}: fused on-device Welford (backbone once,
-N head passes in one launch sequence) vs N separate full passes, 1 GPU, batch 256, bf16.
+N head passes in one launch sequence) vs N separate full passes, 1 GPU, batch 256, f16 (the headline storage type).
 Prints one JSON line per (N, mode).  usage: python tools/sweep_mc.py [--batch 256]"""
 import argparse, json, os, sys, time
 import torch
@@ -11,7 +11,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--steps', type=int, default=8)
 args = ap.parse_args()
-eng = Engine(synthetic_weights(1), dtype='bf16', max_batch=args.batch, max_mc=50)
+ap_dtype = 'f16'
+eng = Engine(synthetic_weights(1), dtype=ap_dtype, max_batch=args.batch, max_mc=50)
 tiles = torch.randint(0, 256, (args.batch, 299, 299, 3), dtype=torch.uint8, device='cuda')
 for mc in (1, 5, 10, 30, 50):
     ref = None
