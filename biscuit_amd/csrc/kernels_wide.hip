@@ -627,14 +627,17 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             // pair-major: the folded-BN constants of one pair are 16 registers (the next tile's weight fragments and every
             // per-lane constant of the loop stay live across this epilogue)
 #pragma unroll
-            for (int q = 0; q < RN / 2; ++q) {
-                if (ch0 + q * 32 >= NP) continue;               // wave 7's last pair lies in the channel padding (wave-uniform)
-                const float4 s0 = *reinterpret_cast<const float4*>(smem + sb_lane + q * 128);
-                const float4 s1 = *reinterpret_cast<const float4*>(smem + sb_lane + q * 128 + 16);
-                const float4 b0 = *reinterpret_cast<const float4*>(smem + sb_lane + 3072 + q * 128);
-                const float4 b1 = *reinterpret_cast<const float4*>(smem + sb_lane + 3072 + q * 128 + 16);
+            for (int i = 0; i < MF; ++i) {
 #pragma unroll
-                for (int i = 0; i < MF; ++i) {
+                for (int q = 0; q < RN / 2; ++q) {
+                    if (ch0 + q * 32 >= NP) continue;           // wave 7's last pair lies in the channel padding (wave-uniform)
+                    // row-major: the three 64-byte pieces of a pixel row go out back to back, so the halves of a 128-byte
+                    // line reach L2 together; the folded-BN constants are re-read from LDS for every piece (16 registers)
+                    const int sbq = opaque(sb_lane + q * 128);
+                    const float4 s0 = *reinterpret_cast<const float4*>(smem + sbq);
+                    const float4 s1 = *reinterpret_cast<const float4*>(smem + sbq + 16);
+                    const float4 b0 = *reinterpret_cast<const float4*>(smem + sbq + 3072);
+                    const float4 b1 = *reinterpret_cast<const float4*>(smem + sbq + 3072 + 16);
                     const int row = i * 16 + er16;
                     // the accumulators are copied out HERE, tile by tile (volatile: hipcc otherwise copies the 40 registers of a
                     // pair, or all 120, out up front and spills around them)
