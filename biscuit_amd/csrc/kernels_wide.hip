@@ -1,9 +1,10 @@
-// SeparableConv2D 728 -> 728 on 19x19 maps (25 of the 34 separable convolutions, ~75 % of the network's FLOPs), bf16.
+// SeparableConv2D with 728 output channels: the 25 layers 728 -> 728 on 19x19 maps (~75 % of the network's FLOPs),
+// block4_sepconv2 (728 -> 728, 37x37) and block4_sepconv1 (256 -> 728, 37x37); 16-bit storage (bf16 or f16).
 //
-// One workgroup = 8 waves (two per SIMD, 256 registers each): it owns an image-aligned tile of 4 map rows (76 pixels,
-// padded to 80 MFMA rows; the 5th tile of an image has 3 rows: 1 280 tiles per batch of 256 = five whole rounds of the
-// 256 CUs) and ALL 768 (padded) output channels; wave w keeps the 80 x 96 fp32 accumulator block of channels
-// [96w, 96w+96) in the accumulator file for the whole kernel: 5 x 6 tiles of v_mfma_f32_16x16x32_bf16 = 120 registers.
+// One PERSISTENT workgroup per CU (round 3) = 8 waves (two per SIMD, 256 registers each).  It walks image-aligned tiles
+// of 4 map rows (76 pixels, padded to 80 MFMA rows; the 5th tile of an image has 3 rows: 1 280 tiles per batch of 256,
+// five per workgroup) and computes ALL 768 (padded) output channels of a tile; wave w keeps the 80 x 96 fp32 accumulator
+// block of channels [96w, 96w+96) in the accumulator file: 5 x 6 tiles of v_mfma_f32_16x16x32 = 120 registers.
 // The contraction is walked in 64-channel chunks, one workgroup barrier per chunk, and inside a chunk EVERY wave runs
 // one instruction stream that carries all three stages, interleaved instruction by instruction (a wave issues in
 // order: five MFMAs in a row hold it for 80 cycles with the vector ALU idle, 25 vector instructions in a row leave the
@@ -11,17 +12,23 @@
 //     G(c)    60 MFMAs: A fragments from the LDS chunk buffer, B fragments (weights, host-packed in 16x16x32
 //             fragment order) reloaded for the next k-step as soon as its 5 MFMAs are issued
 //     D(c+1)  the depthwise 3x3 of the NEXT chunk on the vector ALU: lane = (channel pair, run of 5 pixels of a tile
-//             row), a 3x3 sliding window in registers, per pixel 3 ds_read_b32 + 6 unpack + 18 v_fma_f32 +
-//             1 v_cvt_pk_bf16_f32 + 1 ds_write_b32 -- no per-tap masks (the halo image in LDS has zero columns left
-//             and right of every row and zero rows outside the map), no packed-f32 arithmetic
+//             row), a 3x3 sliding window in registers, per pixel 3 ds_read_b32, 18 multiply-adds (bf16: + 6 unpack;
+//             f16: v_fma_mix_f32 straight from the packed dword), 1 packed convert, 1 ds_write_b32 -- no per-tap masks
+//             (the halo image in LDS has zero columns left and right of every row and zero rows outside the map), no
+//             packed-f32 arithmetic (v_pk_fma_f32 halves the instruction count and measured 10 % SLOWER)
 //     L(c+2)  the halo image of chunk c+2 by LDS-DMA (global_load_lds_dwordx4: no registers)
-// Measured (stamps, ablation builds): a SIMD issues about one instruction of ANY kind per 4 cycles from its
-// two waves and an MFMA holds the port for 8 of its 16, so a chunk costs ~4 cycles per non-MFMA instruction on top of
-// 8 per MFMA; an fp32 copy of the halo image (no unpacking per use) traded 50 vector for as many LDS instructions and
-// a third pipeline stage, and measured the same.
-// which is what the round-1 kernel (8 waves, 2 per SIMD, stage D and stage G back to back in every wave) could not
-// do: there the vector ALU work of one wave was NOT issued into the shadow of its SIMD partner's MFMAs, and the
-// depthwise stage cost 14 vector instructions per MFMA-equivalent; here it is under 5.
+// The chunk sequence RUNS ON INTO THE NEXT TILE: iteration NCH-2 fetches the next tile's halo chunk 0, iteration NCH-1
+// its chunk 1 while the depthwise stage builds its first A chunk and the weight fragments of its first k-step are
+// loaded -- a tile has no prologue of its own (round 2: 8 k of a tile's 60 k cycles).  The EPILOGUE touches no LDS the
+// loop uses: the host interleaves the two 16-wide n-fragments of a pair (weights.py: frag16_channel) so that a lane
+// holds eight CONSECUTIVE channels of its pixel over the pair, i.e. 16-byte stores straight from the accumulators and
+// 16-byte loads of the residual -- rows 0..31 of the residual tile prefetched into LDS by DMA under the K loop, rows
+// 32..79 loaded at the start of the epilogue, EVERY load before the first store (vmcnt retires in order and a store
+// retires ~1.8 k cycles after issue: a load behind a store cannot be consumed earlier; the first form of this epilogue,
+// loads and stores alternating, took 27 k cycles per tile instead of 11 k).
+// Measured (in-kernel stamps, tools/stamps_wide.py): chunks 3.0-3.3 k cycles each (the MFMAs alone: 1.92 k), the two
+// chunks after an epilogue 4-5 k (their weight loads queue behind its stores), epilogue 4 k without / 11 k with a
+// residual input; 51-55 k per tile against 58-66 k in round 2 -- 0.160 -> 0.148 ms per layer, bit-identical results.
 // Tap order and fp32 accumulation of the depthwise stage are those of every other producer in this library.
 #include "gemm_common.h"
 

@@ -331,6 +331,22 @@ def test_full_size_properties(engines):
     assert abs(float(mu[0]) - float(s[:, 1].double().mean())) < 1e-9
 
 
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+def test_persistent_kernel_every_tile_count(engines, dtype):
+    """The 728-wide kernel is persistent: one workgroup per CU walks tiles b, b + 256, ...  Batches whose tile counts
+    are below, at, just above and far from multiples of the 256 workgroups (5 tiles per image at 19x19, 19 at 37x37)
+    must give every image the features it gets inside a full batch, bit for bit."""
+    eng = engines[dtype]
+    g = torch.Generator(device='cuda').manual_seed(4)
+    tiles = torch.randint(0, 256, (256, 299, 299, 3), dtype=torch.uint8, device='cuda', generator=g)
+    full = eng.backbone(eng.stage(tiles))
+    for n in (2, 13, 14, 27, 51, 52, 53, 77, 103, 205, 255):
+        part = eng.backbone(eng.stage(tiles[:n].contiguous()))
+        assert torch.equal(part, full[:n]), (dtype, n)
+    tail = eng.backbone(eng.stage(tiles[200:].contiguous()))          # other images first in the batch
+    assert torch.equal(tail, full[200:])
+
+
 def test_evaluate_driver_matches_direct_calls(engines):
     """biscuit_amd.inference.evaluate (ragged slides, batches spanning slides) == direct calls."""
     from biscuit_amd.inference import Slide, evaluate
