@@ -20,10 +20,11 @@ Weights arrive as a dict of numpy arrays in Keras layout/names
 [1,1,Cin,Cout], ``*_bn/{gamma,beta,moving_mean,moving_variance}``, conv
 ``kernel`` HWIO, dense ``kernel`` [in,out] + ``bias``).
 
-``emulate_bf16=True`` additionally rounds to bfloat16 at exactly the points where
-the HIP bf16 path stores bf16 (staged tile, every layer output, the depthwise
-result, the matrix-core weights); accumulation stays fp32.  It is a secondary
-checker for the bf16 kernels; the fp32 mode is the parity oracle.
+``emulate='f16'`` / ``emulate='bf16'`` (or the older ``emulate_bf16=True``) additionally round to
+that 16-bit type at exactly the points where the HIP path of that storage type does (staged
+tile, every layer output, the depthwise result, the matrix-core weights; f16 saturates at
++-65504 as the device does); accumulation, depthwise taps and folded BN stay fp32.  These are
+secondary checkers for the 16-bit kernels; the fp32 mode is the parity oracle.
 """
 import numpy as np
 import torch
