@@ -30,6 +30,8 @@ struct GemmLayer {
     int nfp = 0;             // padded n-frags in wp
 };
 
+struct HeadLayer { const void* wh = nullptr; const void* wl = nullptr; const float* bias = nullptr; int k = 0; };
+
 struct ProfRec { int cls; hipEvent_t a, b; };
 
 }  // namespace
@@ -44,6 +46,7 @@ struct bq_ctx {
     std::map<std::string, GemmLayer> layers;
     const float* stem_w = nullptr; const float* stem_s = nullptr; const float* stem_b = nullptr;
     const float* logits_w = nullptr; const float* logits_b = nullptr;
+    HeadLayer head[2];             // hidden_0, hidden_1: weights split into two halves (kernels_head.hip)
     bool loaded = false;
     int num_cus = 256;
     float* d_srgb_lut = nullptr;   // tables of the Reinhard normaliser
@@ -90,7 +93,7 @@ constexpr long long kMaxAct = 147LL * 147 * 128;
 constexpr long long kMaxRes = 74LL * 74 * 128;
 
 struct WsLayout {
-    size_t a, b, c, r, staged, feat, hpart, h0, h1, state, total;
+    size_t a, b, c, r, staged, feat, h0, h1, state, total;
 };
 
 WsLayout ws_layout(const bq_ctx* c, int n, int mc) {
@@ -105,7 +108,6 @@ WsLayout ws_layout(const bq_ctx* c, int n, int mc) {
     L.staged = take((size_t)n * kStaged * es);
     L.feat = take((size_t)n * 2048 * 4);
     const size_t rows = (size_t)n * (mc > 0 ? mc : 1);
-    L.hpart = take(rows * 1024 * 4);
     L.h0 = take(rows * 1024 * 4);
     L.h1 = take(rows * 1024 * 4);
     L.state = take((size_t)n * 5 * 4);
@@ -167,7 +169,6 @@ int pick_shape(const bq_ctx* c, int prod, int nfp) {
         }
         return -1;
     }
-    if (prod == PROD_DROPOUT) return SHAPE_H;
     if (nfp == 4) return SHAPE_B;
     if (nfp == 8) return SHAPE_C;
     return SHAPE_H;
@@ -474,7 +475,6 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
               int init, int finalize, float* state, float* mean2, float* std2, unsigned char* ws,
               hipStream_t s) {
     const WsLayout L = ws_layout(c, n, mc_n);
-    float* hpart = (float*)(ws + L.hpart);
     float* h0 = (float*)(ws + L.h0);
     float* h1 = (float*)(ws + L.h1);
     const double rate = (double)c->cfg.dropout;
@@ -483,38 +483,17 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
     const unsigned thresh = (unsigned)t;
     const float dscale = (float)(1.0 / (1.0 - rate));
     const int rows = n * mc_n;
-    const char* names[2] = {"hidden_0", "hidden_1"};
     for (int layer = 0; layer < 2; ++layer) {
-        auto it = c->layers.find(names[layer]);
-        if (it == c->layers.end()) return fail(c, BQ_ERR_WEIGHTS, "head weights not loaded");
-        const GemmLayer& G = it->second;
-        const int K = G.kpad;                    // 2048 / 1024
-        // K handled per launch = 1024 (131.6 KB of LDS for the 32-row A tile: one workgroup per CU, and
-        // 7 680 rows are only 240 workgroups, so the launch is one latency chain per CU).  BQ_HEAD_WAVES=4
-        // restores the 4-wave workgroup.
-        static const bool w8 = !(bq_exp_env("BQ_HEAD_WAVES") && atoi(bq_exp_env("BQ_HEAD_WAVES")) == 4);
-        const int KS = 1024;
-        const int nsplit = K / KS;
+        const HeadLayer& G = c->head[layer];
+        if (!G.wh) return fail(c, BQ_ERR_WEIGHTS, "head weights not loaded");
+        const int K = G.k;                       // 2048 / 1024
+        // three f16 MFMAs per fp32 product (kernels_head.hip): 6 x the nominal FLOPs of the layer
         ProfScope ps(c, s, layer == 0 ? "mc_head_dense0" : "mc_head_dense1", 2.0 * rows * (double)K * 1024,
                      4.0 * ((layer == 0 ? (double)n : (double)rows) * K + (double)rows * 1024 + (double)K * 1024));
-        for (int sp = 0; sp < nsplit; ++sp) {
-            const bool last = sp == nsplit - 1;
-            GemmParams p{};
-            p.in = layer == 0 ? (const void*)feat : (const void*)h0;
-            p.wp = G.wp;
-            p.scale = nullptr;
-            p.bias = last ? G.bias : nullptr;
-            p.residual = sp > 0 ? hpart : nullptr;
-            p.out = last ? (layer == 0 ? h0 : h1) : hpart;
-            p.M = rows; p.K = KS; p.KBtot = K / 8; p.kb0 = sp * (KS / 8); p.k_off = sp * KS;
-            p.NFp = G.nfp; p.Nstore = 1024; p.ldo = 1024; p.ldi = K;
-            p.relu = last ? 1 : 0;
-            p.seed_lo = (unsigned)(seed & 0xffffffffu); p.seed_hi = (unsigned)(seed >> 32);
-            p.thresh = thresh; p.dscale = dscale; p.layer = layer; p.mc_n = mc_n; p.pass0 = pass0;
-            p.in_row_is_tile = layer == 0 ? 1 : 0; p.tile0 = tile0; p.tile0_dev = c->d_tile0;
-            const int e = launch_gemm(BQ_DTYPE_F32, PROD_DROPOUT, w8 ? SHAPE_I : SHAPE_H, p, s);
-            if (e) return fail(c, BQ_ERR_HIP, std::string("head dense launch: ") + hipGetErrorString((hipError_t)e));
-        }
+        const int e = launch_head_dense(layer == 0 ? feat : h0, G.wh, G.wl, G.bias, layer == 0 ? h0 : h1, rows, K, mc_n, pass0,
+                                        layer == 0 ? 1 : 0, layer, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), thresh,
+                                        dscale, tile0, c->d_tile0, s);
+        if (e) return fail(c, BQ_ERR_HIP, std::string("head dense launch: ") + hipGetErrorString((hipError_t)e));
     }
     {
         ProfScope ps(c, s, "mc_head_softmax_welford", 2.0 * rows * 1024 * 2, 4.0 * rows * 1024);
@@ -681,6 +660,7 @@ int bq_load_weights(bq_ctx* c, const void* host_blob, size_t nbytes) {
     if (!guard.ok) return fail(c, BQ_ERR_HIP, "hipSetDevice failed");
     if (c->d_blob) { (void)hipFree(c->d_blob); c->d_blob = nullptr; }
     c->entries.clear(); c->layers.clear(); c->loaded = false;
+    c->head[0] = c->head[1] = HeadLayer{};
     HIPCHK(c, hipMalloc((void**)&c->d_blob, nbytes));
     HIPCHK(c, hipMemcpy(c->d_blob, hb, nbytes, hipMemcpyHostToDevice));
     c->blob_bytes = nbytes;
@@ -712,8 +692,16 @@ int bq_load_weights(bq_ctx* c, const void* host_blob, size_t nbytes) {
     for (auto& sp : seps)
         RUN(register_gemm_layer(c, "block" + std::to_string(sp.block) + "_sepconv" + std::to_string(sp.idx),
                                 sp.cin, sp.cout, pad16(sp.cin), true, vec, elt));
-    RUN(register_gemm_layer(c, "hidden_0", 2048, 1024, 2048, false, 4, 4));
-    RUN(register_gemm_layer(c, "hidden_1", 1024, 1024, 1024, false, 4, 4));
+    for (int layer = 0; layer < 2; ++layer) {
+        const std::string name = layer == 0 ? "hidden_0" : "hidden_1";
+        const int K = layer == 0 ? 2048 : 1024;
+        auto wh = c->entries.find(name + "/wph"), wl = c->entries.find(name + "/wpl"), bi = c->entries.find(name + "/bias");
+        const size_t want = (size_t)32 * (K / 16) * 64 * 16;       // [1024 / 32][K / 16][64] x 16 B
+        if (wh == c->entries.end() || wl == c->entries.end() || bi == c->entries.end() || wh->second.n != want ||
+            wl->second.n != want || bi->second.n < 1024 * 4)
+            return fail(c, BQ_ERR_WEIGHTS, "missing or malformed head tensors of " + name);
+        c->head[layer] = HeadLayer{wh->second.p, wl->second.p, reinterpret_cast<const float*>(bi->second.p), K};
+    }
     c->loaded = true;
     return BQ_OK;
 }

@@ -45,8 +45,7 @@ enum BqProducer : int {
     PROD_DW = 0,      // depthwise 3x3 'same' of an NHWC map (SeparableConv2D first half)
     PROD_DW_RELU = 1, // same, ReLU applied to the input on load (block*_sepconv1_act)
     PROD_S2 = 2,      // 1x1 / stride-2 gather (residual Conv2D(1, strides=2, 'same'))
-    PROD_IM2COL = 3,  // 3x3 valid im2col, K = 9*C (block1_conv2)
-    PROD_DROPOUT = 4  // Philox inverted dropout of fp32 rows (MC head Dense layers)
+    PROD_IM2COL = 3   // 3x3 valid im2col, K = 9*C (block1_conv2)
 };
 
 enum BqShape : int {       // MF, WM, WN, RN   (tile rows = 32*MF, waves = WM*WN)
@@ -58,7 +57,7 @@ enum BqShape : int {       // MF, WM, WN, RN   (tile rows = 32*MF, waves = WM*WN
     SHAPE_F = 5,           // 2, 1, 8, 3
     SHAPE_G = 6,           // 1, 1, 8, 4
     SHAPE_H = 7,           // 1, 1, 4, 2   fp32 fallback
-    SHAPE_I = 8,           // 1, 1, 8, 2   MC head: 8 waves on a 32-row tile
+    SHAPE_I = 8,           // 1, 1, 8, 2   (unused since the MC head got its own kernel)
     SHAPE_J = 9,           // 2, 1, 4, 1   N = 128, 64-row tiles (1x1/s2 residual convs: more workgroups per CU)
     SHAPE_K = 10           // 2, 1, 4, 2   N = 256, 64-row tiles
 };
@@ -83,12 +82,6 @@ struct GemmParams {
     int H, W;              // output spatial size
     int Hi, Wi;            // input spatial size
     int relu;              // ReLU in the epilogue
-    // PROD_DROPOUT
-    unsigned seed_lo, seed_hi, thresh;
-    float dscale;
-    int layer, mc_n, pass0, in_row_is_tile;
-    long long tile0;
-    const long long* tile0_dev;   // optional device-side addend to tile0 (graph replay: the index changes between replays)
     int lds_total;         // dynamic LDS bytes of the launch (set by the pipe launcher)
 };
 
@@ -119,6 +112,9 @@ int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, in
 int launch_respool(int dtype, const void* x, const void* wp32, const float* scale, const float* bias, const void* y, void* out,
                    int n, int Hi, int Wi, int K, int ldx, int ld, int nf32, hipStream_t s);
 int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s);
+int launch_head_dense(const float* in, const void* wh, const void* wl, const float* bias, float* out, int rows, int K,
+                      int mc_n, int pass0, int in_row_is_tile, int layer, unsigned seed_lo, unsigned seed_hi, unsigned thresh,
+                      float dscale, long long tile0, const long long* tile0_dev, hipStream_t s);
 int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, const long long* tile0_dev,
                       unsigned seed_lo, unsigned seed_hi, unsigned thresh, float dscale,
                       const float* w2, const float* b2, int init, int finalize, float* state,

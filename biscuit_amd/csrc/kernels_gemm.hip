@@ -1,11 +1,11 @@
 // Fused "producer -> LDS A tile -> MFMA" kernel: the workhorse of the Xception backbone
 // (SeparableConv2D = depthwise 3x3 + pointwise 1x1 + folded BN [+ residual] [+ ReLU],
-// residual 1x1/s2 convs, block1_conv2 as im2col) and of the MC-dropout Dense layers.
+// residual 1x1/s2 convs, block1_conv2 as im2col).  (The MC-dropout Dense layers have their own kernel, kernels_head.hip.)
 //
 // Design (gfx950 / CDNA4, wave64):
 //  * One workgroup owns MT = 32*MF output pixels and ALL output channels.  Phase 1
 //    builds the [MT][K] A operand in LDS once (depthwise 3x3 on the vector ALU, a
-//    stride-2 gather, an im2col gather, or Philox dropout), so the depthwise result never
+//    stride-2 gather or an im2col gather), so the depthwise result never
 //    touches HBM and is not recomputed per output-channel tile.
 //  * Phase 2: every wave owns RN 32-wide output-channel fragments per pass and all RM
 //    row fragments; weights were pre-swizzled on the host into MFMA fragment order, so a
@@ -16,7 +16,7 @@
 //    or 16-byte (fp32) NHWC stores instead of 2-byte ones.
 //  * LDS row stride is an odd number of 16-byte slots: ds_read_b128 of 16 distinct rows
 //    is bank-conflict free (MI355X guide, LDS section).
-//  * bf16 uses v_mfma_f32_32x32x16_bf16; fp32 (parity mode and the MC head) uses four
+//  * bf16 / f16 use v_mfma_f32_32x32x16_{bf16,f16}; fp32 (the exact mode) uses four
 //    exact-fp32 v_mfma_f32_32x32x2_f32 per 16-byte fragment with the k order permuted
 //    identically on both operands.
 #include "gemm_common.h"
@@ -139,28 +139,6 @@ __device__ __forceinline__ void produce(const GemmParams& p, unsigned char* smem
                     const int ru = r + u * RF;
                     if (ru < MT && m0 + ru < p.M)
                         *reinterpret_cast<uint4*>(smem + (size_t)ru * stride + c * 16) = v[u];
-                }
-            }
-        } else {  // PROD_DROPOUT (T = float): Philox4x32-10 inverted dropout
-            for (int r = tr; r < MT; r += RF) {
-                const int m = m0 + r;
-                if (m < p.M) {
-                    const int tile = m / p.mc_n;
-                    const int pass = p.pass0 + (m - tile * p.mc_n);
-                    const size_t row = p.in_row_is_tile ? (size_t)tile : (size_t)m;
-                    const uint4 vv = *reinterpret_cast<const uint4*>(in + row * ldi + ch0);
-                    unsigned rnd[4];
-                    const long long t0 = p.tile0 + (p.tile0_dev ? *p.tile0_dev : 0);
-                    philox4x32_10((unsigned)(ch0 >> 2), (unsigned)p.layer, (unsigned)pass,
-                                  (unsigned)(t0 + tile), p.seed_lo, p.seed_hi, rnd);
-                    float f[4];
-                    f[0] = __uint_as_float(vv.x); f[1] = __uint_as_float(vv.y);
-                    f[2] = __uint_as_float(vv.z); f[3] = __uint_as_float(vv.w);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) f[j] = (rnd[j] >= p.thresh) ? f[j] * p.dscale : 0.f;
-                    *reinterpret_cast<uint4*>(smem + (size_t)r * stride + c * 16) =
-                        make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]),
-                                   __float_as_uint(f[2]), __float_as_uint(f[3]));
                 }
             }
         }
@@ -337,8 +315,6 @@ int launch_gemm(int dtype, int prod, int shape, const GemmParams& p, hipStream_t
         BQ_CASE(float, PROD_DW, SHAPE_H)
         BQ_CASE(float, PROD_DW_RELU, SHAPE_H)
         BQ_CASE(float, PROD_S2, SHAPE_H)
-        BQ_CASE(float, PROD_DROPOUT, SHAPE_H)
-        BQ_CASE(float, PROD_DROPOUT, SHAPE_I)
     }
     return (int)hipErrorInvalidValue;
 }

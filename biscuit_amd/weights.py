@@ -208,6 +208,17 @@ def f32_to_f16_bits(a):
     return a.astype(np.float16).view(np.uint16)
 
 
+HEAD_SPLIT_SCALE = 2048.0          # 2^11: kernels_head.hip HSCALE
+
+
+def split_f16(a):
+    """float32 -> (hi, lo) IEEE-half bit patterns with a ~= hi + lo / 2^11: hi = f16(a), lo = f16((a - hi) * 2^11)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    hi = np.clip(a, -65504.0, 65504.0).astype(np.float16)
+    lo = ((a - hi.astype(np.float32)) * np.float32(HEAD_SPLIT_SCALE)).astype(np.float16)
+    return hi.view(np.uint16), lo.view(np.uint16)
+
+
 DTYPE_CODE = {'f32': 0, 'bf16': 1, 'f16': 2}      # BQ_DTYPE_* of include/biscuit_hip.h
 
 
@@ -331,13 +342,16 @@ def pack_blob(w, dtype='bf16'):
             add(name + '/wp16', to_bits(pack_fragments16(w[name + '/pointwise_kernel'].reshape(cin, cout), cp, npad)))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)
-    # head stays fp32 regardless of the backbone dtype (MC std ~1e-2 must not be
-    # quantisation noise); always V = 4 fragments.
+    # The head keeps fp32 ACCURACY regardless of the backbone dtype (MC std ~1e-2 must not be quantisation noise), at the
+    # 16-bit matrix rate: every weight is split into two IEEE halves, w = hi + lo / 2^11 (22 significand bits; the scale
+    # keeps lo out of the subnormals), both in 32x32x16 fragment order (kernels_head.hip multiplies three of the four
+    # hi / lo cross terms of x * w with fp32 accumulation).
     for name, kin in (('hidden_0', 2048), ('hidden_1', 1024)):
-        p = pack_fragments(w[name + '/kernel'], kin, 4)
-        add(name + '/wp', p)
-        n = p.shape[0] * 32
-        add_affine(name, np.ones(w[name + '/bias'].size, np.float32), w[name + '/bias'], n)
+        p = pack_fragments(w[name + '/kernel'], kin, 8)
+        hi, lo = split_f16(p)
+        add(name + '/wph', hi)
+        add(name + '/wpl', lo)
+        add(name + '/bias', _padvec(w[name + '/bias'].astype(np.float32), p.shape[0] * 32))
     add('logits/w', w['logits/kernel'].astype(np.float32))
     add('logits/bias', w['logits/bias'].astype(np.float32))
 

@@ -117,6 +117,31 @@ def test_fragment_pairs_interleave():
         assert p[ks, nf, lane, v] == (w[k, n] if (k < 40 and n < 70) else 0.0)
 
 
+def test_head_weight_split_keeps_fp32_accuracy():
+    """kernels_head.hip multiplies fp32 operands as two IEEE halves each: w ~= hi + lo / 2^11.  The pair carries 22
+    significand bits, and the three-term product with fp32 accumulation is as close to float64 as a plain fp32 GEMM."""
+    rng = np.random.default_rng(5)
+    w = rng.uniform(-0.05, 0.05, (2048, 256)).astype(np.float32)
+    w[:4, 0] = [0.0, 1e-7, -3e-5, 65000.0]
+    hi, lo = (x.view(np.float16).astype(np.float32) for x in W.split_f16(w))
+    back = hi + lo / np.float32(W.HEAD_SPLIT_SCALE)
+    rel = np.abs(back - w) / np.maximum(np.abs(w), 1e-4)
+    assert rel.max() < 2.0 ** -21 and np.isfinite(back).all()
+    x = (np.abs(rng.normal(0.8, 0.5, (64, 2048))) * (rng.random((64, 2048)) >= 0.1) / 0.9).astype(np.float32)
+    xh, xl = (t.view(np.float16).astype(np.float32) for t in W.split_f16(x))
+    ref = x.astype(np.float64) @ w.astype(np.float64)
+    three = (xh @ hi) + ((xh @ lo) + (xl @ hi)) / np.float32(W.HEAD_SPLIT_SCALE)
+    plain = x @ w
+    e3, e1 = np.abs(three - ref), np.abs(plain - ref)
+    assert np.sqrt((e3[:, 1:] ** 2).mean()) < 2.0 * np.sqrt((e1[:, 1:] ** 2).mean()) and e3[:, 1:].max() < 1e-5
+    blob = W.pack_blob(W.synthetic_weights(3), 'f16')
+    n = struct.unpack_from('<4sIII', blob, 0)[2]
+    names = {struct.unpack_from('<48sQQ', blob, 16 + 64 * i)[0].rstrip(b'\0').decode(): struct.unpack_from('<48sQQ', blob, 16 + 64 * i)[1:]
+             for i in range(n)}
+    assert names['hidden_0/wph'][1] == names['hidden_0/wpl'][1] == 32 * 128 * 64 * 8 * 2
+    assert names['hidden_1/wph'][1] == 32 * 64 * 64 * 8 * 2 and 'hidden_0/wp' not in names
+
+
 def test_blob_directory_roundtrip():
     w = W.synthetic_weights(3)
     blob = W.pack_blob(w, 'bf16')
