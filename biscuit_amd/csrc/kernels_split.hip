@@ -100,7 +100,9 @@ constexpr int A_ROW = BK * 2 + 16;        // 144 B: 9 slots, conflict-free ds_re
 constexpr int A_BUF = BM * A_ROW;         // 18 KB
 constexpr int ST_ROW = BN * 2 + 16;       // staging row of the output tile
 
-template <typename T, int PF>
+// S2: the rows of A are the even pixels of a larger map (1x1 / stride 2 / 'same' shortcut convolutions): row m = output
+// pixel (img, y, x) of an H x W map reads input pixel (img, 2y, 2x) of the Hi x Wi map.
+template <typename T, int PF, bool S2>
 __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
     if constexpr (H16<T>::F16) bq_f16_saturate();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -116,14 +118,26 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
 
     // A staging: 4 pieces per thread and chunk; row = idx >> 3, piece = idx & 7
     const int jp = tid & 7;
+    size_t arow[4];                                  // element offset of this thread's four A rows (the same for every chunk)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int row = m0 + ((tid + q * 256) >> 3);
+        row = row < p.M ? row : p.M - 1;
+        if constexpr (S2) {
+            const int hw = p.H * p.W;
+            const int img = row / hw, rem = row - img * hw;
+            const int y = rem / p.W, x = rem - y * p.W;
+            arow[q] = ((size_t)(img * p.Hi + 2 * y) * p.Wi + 2 * x) * p.ldi;
+        } else {
+            arow[q] = (size_t)row * p.ldi;
+        }
+    }
     auto load_a = [&](int c, uint4 (&r)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int row = m0 + ((tid + q * 256) >> 3);
-            row = row < p.M ? row : p.M - 1;
             const int k0 = c * BK + jp * 8;
             const int kc = k0 < K ? k0 : 0;           // past K (tail chunk): any valid address, zeroed below
-            uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)row * p.ldi + kc);
+            uint4 v = *reinterpret_cast<const uint4*>(A + arow[q] + kc);
             if (k0 >= K) v = make_uint4(0, 0, 0, 0);
             r[q] = v;
         }
@@ -257,12 +271,18 @@ int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, i
                       : launch_dw3x3_t<bf16_t>(in, dw, out, n, H, W, C, relu, s);
 }
 
-// p.in = depthwise result [M][ldi]; p.NFp multiple of 4; 16-bit types only
-int launch_gemm_tile(int dtype, const GemmParams& p, hipStream_t s) {
+// p.in = depthwise result [M][ldi] -- or, with s2, the map [n][Hi][Wi][ldi] whose even pixels are the rows;
+// p.NFp multiple of 4; 16-bit types only
+int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s) {
     if (p.NFp % 4 != 0 || p.K % 16 != 0) return (int)hipErrorInvalidValue;
     const size_t lds = 2 * A_BUF > BM * ST_ROW ? 2 * A_BUF : BM * ST_ROW;
     const int grid = ((p.M + BM - 1) / BM) * (p.NFp / 4);
-    if (dtype == 2) hipLaunchKernelGGL((gemm_tile_kernel<f16_t, 4>), dim3(grid), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((gemm_tile_kernel<bf16_t, 4>), dim3(grid), dim3(256), lds, s, p);
+    if (dtype == 2) {
+        if (s2) hipLaunchKernelGGL((gemm_tile_kernel<f16_t, 4, true>), dim3(grid), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((gemm_tile_kernel<f16_t, 4, false>), dim3(grid), dim3(256), lds, s, p);
+    } else {
+        if (s2) hipLaunchKernelGGL((gemm_tile_kernel<bf16_t, 4, true>), dim3(grid), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((gemm_tile_kernel<bf16_t, 4, false>), dim3(grid), dim3(256), lds, s, p);
+    }
     return (int)hipGetLastError();
 }
