@@ -554,6 +554,15 @@ def tfrecord_leg(pool_e, args, n_slides=8, tiles_per_slide=256):
         for p in paths:
             tfrecord.read_slide(p, 299)
         dec = time.perf_counter() - t0
+        # the same tiles as JPEG records (Slideflow's img_format='jpg'): decode only, one file
+        jbase = [tfrecord.encode_image(t, 'JPEG') for t in make_tiles(32, seed=21)]
+        jp = os.path.join(d, 'j.tfrecords')
+        tfrecord.write_slide(jp, 'j', [jbase[i % 32] for i in range(tiles_per_slide)], np.zeros((tiles_per_slide, 2), np.int64))
+        tfrecord.read_slide(jp, 299)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            tfrecord.read_slide(jp, 299)
+        jdec = (time.perf_counter() - t0) / 4
         slides = slides_from_tfrecords(paths, {f's{s}': s % 2 for s in range(n_slides)})
         evaluate(pool_e, slides[:1], mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False)     # warm-up
         t0 = time.perf_counter()
@@ -562,7 +571,9 @@ def tfrecord_leg(pool_e, args, n_slides=8, tiles_per_slide=256):
         n = n_slides * tiles_per_slide
         assert int(res.slide_count.sum()) == n
         return {'tiles': n, 'value': n / dt, 'unit': 'tiles/s', 'decode_only_tiles_per_s': n / dec,
+                'jpeg_decode_only_tiles_per_s': tiles_per_slide / jdec,
                 'host_cores': usable_cores(), 'png_bytes_per_tile': nbytes / n,
+                'jpeg_bytes_per_tile': os.path.getsize(jp) / tiles_per_slide,
                 'note': 'end to end from PNG TFRecords incl. host decode, H2D, kernels, tile table; bound by host decode '
                         'when decode_only is below the resident-tiles value'}
     finally:

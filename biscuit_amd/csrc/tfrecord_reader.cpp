@@ -3,6 +3,7 @@
 // (zlib inflate + scanline unfilter).  Host code only: g++, -lz, -lpthread.
 #include "../../include/biscuit_io.h"
 #include "inflate_fast.h"
+#include "jpeg_baseline.h"
 
 #include <fcntl.h>
 #include <string.h>
@@ -12,6 +13,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -448,6 +450,7 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
     const size_t tile_bytes = (size_t)tile_px * tile_px * 3;
     auto work = [&]() {
         std::vector<PngJob> jobs(2);                      // two tiles at a time: their streams are inflated in one loop
+        std::unique_ptr<bqjpg::Scratch> jpg;              // built on the first JPEG record
         auto fail = [&](int e, int64_t i) {
             int expect = BQIO_OK;
             if (status.compare_exchange_strong(expect, e)) bad.store(first + i);
@@ -457,24 +460,37 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
             if (i0 >= count || status.load() != BQIO_OK) return;
             const int nj = i0 + 1 < count ? 2 : 1;
             Example ex[2];
+            int png[2], npng = 0;                          // the records of this pair that are PNG -> jobs[0..npng)
             for (int k = 0; k < nj; ++k) {
                 int e = BQIO_OK;
                 if (!parse_example(r->records[(size_t)(first + i0 + k)], ex[k]) || !ex[k].image.p) e = BQIO_ERR_CORRUPT;
-                else if (image_format(ex[k].image) != BQIO_IMG_PNG) e = BQIO_ERR_UNSUPPORTED;
-                else e = png_parse(ex[k].image, tile_px, jobs[k]);
-                if (e != BQIO_OK) { fail(e, i0 + k); return; }
-            }
-            bool ok[2] = {false, false};
-            if (nj == 2)
-                bqinf::inflate_zlib2(jobs[0].zbuf.data(), jobs[0].z_n, jobs[0].raw.data(), jobs[0].raw_n, jobs[0].tables, ok[0],
-                                     jobs[1].zbuf.data(), jobs[1].z_n, jobs[1].raw.data(), jobs[1].raw_n, jobs[1].tables, ok[1]);
-            else
-                ok[0] = bqinf::inflate_zlib(jobs[0].zbuf.data(), jobs[0].z_n, jobs[0].raw.data(), jobs[0].raw_n, jobs[0].tables);
-            for (int k = 0; k < nj; ++k) {
-                int e = (ok[k] || inflate_second_opinion(jobs[k])) ? png_finish(jobs[k], out + (size_t)(i0 + k) * tile_bytes)
-                                                                   : BQIO_ERR_CORRUPT;
+                else switch (image_format(ex[k].image)) {
+                    case BQIO_IMG_PNG:
+                        e = png_parse(ex[k].image, tile_px, jobs[npng]);
+                        png[npng++] = k;
+                        break;
+                    case BQIO_IMG_JPEG: {
+                        if (!jpg) jpg.reset(new bqjpg::Scratch());
+                        const int j = bqjpg::decode(ex[k].image.p, ex[k].image.n, tile_px, out + (size_t)(i0 + k) * tile_bytes, *jpg);
+                        e = j == bqjpg::OK ? BQIO_OK : j == bqjpg::WRONG_SIZE ? BQIO_ERR_FORMAT : BQIO_ERR_UNSUPPORTED;
+                        break;
+                    }
+                    default: e = BQIO_ERR_UNSUPPORTED;
+                }
                 if (e != BQIO_OK) { fail(e, i0 + k); return; }
                 if (loc) { loc[2 * (i0 + k)] = ex[k].loc_x; loc[2 * (i0 + k) + 1] = ex[k].loc_y; }
+            }
+            bool ok[2] = {false, false};
+            if (npng == 2)
+                bqinf::inflate_zlib2(jobs[0].zbuf.data(), jobs[0].z_n, jobs[0].raw.data(), jobs[0].raw_n, jobs[0].tables, ok[0],
+                                     jobs[1].zbuf.data(), jobs[1].z_n, jobs[1].raw.data(), jobs[1].raw_n, jobs[1].tables, ok[1]);
+            else if (npng == 1)
+                ok[0] = bqinf::inflate_zlib(jobs[0].zbuf.data(), jobs[0].z_n, jobs[0].raw.data(), jobs[0].raw_n, jobs[0].tables);
+            for (int j = 0; j < npng; ++j) {
+                const int k = png[j];
+                int e = (ok[j] || inflate_second_opinion(jobs[j])) ? png_finish(jobs[j], out + (size_t)(i0 + k) * tile_bytes)
+                                                                   : BQIO_ERR_CORRUPT;
+                if (e != BQIO_OK) { fail(e, i0 + k); return; }
             }
         }
     };
@@ -485,11 +501,18 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
     const int e = status.load();
     if (e != BQIO_OK) {
         if (bad_index) *bad_index = bad.load();
-        r->err = e == BQIO_ERR_UNSUPPORTED ? "image_raw is not a PNG this decoder handles"
+        r->err = e == BQIO_ERR_UNSUPPORTED ? "image_raw is not a PNG or baseline JPEG this decoder handles"
                  : e == BQIO_ERR_FORMAT    ? "tile size differs from tile_px"
                                            : "corrupt record or PNG";
     }
     return e;
+}
+
+int bqio_decode_jpeg(const uint8_t* data, size_t len, int tile_px, uint8_t* out) {
+    if (!data || !out || tile_px <= 0) return BQIO_ERR_ARG;
+    std::unique_ptr<bqjpg::Scratch> S(new bqjpg::Scratch());
+    const int j = bqjpg::decode(data, len, tile_px, out, *S);
+    return j == bqjpg::OK ? BQIO_OK : j == bqjpg::WRONG_SIZE ? BQIO_ERR_FORMAT : BQIO_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

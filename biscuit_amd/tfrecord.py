@@ -6,9 +6,9 @@ them: the container is length-prefixed records
     uint64 length | uint32 masked_crc32c(length) | bytes[length] | uint32 masked_crc32c(data)
 each holding a ``tf.train.Example`` protobuf with features ``slide`` (bytes), ``image_raw``
 (bytes: PNG or JPEG), ``loc_x`` / ``loc_y`` (int64).  Only that subset of protobuf is parsed.
-PNG tiles are decoded by the native reader (libbiscuit_io.so: C++ framing, protobuf subset, zlib inflate +
-unfilter, a pool of host threads; include/biscuit_io.h); Pillow handles JPEG payloads and is the fallback
-when the library is not built.  A writer for the same wire format is included so the
+PNG and baseline-JPEG tiles are decoded by the native reader (libbiscuit_io.so: C++ framing, protobuf subset, its own
+inflate + unfilter and its own JPEG decoder, a pool of host threads; include/biscuit_io.h); Pillow decodes what that
+reader refuses (progressive or damaged JPEG) and is the fallback when the library is not built.  A writer for the same wire format is included so the
 reader can be tested without TensorFlow (there are no real TFRecords in this environment).
 """
 import io
@@ -169,8 +169,8 @@ def read_slide(path, tile_px=299, verify='length', native=None, out=None, thread
     """One slide's TFRecord -> (slide name, tiles uint8 [T,px,px,3], loc int64 [T,2]).
 
     ``native=None`` uses libbiscuit_io.so (C++ framing / protobuf / PNG decode on a thread pool) when it
-    is built and falls back to the pure-Python reader otherwise; records the native decoder does not
-    handle (JPEG) are decoded with Pillow either way.  ``out``: optional uint8 buffer [T,px,px,3] to
+    is built and falls back to the pure-Python reader otherwise; a slide with a record the native decoder
+    refuses (progressive JPEG, a damaged stream) is decoded with Pillow either way.  ``out``: optional uint8 buffer [T,px,px,3] to
     decode into (pinned memory for an overlapped H2D copy)."""
     if native is None:
         from . import tfrecord_native
@@ -185,7 +185,7 @@ def read_slide(path, tile_px=299, verify='length', native=None, out=None, thread
                 tiles, locs = r.decode(0, n, tile_px, out=out, threads=threads)
                 return r.slide, tiles, locs
             except tn.UnsupportedImage:
-                name = r.slide            # JPEG payloads: Pillow below
+                name = r.slide            # outside the native decoders' subset: Pillow below
     tiles, locs, name = [], [], None
     for payload in read_records(path, verify):
         ex = parse_example(payload)

@@ -2,9 +2,9 @@
 
 `NativeReader(path)` indexes one slide's TFRecord; `decode(first, count)` returns uint8 tiles
 ``[count, px, px, 3]`` decoded by a pool of host threads, optionally straight into a caller-supplied
-(e.g. pinned) buffer so the H2D copy of one batch overlaps the decode of the next.  JPEG payloads are
-not decoded natively: `decode` raises `UnsupportedImage` and the caller (tfrecord.read_slide) decodes
-those records with Pillow.
+(e.g. pinned) buffer so the H2D copy of one batch overlaps the decode of the next.  PNG and baseline JPEG
+payloads are decoded natively; for anything else (progressive JPEG, a damaged stream) `decode` raises
+`UnsupportedImage` and the caller (tfrecord.read_slide) decodes the slide with Pillow.
 """
 import ctypes as C
 import os
@@ -33,6 +33,7 @@ ABI = {
     'bqio_inflate2': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp, C.c_size_t,
                           C.POINTER(_i), C.POINTER(_i)]),
     'bqio_inflate_fallbacks': (_i64, []),
+    'bqio_decode_jpeg': (_i, [C.c_char_p, C.c_size_t, _i, _vp]),
 }
 
 
@@ -85,6 +86,18 @@ def inflate2(za, len_a, zb, len_b):
     return (oa.tobytes() if ka.value else None), (ob.tobytes() if kb.value else None)
 
 
+def decode_jpeg(raw, tile_px=299):
+    """One JPEG file's bytes -> uint8 [px,px,3] through the reader's own baseline decoder (csrc/jpeg_baseline.h);
+    UnsupportedImage for streams outside its subset, ValueError for a tile of another size.  For tests."""
+    out = np.empty((tile_px, tile_px, 3), np.uint8)
+    e = lib().bqio_decode_jpeg(bytes(raw), len(raw), tile_px, out.ctypes.data)
+    if e == ERR_UNSUPPORTED:
+        raise UnsupportedImage(0)
+    if e != 0:
+        raise ValueError(f'bqio_decode_jpeg: error {e}')
+    return out
+
+
 def inflate_fallbacks():
     """Streams handed to zlib after the reader's own decompressor refused them although zlib accepts them (0 = none)."""
     return int(lib().bqio_inflate_fallbacks())
@@ -92,7 +105,7 @@ def inflate_fallbacks():
 
 class UnsupportedImage(ValueError):
     def __init__(self, index):
-        super().__init__(f'record {index}: image_raw is not a PNG the native decoder handles')
+        super().__init__(f'record {index}: image_raw is not a PNG or baseline JPEG the native decoder handles')
         self.index = index
 
 

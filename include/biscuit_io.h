@@ -6,9 +6,12 @@
  * configure.py:118-124): TFRecord framing
  *     uint64 length | uint32 masked_crc32c(length) | bytes[length] | uint32 masked_crc32c(data)
  * a `tf.train.Example` holding `slide` (bytes), `image_raw` (bytes, PNG or JPEG), `loc_x`,
- * `loc_y` (int64), and the PNG decode (zlib inflate + scanline unfilter written here; the image
- * has no libpng).  JPEG payloads are reported, not decoded: the caller hands those bytes to its
- * own decoder.  No TensorFlow, no Slideflow.  Plain pointers and sizes only.
+ * `loc_y` (int64), the PNG decode (zlib inflate + scanline unfilter written here; the image
+ * has no libpng) and the baseline-JPEG decode (csrc/jpeg_baseline.h: the arithmetic of libjpeg's
+ * defaults -- islow IDCT, fancy upsampling -- which is what TensorFlow's decode_jpeg runs, so the
+ * bytes are the ones the reference's pipeline saw).  JPEG streams outside that subset are reported,
+ * not decoded: the caller hands those bytes to its own decoder.  No TensorFlow, no Slideflow.
+ * Plain pointers and sizes only.
  */
 #ifndef BISCUIT_IO_H
 #define BISCUIT_IO_H
@@ -45,12 +48,18 @@ int bqio_image_format(bqio_reader* r, int64_t index);
 int bqio_image_bytes(bqio_reader* r, int64_t index, const uint8_t** data, size_t* len);
 
 /* Decode records [first, first+count): RGB uint8 tiles into out[count][tile_px][tile_px][3],
- * loc_x/loc_y into loc[count][2] (may be NULL), with n_threads worker threads.  PNG only
- * (8-bit grey, RGB, palette, RGBA -- alpha dropped; non-interlaced).  A JPEG or otherwise
- * unsupported payload returns BQIO_ERR_UNSUPPORTED and leaves the index of the first such record
- * in *bad_index (may be NULL); a tile of the wrong size returns BQIO_ERR_FORMAT. */
+ * loc_x/loc_y into loc[count][2] (may be NULL), with n_threads worker threads.  PNG (8-bit grey,
+ * RGB, palette, RGBA -- alpha dropped; non-interlaced) and baseline JPEG (8-bit, Huffman, one
+ * interleaved scan, grey or YCbCr at 4:4:4 / 4:2:2 / 4:2:0, restart markers allowed).  Any other
+ * payload -- progressive JPEG, a damaged JPEG stream, ... -- returns BQIO_ERR_UNSUPPORTED and
+ * leaves the index of the first such record in *bad_index (may be NULL); a tile of the wrong size
+ * returns BQIO_ERR_FORMAT. */
 int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc,
                 int n_threads, int64_t* bad_index);
+
+/* One JPEG file (as bqio_image_bytes returns it) -> out[tile_px][tile_px][3], the decoder
+ * bqio_decode uses, exported for tests.  BQIO_OK / BQIO_ERR_UNSUPPORTED / BQIO_ERR_FORMAT. */
+int bqio_decode_jpeg(const uint8_t* data, size_t len, int tile_px, uint8_t* out);
 
 /* masked CRC-32C of a buffer (the TFRecord checksum), exported for tests and writers. */
 uint32_t bqio_masked_crc32c(const uint8_t* data, size_t len);

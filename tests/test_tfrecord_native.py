@@ -113,23 +113,31 @@ def test_errors(tmp_path):
         tn.NativeReader(bad)
     with pytest.raises(IOError):
         tn.NativeReader(str(tmp_path / 'missing.tfrecords'))
-    # wrong tile size, JPEG payload, empty file
+    # wrong tile size, JPEG payloads, empty file
     small = str(tmp_path / 'small.tfrecords')
     _write(small, [_png(tiles[0][:100, :100])])
     with tn.NativeReader(small) as r, pytest.raises(ValueError, match='tile size'):
         r.decode()
     from PIL import Image
-    jb = io.BytesIO()
+    jb, pb = io.BytesIO(), io.BytesIO()
     Image.fromarray(tiles[0]).save(jb, format='JPEG', quality=95)
+    Image.fromarray(tiles[0]).save(pb, format='JPEG', quality=95, progressive=True)
     mixed = str(tmp_path / 'mixed.tfrecords')
-    _write(mixed, [_png(tiles[0]), jb.getvalue()])
-    with tn.NativeReader(mixed) as r:
+    _write(mixed, [_png(tiles[0]), jb.getvalue(), _png(tiles[1])])
+    with tn.NativeReader(mixed) as r:                # PNG and baseline JPEG records side by side
         assert r.image_format(1) == tn.IMG_JPEG
+        t, _ = r.decode()
+    assert np.array_equal(t[0], tiles[0]) and np.array_equal(t[2], tiles[1])
+    assert np.array_equal(t[1], np.asarray(Image.open(io.BytesIO(jb.getvalue())).convert('RGB')))
+    prog = str(tmp_path / 'prog.tfrecords')
+    _write(prog, [_png(tiles[0]), pb.getvalue()])
+    with tn.NativeReader(prog) as r:                 # progressive: outside the native decoder's subset
         with pytest.raises(tn.UnsupportedImage) as ei:
             r.decode()
         assert ei.value.index == 1
-    name, t, _ = tfr.read_slide(mixed)               # falls back to Pillow for the JPEG record
+    name, t, _ = tfr.read_slide(prog)                # ... so the slide is decoded with Pillow
     assert t.shape == (2, 299, 299, 3) and np.array_equal(t[0], tiles[0])
+    assert np.array_equal(t[1], np.asarray(Image.open(io.BytesIO(pb.getvalue())).convert('RGB')))
     empty = str(tmp_path / 'empty.tfrecords')
     open(empty, 'wb').close()
     with tn.NativeReader(empty) as r:
