@@ -44,7 +44,15 @@
 namespace {
 using namespace bqk;
 
-constexpr int NP = 736;                 // padded OUTPUT channels: every instance produces 728 (row stride 736)
+// Output side of an instance: NOUT stored channels per pixel (736: the layers that produce 728; 256: block3_sepconv2) on 8
+// waves of RN 16-wide n-fragments each
+template <int NOUT>
+struct NPlan {
+    static constexpr int NP = NOUT;                      // row stride of the output (and of a residual input)
+    static constexpr int RN = (NOUT + 127) / 128;        // n-fragments per wave: 6 (768 padded channels) or 2
+    static constexpr int NFT = 8 * RN, CPW = RN * 16;    // n-fragments in all, output channels per wave
+    static_assert(RN % 2 == 0, "n-fragments are stored as interleaved pairs");
+};
 // Input side of an instance: KIN padded input channels (736: the 728 -> 728 layers; 256: block4_sepconv1), walked in
 // 64-channel chunks -- an even number of them, the last of 32 or 64 channels
 template <int KIN>
@@ -56,25 +64,24 @@ struct KPlan {
     static_assert(KIN % 32 == 0 && NCH % 2 == 0 && NCH >= 4 && (LASTK == 1 || LASTK == 2), "chunk plan");
 };
 constexpr int KC = 64;                  // channels per chunk
-constexpr int MT = 80;                  // MFMA rows per tile
 constexpr int A_STR = KC * 2 + 32;      // 160 B = 10 slots of 16 B: the 16x16x32 fragment read (lane -> row l&15, 16-byte
                                         // k-group l>>4) is conflict-free for ds_read_b128's lane groups iff slots/row = 2 (mod 4)
-constexpr int A_BYTES = (MT + 1) * A_STR;   // row 80 takes the results of pixels past the end of a map row
-constexpr int NSTEP = 5;                // pixels per depthwise run
-constexpr int WN = 8, RN = 6, MF = 5;   // waves, 16-wide n-fragments per wave, 16-row m-fragments
-constexpr int NFT = WN * RN;            // 48 n-fragments of 16 output channels
-constexpr int CPW = RN * 16;            // 96 output channels per wave
-constexpr int TAPS_BYTES = 9 * 736 * 4;  // LDS reserved for the depthwise taps (the widest instance's)
-constexpr int SB_BYTES = 2 * 768 * 4;
+constexpr int WN = 8;                   // waves
 constexpr int RES_ROWS = 32;             // residual rows that go through LDS (row fragments 0 and 1)
-constexpr int RES_PPR = CPW * 2 / 16 + 1; // 13 pieces of 16 B per row: odd
+constexpr int RES_PPR = NPlan<736>::CPW * 2 / 16 + 1; // 13 pieces of 16 B per row: odd (only 736-wide layers have a residual input)
 constexpr int RES_STR = RES_PPR * 16;
 constexpr int NRES = (RES_ROWS * RES_PPR + 63) / 64;   // LDS-DMA instructions per wave: 7, one per chunk
 
-// Geometry of one instance: IW x IW maps, TR map rows per tile (TR * IW <= 80 pixels).
-template <int IW_, int TR_>
+// Geometry of one instance: IW x IW maps, TR map rows per tile; KTAPS / NSB: the widest input / padded output the instance's
+// tap and folded-BN tables in LDS have to hold.
+template <int IW_, int TR_, int KTAPS = 736, int NSB = 768>
 struct Geo {
     static constexpr int IW = IW_, IH = IW_, TR = TR_;
+    static constexpr int MT = (TR * IW + 15) / 16 * 16;      // MFMA rows per tile: 80 (76 or 74 pixels) or 160 (148)
+    static constexpr int MF = MT / 16;                       // 16-row m-fragments
+    static constexpr int A_BYTES = (MT + 1) * A_STR;         // the row behind the last takes the results of pixels past the end of a map row
+    static constexpr int TAPS_BYTES = 9 * KTAPS * 4;         // depthwise taps
+    static constexpr int SB_HALF = NSB * 4, SB_BYTES = 2 * SB_HALF;   // folded BN: scales, then biases
     static constexpr int TPI = (IH + TR - 1) / TR;           // tiles per image
     static constexpr int PW = IW + 2;                        // slots per row of the padded halo image
     static constexpr int NSLOT = (TR + 2) * PW;              // slots of 128 B (64 channels of one pixel)
@@ -82,6 +89,7 @@ struct Geo {
     static constexpr int HPW = (NDMA + WN - 1) / WN;         // ... per wave
     static constexpr int RAW_BYTES = HPW * WN * 1024;
     static constexpr int SEG = 16 / TR;                      // depthwise runs per tile row (16 lane groups in all)
+    static constexpr int NSTEP = (IW + SEG - 1) / SEG;       // pixels per run: 5 (19- and 37-wide maps) or 10 (74-wide)
     // LDS map: the loop's buffers and the two tables.  Round 3: there is NO staging tile any more -- the epilogue goes
     // from the accumulators straight to HBM (see the kernel), so nothing of a tile's end touches LDS and the next
     // tile's halo, taps and first A chunk can be in place before the current tile's epilogue starts.
@@ -94,9 +102,9 @@ struct Geo {
     // the first RES_ROWS rows of a tile's residual input, per wave its 96 channels (RES_STR: 12 pieces + 1 of padding),
     // copied in by LDS-DMA while the K loop runs; nothing else ever uses this region
     static constexpr int OFF_RES = OFF_RAW + 2 * RAW_BYTES;
-    static constexpr int LDS_BYTES = OFF_RES + WN * RES_ROWS * RES_STR;
+    static constexpr int lds_bytes(bool res) { return OFF_RES + (res ? WN * RES_ROWS * RES_STR : 0); }
     static_assert(OFF_RAW < 65536, "immediate offsets of the A / tap / table accesses");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(lds_bytes(IW_ == 19) <= 160 * 1024, "LDS budget (only the 19x19 layers have a residual input)");
     static_assert(SEG * NSTEP >= IW && SEG * TR == 16 && TR * IW <= MT, "depthwise runs do not cover the tile");
 };
 
@@ -163,7 +171,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 //                         k = 10      v_cvt_pk_bf16_f32 + ds_write_b32 into the A chunk
 //                         k = 11..13  unpack column s+2, row k-11, into the registers of column s-1 (dead after tap 6)
 constexpr int NPRIME = 9;
-constexpr int NDW = NPRIME + 14 * NSTEP;
+constexpr int ndw(int nstep) { return NPRIME + 14 * nstep; }
 
 // The window holds what the taps multiply: bf16 -> the two channels unpacked to fp32 (shift / mask, two instructions per
 // dword); f16 -> the packed dword itself, and each tap is ONE v_fma_mix_f32 that takes its half straight out of it (the
@@ -213,7 +221,7 @@ __device__ __forceinline__ unsigned raw_dword(const unsigned char* smem, int raw
 
 // where pixel s of a lane's run writes its result: base + s * A_STR (the offset folds into the ds_write), or one of the NT
 // explicit addresses of the run's last steps (see OOB0 in the kernel)
-template <int NT>
+template <int NT, int NSTEP>
 struct AwAddr {
     int base;
     int dump;                       // the lane's slot in row 80
@@ -227,7 +235,7 @@ struct AwAddr {
     }
 };
 
-template <typename T, bool RELU, int PW, int KP, int M, typename AW>
+template <typename T, bool RELU, int PW, int KP, int NSTEP, int M, typename AW>
 __device__ __forceinline__ void dw_op(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const AW& aw) {
     if constexpr (M < 3) {
 #pragma unroll
@@ -262,17 +270,17 @@ __device__ __forceinline__ void dw_op(DwState<T>& st, unsigned char* smem, int r
     }
 }
 
-template <typename T, bool RELU, int PW, int KP, int LO, int HI, typename AW>
+template <typename T, bool RELU, int PW, int KP, int NSTEP, int LO, int HI, typename AW>
 __device__ __forceinline__ void dw_ops(DwState<T>& st, unsigned char* smem, int raw_addr, int tap_addr, const AW& aw) {
     if constexpr (LO < HI) {
-        dw_op<T, RELU, PW, KP, LO>(st, smem, raw_addr, tap_addr, aw);
-        dw_ops<T, RELU, PW, KP, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
+        dw_op<T, RELU, PW, KP, NSTEP, LO>(st, smem, raw_addr, tap_addr, aw);
+        dw_ops<T, RELU, PW, KP, NSTEP, LO + 1, HI>(st, smem, raw_addr, tap_addr, aw);
     }
 }
 
-// Micro-operations issued before MFMA slot q of a chunk (NSLOTQ = 60 MFMAs per wave): the taps and the first columns go
-// out with the first MFMAs, their unpacking waits a few slots (an LDS round trip), the pixels are spread over the rest.
-constexpr int NSLOTQ = 2 * MF * RN;
+// Micro-operations issued before MFMA slot q of a chunk of NSLOTQ MFMAs per wave (60, or 40): the taps and the first columns
+// go out with the first MFMAs, their unpacking waits a few slots (an LDS round trip), the pixels are spread over the rest.
+template <int NSLOTQ, int NDW>
 constexpr int dw_before(int q) {
     if (q <= 0) return 0;
     if (q < 4) return 2 * q > 6 ? 6 : 2 * q;
@@ -281,7 +289,8 @@ constexpr int dw_before(int q) {
     const int done = NPRIME + ((q - 8) * (NDW - NPRIME) + (NSLOTQ - 10)) / (NSLOTQ - 9);
     return done > NDW ? NDW : done;
 }
-static_assert(dw_before(NSLOTQ) == NDW && dw_before(8) == NPRIME, "micro-operation schedule");
+static_assert(dw_before<60, ndw(5)>(60) == ndw(5) && dw_before<60, ndw(5)>(8) == NPRIME, "micro-operation schedule");
+static_assert(dw_before<40, ndw(10)>(40) == ndw(10) && dw_before<40, ndw(10)>(8) == NPRIME, "micro-operation schedule");
 
 // The MFMA as inline asm with the accumulator tied in place in the accumulator file ("+a"): written through the builtin,
 // hipcc gives every v_mfma_f32_16x16x32_bf16 of this loop a destination other than its C operand and pays for it with
@@ -329,10 +338,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // RES: the layer has a residual input (compile time: the epilogue's loads are then branch-free)
-template <typename T, bool RELU, bool RES, typename G, int KIN>
+template <typename T, bool RELU, bool RES, typename G, int KIN, int NOUT = 736>
 __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams p) {
     if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int KP = KPlan<KIN>::KP, KST = KPlan<KIN>::KST, NCH = KPlan<KIN>::NCH, LASTK = KPlan<KIN>::LASTK;
+    constexpr int NP = NPlan<NOUT>::NP, RN = NPlan<NOUT>::RN, NFT = NPlan<NOUT>::NFT, CPW = NPlan<NOUT>::CPW;
+    constexpr int MT = G::MT, MF = G::MF, A_BYTES = G::A_BYTES, NSTEP = G::NSTEP, NDW = ndw(NSTEP), NSLOTQ = 2 * MF * RN;
+    static_assert(9 * KP * 4 <= G::TAPS_BYTES && NFT * 16 * 4 <= G::SB_HALF && (!RES || NOUT == 736), "tables, residual");
     static_assert(!RES || NRES <= NCH - 2, "the residual prefetch needs one loop iteration of the tile's own per instruction");
     constexpr int IW = G::IW, IH = G::IH, TR = G::TR, TPI = G::TPI, PW = G::PW, NSLOT = G::NSLOT, HPW = G::HPW;
     constexpr int RAW_BYTES = G::RAW_BYTES, OFF_RAW = G::OFF_RAW, OFF_A = G::OFF_A, OFF_TAPS = G::OFF_TAPS, OFF_SB = G::OFF_SB;
@@ -456,8 +468,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             dma16(p.dw, (unsigned)byte, lds0 + OFF_TAPS + j * 1024, __builtin_amdgcn_ballot_w64(byte < 9 * KP * 4));
         }
         const int k3 = wave < 3 ? wave : wave - 3;              // waves 0..2: 1 KiB of scale each, waves 3..5: of bias
-        dma16(wave < 3 ? p.scale : p.bias, (unsigned)(k3 * 1024 + lane * 16), lds0 + OFF_SB + (wave < 3 ? 0 : 3072) + k3 * 1024,
-              __builtin_amdgcn_ballot_w64(wave < 6));
+        dma16(wave < 3 ? p.scale : p.bias, (unsigned)(k3 * 1024 + lane * 16), lds0 + OFF_SB + (wave < 3 ? 0 : G::SB_HALF) + k3 * 1024,
+              __builtin_amdgcn_ballot_w64(wave < 6 && k3 * 1024 + lane * 16 < NFT * 16 * 4));
     }
     uint4 bq[RN];
 #pragma unroll
@@ -483,11 +495,11 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     WSTAMP(3);
     {   // D(0) of the first tile: nothing to overlap it with
         DwState<T> st;
-        AwAddr<NSTEP - OOB0> aw0;
+        AwAddr<NSTEP - OOB0, NSTEP> aw0;
         aw0.base = opaque(awb) + OFF_A;
         aw0.dump = opaque(((tap_lane - OFF_TAPS) >> 1) + (OFF_A + MT * A_STR));
         aw0.last = last_run;
-        dw_ops<T, RELU, PW, KP, 0, NDW>(st, smem, opaque(opaque(raw_lane) + OFF_RAW), opaque(tap_lane), aw0);
+        dw_ops<T, RELU, PW, KP, NSTEP, 0, NDW>(st, smem, opaque(opaque(raw_lane) + OFF_RAW), opaque(tap_lane), aw0);
     }
     WSTAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // halo chunk 1
@@ -531,7 +543,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         // buffer and use; the halo image's base lies beyond the 16-bit immediate: one add, opaque again
         const int a_cur = opaque(a_lane) + (OFF_A + CUR * A_BYTES);
         const int raw_addr = opaque(opaque(raw_lane) + (OFF_RAW + NXT * RAW_BYTES));
-        AwAddr<NSTEP - OOB0> awn;
+        AwAddr<NSTEP - OOB0, NSTEP> awn;
         awn.base = opaque(awb) + (OFF_A + NXT * A_BYTES);
         awn.dump = opaque(((opaque(tap_lane) - OFF_TAPS) >> 1) + (OFF_A + NXT * A_BYTES + MT * A_STR));   // cp * 4 + row 80
         awn.last = last_run;
@@ -549,8 +561,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                 for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR);
             }
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
-            if constexpr (DMODE == 1) dw_ops<T, RELU, PW, KP, dw_before(Q), dw_before(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
-            if constexpr (DMODE == 2) dw_ops<T, RELU, PW, KP, dw_before(2 * Q), dw_before(2 * Q + 2)>(st, smem, raw_addr, tap_addr, awn);
+            if constexpr (DMODE == 1) dw_ops<T, RELU, PW, KP, NSTEP, dw_before<NSLOTQ, NDW>(Q), dw_before<NSLOTQ, NDW>(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
+            if constexpr (DMODE == 2) dw_ops<T, RELU, PW, KP, NSTEP, dw_before<NSLOTQ, NDW>(2 * Q), dw_before<NSLOTQ, NDW>(2 * Q + 2)>(st, smem, raw_addr, tap_addr, awn);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
             if constexpr (FIRST && D == 0) mfma16_first<T>(acc[I][J], bq[J], a[I]);
@@ -600,11 +612,18 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         // The last MFMAs have to have written their accumulators before anything reads them (see mfma16), and hipcc must not
         // move an accumulator read up in front of these wait states: every tile is an operand of one of the two statements
         // (an asm statement takes 30 operands; a tied one counts twice).
+        static_assert((MF == 5 && RN == 6) || (MF == 10 && RN == 2), "operand lists below");
+        if constexpr (RN == 6) {
 #define BQ_ACC_ROW(i) "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5])
-        static_assert(MF == 5 && RN == 6, "operand lists below");
-        asm volatile("s_nop 15\n\ts_nop 15" : BQ_ACC_ROW(0), BQ_ACC_ROW(1), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]));
-        asm volatile("" : "+a"(acc[2][3]), "+a"(acc[2][4]), "+a"(acc[2][5]), BQ_ACC_ROW(3), BQ_ACC_ROW(4));
+            asm volatile("s_nop 15\n\ts_nop 15" : BQ_ACC_ROW(0), BQ_ACC_ROW(1), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]));
+            asm volatile("" : "+a"(acc[2][3]), "+a"(acc[2][4]), "+a"(acc[2][5]), BQ_ACC_ROW(3), BQ_ACC_ROW(4));
 #undef BQ_ACC_ROW
+        } else {
+#define BQ_ACC_ROW(i) "+a"(acc[i][0]), "+a"(acc[i][1])
+            asm volatile("s_nop 15\n\ts_nop 15" : BQ_ACC_ROW(0), BQ_ACC_ROW(1), BQ_ACC_ROW(2), BQ_ACC_ROW(3), BQ_ACC_ROW(4), BQ_ACC_ROW(5), BQ_ACC_ROW(6));
+            asm volatile("" : BQ_ACC_ROW(7), BQ_ACC_ROW(8), BQ_ACC_ROW(MF - 1));
+#undef BQ_ACC_ROW
+        }
         WSTAMP(20);
         // ---- epilogue: folded BN (+ residual) (+ ReLU), 16-bit, straight from the accumulators to HBM -----------------
         {
@@ -618,7 +637,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             // issued BEHIND a store cannot be consumed before that: every load of the epilogue is issued before its first
             // store.  Residual rows 0..31 are already in LDS (copied under the K loop), rows 32..79 (row fragments 2-4)
             // are fetched now, 9 x 16 bytes per lane, and land while fragments 0 and 1 are finished.
-            uint4 rg[MF - 2][RN / 2];
+            uint4 rg[RES ? MF - 2 : 1][RES ? RN / 2 : 1];
             if constexpr (has_res) {
                 const unsigned q2 = ch0 + 2 * 32 < NP ? 128u : 0u;   // wave 7's last pair is channel padding: any valid address
 #pragma unroll
@@ -643,8 +662,8 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                     const int sbq = opaque(sb_lane + q * 128);
                     const float4 s0 = *reinterpret_cast<const float4*>(smem + sbq);
                     const float4 s1 = *reinterpret_cast<const float4*>(smem + sbq + 16);
-                    const float4 b0 = *reinterpret_cast<const float4*>(smem + sbq + 3072);
-                    const float4 b1 = *reinterpret_cast<const float4*>(smem + sbq + 3072 + 16);
+                    const float4 b0 = *reinterpret_cast<const float4*>(smem + sbq + G::SB_HALF);
+                    const float4 b1 = *reinterpret_cast<const float4*>(smem + sbq + G::SB_HALF + 16);
                     const int row = i * 16 + er16;
                     // the accumulators are copied out HERE, tile by tile (volatile: hipcc otherwise copies the 40 registers of a
                     // pair, or all 120, out up front and spills around them)
@@ -693,14 +712,18 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
 
 using G19 = Geo<19, 4>;     // blocks 5-12 and block13_sepconv1: 5 tiles of 4 (the last: 3) rows per image
 using G37 = Geo<37, 2>;     // block4_sepconv2: 19 tiles of 2 (the last: 1) rows per image
+using G74 = Geo<74, 2, 256, 256>;   // block3_sepconv2 (256 -> 256): 37 tiles of 2 rows = 148 pixels, 160 MFMA rows
 
 // The kernel forms byte offsets into the activation tensors in 32 bits: n * H * W * 736 * 2 must stay below 2^32
 // (n < 8 085 images at 19x19, n < 2 132 at 37x37 -- a larger batch falls back to the pipelined kernel).
-// Instances: K = 736 (728 -> 728) on 19x19 and 37x37 maps, K = 256 (block4_sepconv1: 256 -> 728) on 37x37 maps.
+// Instances: K = 736 (728 -> 728) on 19x19 and 37x37 maps, K = 256 (block4_sepconv1: 256 -> 728) on 37x37 maps, and
+// 256 -> 256 on 74x74 maps (block3_sepconv2: no ReLU in front, no residual input).
 bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo, long long M, bool residual) {
-    const bool shape = (K == 736 && (W == G19::IW || W == G37::IW)) || (K == 256 && W == G37::IW && !residual);
-    return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && nfp * 2 == NFT && H == W && shape &&
-           Nstore == NP && ldi == K && ldo == NP && M > 0 && M % (H * W) == 0 && M * NP * 2 < (1ll << 32);
+    const bool wide = Nstore == 736 && nfp * 2 == NPlan<736>::NFT &&
+                      ((K == 736 && (W == G19::IW || (W == G37::IW && !residual))) || (K == 256 && W == G37::IW && !residual));
+    const bool b3 = Nstore == 256 && nfp * 2 == NPlan<256>::NFT && K == 256 && W == G74::IW && !residual && prod == PROD_DW;
+    return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && H == W && (wide || b3) &&
+           ldi == K && ldo == Nstore && M > 0 && M % (H * W) == 0 && M * Nstore * 2 < (1ll << 32);
 }
 
 // wp16: the layer's pointwise weights in 16x16x32 fragment order, n-fragment pairs interleaved (blob entry "<layer>/wp16")
@@ -721,19 +744,24 @@ int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp
     const bool relu_in = prod == PROD_DW_RELU;
 #define BQ_WIDE_SET(T, RES) sepconv_wide_kernel<T, false, RES, G19, 736>, sepconv_wide_kernel<T, true, RES, G19, 736>, \
                             sepconv_wide_kernel<T, false, RES, G37, 736>, sepconv_wide_kernel<T, true, RES, G37, 736>
-    void (*const kerns[20])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
+    void (*const kerns[22])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
                                                  BQ_WIDE_SET(bf16_t, true), BQ_WIDE_SET(f16_t, true),
                                                  sepconv_wide_kernel<bf16_t, false, false, G37, 256>,
                                                  sepconv_wide_kernel<bf16_t, true, false, G37, 256>,
                                                  sepconv_wide_kernel<f16_t, false, false, G37, 256>,
-                                                 sepconv_wide_kernel<f16_t, true, false, G37, 256>};
+                                                 sepconv_wide_kernel<f16_t, true, false, G37, 256>,
+                                                 sepconv_wide_kernel<bf16_t, false, false, G74, 256, 256>,
+                                                 sepconv_wide_kernel<f16_t, false, false, G74, 256, 256>};
 #undef BQ_WIDE_SET
-    const int ki = g.K == 256 ? 16 + (dtype == 2 ? 2 : 0) + (relu_in ? 1 : 0)
+    const bool b3 = g.W == G74::IW;
+    const int ki = b3 ? 20 + (dtype == 2 ? 1 : 0)
+                 : g.K == 256 ? 16 + (dtype == 2 ? 2 : 0) + (relu_in ? 1 : 0)
                               : (p.residual ? 8 : 0) + (dtype == 2 ? 4 : 0) + (big ? 2 : 0) + (relu_in ? 1 : 0);
     auto kern = kerns[ki];
-    const int tpi = big ? G37::TPI : G19::TPI;
-    const int lds = big ? G37::LDS_BYTES : G19::LDS_BYTES;
-    static BqLdsAttr attr[20];
+    const int tpi = b3 ? G74::TPI : big ? G37::TPI : G19::TPI;
+    const bool res = p.residual != nullptr;
+    const int lds = b3 ? G74::lds_bytes(false) : big ? G37::lds_bytes(res) : G19::lds_bytes(res);
+    static BqLdsAttr attr[22];
     if (const int e = attr[ki].ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     // one persistent workgroup per CU (a multiple of 8: every workgroup stays inside its XCD's run of tiles)
     const int ntiles = p.n * tpi;
