@@ -40,6 +40,9 @@
 #ifndef WIDE_ABLATE
 #define WIDE_ABLATE 0
 #endif
+#ifndef WIDE_TAP_ASM
+#define WIDE_TAP_ASM 0
+#endif
 
 namespace {
 using namespace bqk;
@@ -201,6 +204,11 @@ __device__ __forceinline__ typename Win<T>::type unpack2(unsigned d) {
 template <typename T, bool FIRST>
 __device__ __forceinline__ void tap2(float& o0, float& o1, const float2& tw, const typename Win<T>::type& w) {
     if constexpr (H16<T>::F16) {
+        // plain C on purpose: hipcc selects v_fma_mix_f32 for fma(fpext(half of a dword), f32, f32) by itself, and -- unlike
+        // behind an inline-asm v_fma_mix -- does not pad the next instruction that reads the result with an s_nop (it takes
+        // every asm result for a partial-register write: one s_nop per tap, 70 per chunk in the 10-pixel runs of the 74x74
+        // instance)
+#if WIDE_TAP_ASM
         if constexpr (FIRST) {
             asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(o0) : "v"(w), "v"(tw.x));
             asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(o1) : "v"(w), "v"(tw.y));
@@ -208,6 +216,12 @@ __device__ __forceinline__ void tap2(float& o0, float& o1, const float2& tw, con
             o0 = H16<T>::fma_lo(w, tw.x, o0);
             o1 = H16<T>::fma_hi(w, tw.y, o1);
         }
+#else
+        typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+        const f16x2v h = __builtin_bit_cast(f16x2v, w);
+        o0 = __builtin_fmaf((float)h.x, tw.x, FIRST ? 0.f : o0);
+        o1 = __builtin_fmaf((float)h.y, tw.y, FIRST ? 0.f : o1);
+#endif
     } else {
         o0 = fmaf(tw.x, w.x, FIRST ? 0.f : o0);
         o1 = fmaf(tw.y, w.y, FIRST ? 0.f : o1);
@@ -320,6 +334,20 @@ __device__ __forceinline__ void mfma16_first(f32x4v& acc, const uint4& b, const 
     else
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0"
                      : "=a"(acc) : "v"(__builtin_bit_cast(u32x4, b)), "v"(__builtin_bit_cast(u32x4, a)));
+}
+
+// The same with the weight fragment in the accumulator file (the narrow instance keeps a whole chunk's fragments there, see
+// BPRE in the kernel)
+typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+template <typename T, bool FIRST>
+__device__ __forceinline__ void mfma16_ab(f32x4v& acc, const u32x4a& b, const uint4& a) {
+    if constexpr (H16<T>::F16) {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc) : "a"(b), "v"(__builtin_bit_cast(u32x4a, a)));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(b), "v"(__builtin_bit_cast(u32x4a, a)));
+    } else {
+        if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(b), "v"(__builtin_bit_cast(u32x4a, a)));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(b), "v"(__builtin_bit_cast(u32x4a, a)));
+    }
 }
 
 // An LDS base address the compiler must take as it is: offsets beyond the 16-bit immediate of ds_* would otherwise be
@@ -471,9 +499,34 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         dma16(wave < 3 ? p.scale : p.bias, (unsigned)(k3 * 1024 + lane * 16), lds0 + OFF_SB + (wave < 3 ? 0 : G::SB_HALF) + k3 * 1024,
               __builtin_amdgcn_ballot_w64(wave < 6 && k3 * 1024 + lane * 16 < NFT * 16 * 4));
     }
+    // BPRE (the narrow instance, 2 n-fragments per wave): ALL the weight fragments of a chunk (2 k-steps x 2) are fetched one
+    // chunk ahead, at the top of the chunk together with the halo DMA, into the accumulator file (48 of its registers are
+    // free here) by asm loads, and the only vector-memory wait of a chunk is the one that closes it.  Why: vmcnt retires in
+    // order, so a fragment load issued BEHIND the halo DMA cannot be consumed before that DMA -- an HBM round trip of 3.3 k
+    // cycles at this instance's 38 KB per chunk and workgroup -- has landed, and with fragments reloaded k-step by k-step
+    // (the wide instances' scheme: no registers for more) every chunk's MFMAs and the depthwise stage interleaved with
+    // them waited that trip out: 5.4-6.7 k cycles per chunk where DMA alone takes 3.3 k and the instructions ~3.5 k.
+    constexpr bool BPRE = RN == 2;
     uint4 bq[RN];
+    u32x4a bb[2][2][RN];
+    auto load_bb = [&](int ks, u32x4a (&dst)[RN]) {
+        const unsigned long long b = (unsigned long long)(wbase + (size_t)ks * (NFT * 1024));
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+        // (the base may just have been written by v_readfirstlane: a vector-memory instruction reads an SGPR 5 wait states
+        // behind a VALU write of it, and hipcc does not pad in front of an asm statement)
+        asm volatile("s_nop 4" :: "s"(sb));
 #pragma unroll
-    for (int j = 0; j < RN; ++j) bq[j] = load_b(0, j);
+        for (int j = 0; j < RN; ++j)
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst[j]) : "v"(voff), "s"(sb), "n"(j * 1024) : "memory");
+    };
+    if constexpr (BPRE) {
+        load_bb(0, bb[0][0]);
+        load_bb(1, bb[0][1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bq[j] = load_b(0, j);
+    }
     halo_dma(1, 1);
     // zero what the DMA never writes: pad columns and slots past the image once and for all, map rows outside the map
     // for this tile (both halo buffers)
@@ -538,6 +591,11 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             }
         }
         if constexpr (has_res) { if (c < NRES) res_dma(c); }
+        if constexpr (BPRE) {                                   // the next chunk's fragments (past the end: the next tile's first chunk)
+            const int kn = (c + 1 < NCH ? c + 1 : 0) * (KC / 32);
+            load_bb(kn, bb[NXT][0]);
+            load_bb(kn + 1, bb[NXT][1]);
+        }
         // LDS addresses: the per-lane constant goes through opaque() FIRST, so that base + constant is formed here (or
         // folded into the instruction's immediate) instead of being hoisted out of the tile loop into one register per
         // buffer and use; the halo image's base lies beyond the 16-bit immediate: one add, opaque again
@@ -565,11 +623,12 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             if constexpr (DMODE == 2) dw_ops<T, RELU, PW, KP, NSTEP, dw_before<NSLOTQ, NDW>(2 * Q), dw_before<NSLOTQ, NDW>(2 * Q + 2)>(st, smem, raw_addr, tap_addr, awn);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
-            if constexpr (FIRST && D == 0) mfma16_first<T>(acc[I][J], bq[J], a[I]);
+            if constexpr (BPRE) mfma16_ab<T, FIRST && D == 0>(acc[I][J], bb[CUR][D][J], a[I]);
+            else if constexpr (FIRST && D == 0) mfma16_first<T>(acc[I][J], bq[J], a[I]);
             else mfma16<T>(acc[I][J], bq[J], a[I]);
 #endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 1))          // 1 = weights stay in registers
-            if constexpr (I == MF - 1) {                        // the fragment is dead: fetch it for the next k-step
+            if constexpr (I == MF - 1 && !BPRE) {               // the fragment is dead: fetch it for the next k-step
                 const int nx = ks0 + D + 1;
                 bq[J] = load_b(nx < KST ? nx : 0, J);           // past the end: k-step 0, the next tile's first
             }
@@ -579,7 +638,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             __builtin_amdgcn_sched_barrier(0);                  // the source order of this loop IS the schedule
         });
         WSTAMP(6 + c);
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(RN) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(BPRE ? 0 : RN) : "memory");
         __syncthreads();
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;

@@ -7,7 +7,7 @@ run() {
   timeout 300 python bench.py --steps 60 --warmup 5 --streams 1 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('  ms_per_step %.4f' % d['ms_per_step'], ' '.join('%s=%.4f' % (k['name'].replace('sepconv_',''), k['ms_per_launch']) for k in d['kernels'] if 'n728' in k['name']))
+print('  ms_per_step %.4f' % d['ms_per_step'], ' '.join('%s=%.4f' % (k['name'].replace('sepconv_',''), k['ms_per_launch']) for k in d['kernels'] if 'n728' in k['name'] or 'k256_n256' in k['name']))
 "
 }
 echo "== tree build"; run; run
