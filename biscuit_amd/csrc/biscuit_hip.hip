@@ -234,7 +234,10 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
         if (a.prod == PROD_IM2COL && L.cin == 32 && L.cout == 64) kind = 0;
         else if (a.prod == PROD_DW && L.cin == 64 && L.cout == 128) kind = 1;
         else if (a.prod == PROD_DW && L.cin == 128 && L.cout == 128) kind = 2;
-        else if (a.prod == PROD_DW_RELU && L.cin == 128 && L.cout == 256) kind = 3;
+        else if (a.prod == PROD_DW_RELU && L.cin == 128 && L.cout == 256 &&
+                 !(L.wp16 && a.H == a.Hi && a.W == a.Wi && nsplit == 1 &&
+                   wide_supported(dtype, a.prod, L.nfp, a.H, a.W, L.kpad, a.ldo, a.ldi, a.ldo, p.M, false)))
+            kind = 3;               // (block3_sepconv1: the wide kernel's 74x74 instance when its weights are there)
         if (kind >= 0 && ((tile_mask >> kind) & 1)) {
             const int e = launch_tile_conv(dtype, kind, a.in, L.wp, L.dw, L.scale, L.bias, a.out, a.n, a.H, a.W, a.Hi, a.Wi,
                                            a.relu, c->num_cus, s);

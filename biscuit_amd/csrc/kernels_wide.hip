@@ -64,7 +64,7 @@ struct KPlan {
     static constexpr int KST = KIN / 32;                 // k-steps of 32 (one v_mfma_f32_16x16x32 deep)
     static constexpr int NCH = (KIN + 63) / 64;          // chunks
     static constexpr int LASTK = (KIN - (NCH - 1) * 64) / 32;   // k-steps of the last chunk: 1 or 2
-    static_assert(KIN % 32 == 0 && NCH % 2 == 0 && NCH >= 4 && (LASTK == 1 || LASTK == 2), "chunk plan");
+    static_assert(KIN % 32 == 0 && NCH % 2 == 0 && NCH >= 2 && (LASTK == 1 || LASTK == 2), "chunk plan");
 };
 constexpr int KC = 64;                  // channels per chunk
 constexpr int A_STR = KC * 2 + 32;      // 160 B = 10 slots of 16 B: the 16x16x32 fragment read (lane -> row l&15, 16-byte
@@ -653,15 +653,18 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     for (;;) {
         has_next = vb + nwg < ntiles;
         WSTAMP(18);
-        chunk(I0{}, K2{}, I1{}, std::true_type{}, 0);
-        chunk(I1{}, K2{}, I1{}, std::false_type{}, 1);
-        for (int c = 2; c < NCH - 2; c += 2) {
-            chunk(I0{}, K2{}, I1{}, std::false_type{}, c);
-            chunk(I1{}, K2{}, I1{}, std::false_type{}, c + 1);
+        if constexpr (NCH > 2) {
+            chunk(I0{}, K2{}, I1{}, std::true_type{}, 0);
+            chunk(I1{}, K2{}, I1{}, std::false_type{}, 1);
+            for (int c = 2; c < NCH - 2; c += 2) {
+                chunk(I0{}, K2{}, I1{}, std::false_type{}, c);
+                chunk(I1{}, K2{}, I1{}, std::false_type{}, c + 1);
+            }
         }
         const int m0 = t_m0, npix = t_npix;                      // of the tile whose accumulators are being finished
         if (has_next) tile_setup(vb + nwg, t_m0, t_npix);        // from here on the halo constants describe the next tile
-        chunk(I0{}, K2{}, I1{}, std::false_type{}, NCH - 2);
+        // (a plan of two chunks -- 128 input channels -- has nothing in front of these two: the first one starts the accumulators)
+        chunk(I0{}, K2{}, I1{}, std::integral_constant<bool, NCH == 2>{}, NCH - 2);
         // (one instance whether or not a tile follows: two copies of the chunk under a branch make hipcc give the
         // accumulator tiles different registers on the two paths and move them between -- a workgroup's very last tile
         // builds an A chunk nobody reads)
@@ -771,7 +774,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
 
 using G19 = Geo<19, 4>;     // blocks 5-12 and block13_sepconv1: 5 tiles of 4 (the last: 3) rows per image
 using G37 = Geo<37, 2>;     // block4_sepconv2: 19 tiles of 2 (the last: 1) rows per image
-using G74 = Geo<74, 2, 256, 256>;   // block3_sepconv2 (256 -> 256): 37 tiles of 2 rows = 148 pixels, 160 MFMA rows
+using G74 = Geo<74, 2, 256, 256>;   // block3_sepconv1 / 2 (128 / 256 -> 256): 37 tiles of 2 rows = 148 pixels, 160 MFMA rows
 
 // The kernel forms byte offsets into the activation tensors in 32 bits: n * H * W * 736 * 2 must stay below 2^32
 // (n < 8 085 images at 19x19, n < 2 132 at 37x37 -- a larger batch falls back to the pipelined kernel).
@@ -780,7 +783,9 @@ using G74 = Geo<74, 2, 256, 256>;   // block3_sepconv2 (256 -> 256): 37 tiles of
 bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo, long long M, bool residual) {
     const bool wide = Nstore == 736 && nfp * 2 == NPlan<736>::NFT &&
                       ((K == 736 && (W == G19::IW || (W == G37::IW && !residual))) || (K == 256 && W == G37::IW && !residual));
-    const bool b3 = Nstore == 256 && nfp * 2 == NPlan<256>::NFT && K == 256 && W == G74::IW && !residual && prod == PROD_DW;
+    // block 3: 256 -> 256 behind the ReLU of the layer before, 128 -> 256 with its own ReLU in front
+    const bool b3 = Nstore == 256 && nfp * 2 == NPlan<256>::NFT && W == G74::IW && !residual &&
+                    ((K == 256 && prod == PROD_DW) || (K == 128 && prod == PROD_DW_RELU));
     return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && H == W && (wide || b3) &&
            ldi == K && ldo == Nstore && M > 0 && M % (H * W) == 0 && M * Nstore * 2 < (1ll << 32);
 }
@@ -803,24 +808,26 @@ int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp
     const bool relu_in = prod == PROD_DW_RELU;
 #define BQ_WIDE_SET(T, RES) sepconv_wide_kernel<T, false, RES, G19, 736>, sepconv_wide_kernel<T, true, RES, G19, 736>, \
                             sepconv_wide_kernel<T, false, RES, G37, 736>, sepconv_wide_kernel<T, true, RES, G37, 736>
-    void (*const kerns[22])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
+    void (*const kerns[24])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
                                                  BQ_WIDE_SET(bf16_t, true), BQ_WIDE_SET(f16_t, true),
                                                  sepconv_wide_kernel<bf16_t, false, false, G37, 256>,
                                                  sepconv_wide_kernel<bf16_t, true, false, G37, 256>,
                                                  sepconv_wide_kernel<f16_t, false, false, G37, 256>,
                                                  sepconv_wide_kernel<f16_t, true, false, G37, 256>,
                                                  sepconv_wide_kernel<bf16_t, false, false, G74, 256, 256>,
-                                                 sepconv_wide_kernel<f16_t, false, false, G74, 256, 256>};
+                                                 sepconv_wide_kernel<f16_t, false, false, G74, 256, 256>,
+                                                 sepconv_wide_kernel<bf16_t, true, false, G74, 128, 256>,
+                                                 sepconv_wide_kernel<f16_t, true, false, G74, 128, 256>};
 #undef BQ_WIDE_SET
     const bool b3 = g.W == G74::IW;
-    const int ki = b3 ? 20 + (dtype == 2 ? 1 : 0)
+    const int ki = b3 ? 20 + (g.K == 128 ? 2 : 0) + (dtype == 2 ? 1 : 0)
                  : g.K == 256 ? 16 + (dtype == 2 ? 2 : 0) + (relu_in ? 1 : 0)
                               : (p.residual ? 8 : 0) + (dtype == 2 ? 4 : 0) + (big ? 2 : 0) + (relu_in ? 1 : 0);
     auto kern = kerns[ki];
     const int tpi = b3 ? G74::TPI : big ? G37::TPI : G19::TPI;
     const bool res = p.residual != nullptr;
     const int lds = b3 ? G74::lds_bytes(false) : big ? G37::lds_bytes(res) : G19::lds_bytes(res);
-    static BqLdsAttr attr[22];
+    static BqLdsAttr attr[24];
     if (const int e = attr[ki].ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     // one persistent workgroup per CU (a multiple of 8: every workgroup stays inside its XCD's run of tiles)
     const int ntiles = p.n * tpi;
