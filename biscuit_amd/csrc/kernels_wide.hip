@@ -1,5 +1,7 @@
-// SeparableConv2D with 728 output channels: the 25 layers 728 -> 728 on 19x19 maps (~75 % of the network's FLOPs),
-// block4_sepconv2 (728 -> 728, 37x37) and block4_sepconv1 (256 -> 728, 37x37); 16-bit storage (bf16 or f16).
+// SeparableConv2D from block 3 to block 13: the 25 layers 728 -> 728 on 19x19 maps (~75 % of the network's FLOPs),
+// block4_sepconv2 (728 -> 728, 37x37), block4_sepconv1 (256 -> 728, 37x37) and block 3's two layers (128 / 256 -> 256,
+// 74x74: the narrow instance, see NPlan / BPRE); 16-bit storage (bf16 or f16).  The description is the 19x19 instance's; the
+// others differ in the constants Geo, KPlan and NPlan derive (rows per tile, chunks, fragments per wave).
 //
 // One PERSISTENT workgroup per CU (round 3) = 8 waves (two per SIMD, 256 registers each).  It walks image-aligned tiles
 // of 4 map rows (76 pixels, padded to 80 MFMA rows; the 5th tile of an image has 3 rows: 1 280 tiles per batch of 256,
