@@ -307,6 +307,7 @@ constexpr int dw_before(int q) {
 }
 static_assert(dw_before<60, ndw(5)>(60) == ndw(5) && dw_before<60, ndw(5)>(8) == NPRIME, "micro-operation schedule");
 static_assert(dw_before<40, ndw(10)>(40) == ndw(10) && dw_before<40, ndw(10)>(8) == NPRIME, "micro-operation schedule");
+static_assert(dw_before<40, ndw(5)>(40) == ndw(5) && dw_before<20, ndw(5)>(20) == ndw(5), "micro-operation schedule");
 
 // The MFMA as inline asm with the accumulator tied in place in the accumulator file ("+a"): written through the builtin,
 // hipcc gives every v_mfma_f32_16x16x32_bf16 of this loop a destination other than its C operand and pays for it with
@@ -368,13 +369,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // RES: the layer has a residual input (compile time: the epilogue's loads are then branch-free)
-template <typename T, bool RELU, bool RES, typename G, int KIN, int NOUT = 736>
+// LDO / NFTOT: row stride of the output and n-fragments of the layer's weight array when the launch produces a column SLICE
+// of a wider layer (block13_sepconv2, 1 024 outputs = two launches of 512: the launcher offsets the pointers)
+template <typename T, bool RELU, bool RES, typename G, int KIN, int NOUT = 736, int LDO = NOUT, int NFTOT = NPlan<NOUT>::NFT>
 __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams p) {
     if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int KP = KPlan<KIN>::KP, KST = KPlan<KIN>::KST, NCH = KPlan<KIN>::NCH, LASTK = KPlan<KIN>::LASTK;
     constexpr int NP = NPlan<NOUT>::NP, RN = NPlan<NOUT>::RN, NFT = NPlan<NOUT>::NFT, CPW = NPlan<NOUT>::CPW;
     constexpr int MT = G::MT, MF = G::MF, A_BYTES = G::A_BYTES, NSTEP = G::NSTEP, NDW = ndw(NSTEP), NSLOTQ = 2 * MF * RN;
-    static_assert(9 * KP * 4 <= G::TAPS_BYTES && NFT * 16 * 4 <= G::SB_HALF && (!RES || NOUT == 736), "tables, residual");
+    static_assert(9 * KP * 4 <= G::TAPS_BYTES && NFT * 16 * 4 <= G::SB_HALF && (!RES || (NOUT == 736 && LDO == NOUT)), "tables, residual");
     static_assert(!RES || NRES <= NCH - 2, "the residual prefetch needs one loop iteration of the tile's own per instruction");
     constexpr int IW = G::IW, IH = G::IH, TR = G::TR, TPI = G::TPI, PW = G::PW, NSLOT = G::NSLOT, HPW = G::HPW;
     constexpr int RAW_BYTES = G::RAW_BYTES, OFF_RAW = G::OFF_RAW, OFF_A = G::OFF_A, OFF_TAPS = G::OFF_TAPS, OFF_SB = G::OFF_SB;
@@ -435,7 +438,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     auto load_b = [&](int ks, int j) {
         // the base is uniform: hand it to the compiler as scalars so that the load takes the scalar-base form (no
         // 64-bit vector address arithmetic per fragment)
-        const unsigned long long b = (unsigned long long)(wbase + (size_t)ks * (NFT * 1024) + (j >> 2) * 4096);
+        const unsigned long long b = (unsigned long long)(wbase + (size_t)ks * (NFTOT * 1024) + (j >> 2) * 4096);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
         typedef const __attribute__((address_space(1))) unsigned char* gptr_t;
         gptr_t sb = (gptr_t)(((unsigned long long)hi << 32) | lo);
@@ -512,7 +515,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     uint4 bq[RN];
     u32x4a bb[2][2][RN];
     auto load_bb = [&](int ks, u32x4a (&dst)[RN]) {
-        const unsigned long long b = (unsigned long long)(wbase + (size_t)ks * (NFT * 1024));
+        const unsigned long long b = (unsigned long long)(wbase + (size_t)ks * (NFTOT * 1024));
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
         const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
         // (the base may just have been written by v_readfirstlane: a vector-memory instruction reads an SGPR 5 wait states
@@ -676,8 +679,13 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         // The last MFMAs have to have written their accumulators before anything reads them (see mfma16), and hipcc must not
         // move an accumulator read up in front of these wait states: every tile is an operand of one of the two statements
         // (an asm statement takes 30 operands; a tied one counts twice).
-        static_assert((MF == 5 && RN == 6) || (MF == 10 && RN == 2), "operand lists below");
-        if constexpr (RN == 6) {
+        static_assert((MF == 5 && (RN == 6 || RN == 4)) || (MF == 10 && RN == 2), "operand lists below");
+        if constexpr (RN == 4) {
+#define BQ_ACC_ROW(i) "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][RN - 1])
+            asm volatile("s_nop 15\n\ts_nop 15" : BQ_ACC_ROW(0), BQ_ACC_ROW(1), BQ_ACC_ROW(2));
+            asm volatile("" : BQ_ACC_ROW(3), BQ_ACC_ROW(4));
+#undef BQ_ACC_ROW
+        } else if constexpr (RN == 6) {
 #define BQ_ACC_ROW(i) "+a"(acc[i][0]), "+a"(acc[i][1]), "+a"(acc[i][2]), "+a"(acc[i][3]), "+a"(acc[i][4]), "+a"(acc[i][5])
             asm volatile("s_nop 15\n\ts_nop 15" : BQ_ACC_ROW(0), BQ_ACC_ROW(1), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]));
             asm volatile("" : "+a"(acc[2][3]), "+a"(acc[2][4]), "+a"(acc[2][5]), BQ_ACC_ROW(3), BQ_ACC_ROW(4));
@@ -758,7 +766,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.z) : "v"(o.z), "v"(lo2));
                     asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.w) : "v"(o.w), "v"(lo2));
                     if (row < npix)
-                        *reinterpret_cast<uint4*>(outb + (size_t)((unsigned)(m0 + row) * (unsigned)(NP * 2) + lane_ch + q * 64)) = o;
+                        *reinterpret_cast<uint4*>(outb + (size_t)((unsigned)(m0 + row) * (unsigned)(LDO * 2) + lane_ch + q * 64)) = o;
                     __builtin_amdgcn_sched_barrier(0);          // (or hipcc copies all 120 accumulators out up front)
                 }
             }
@@ -788,7 +796,9 @@ bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstor
     // block 3: 256 -> 256 behind the ReLU of the layer before, 128 -> 256 with its own ReLU in front
     const bool b3 = Nstore == 256 && nfp * 2 == NPlan<256>::NFT && W == G74::IW && !residual &&
                     ((K == 256 && prod == PROD_DW) || (K == 128 && prod == PROD_DW_RELU));
-    return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && H == W && (wide || b3) &&
+    // block13_sepconv2 (728 -> 1 024): two launches of 512 columns each (160 accumulator registers per wave do not exist)
+    const bool b13 = Nstore == 1024 && nfp * 2 == 2 * NPlan<512>::NFT && K == 736 && W == G19::IW && !residual && prod == PROD_DW;
+    return dtype != 0 && (prod == PROD_DW || prod == PROD_DW_RELU) && H == W && (wide || b3 || b13) &&
            ldi == K && ldo == Nstore && M > 0 && M % (H * W) == 0 && M * Nstore * 2 < (1ll << 32);
 }
 
@@ -810,7 +820,7 @@ int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp
     const bool relu_in = prod == PROD_DW_RELU;
 #define BQ_WIDE_SET(T, RES) sepconv_wide_kernel<T, false, RES, G19, 736>, sepconv_wide_kernel<T, true, RES, G19, 736>, \
                             sepconv_wide_kernel<T, false, RES, G37, 736>, sepconv_wide_kernel<T, true, RES, G37, 736>
-    void (*const kerns[24])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
+    void (*const kerns[26])(const WideParams) = {BQ_WIDE_SET(bf16_t, false), BQ_WIDE_SET(f16_t, false),
                                                  BQ_WIDE_SET(bf16_t, true), BQ_WIDE_SET(f16_t, true),
                                                  sepconv_wide_kernel<bf16_t, false, false, G37, 256>,
                                                  sepconv_wide_kernel<bf16_t, true, false, G37, 256>,
@@ -819,17 +829,20 @@ int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp
                                                  sepconv_wide_kernel<bf16_t, false, false, G74, 256, 256>,
                                                  sepconv_wide_kernel<f16_t, false, false, G74, 256, 256>,
                                                  sepconv_wide_kernel<bf16_t, true, false, G74, 128, 256>,
-                                                 sepconv_wide_kernel<f16_t, true, false, G74, 128, 256>};
+                                                 sepconv_wide_kernel<f16_t, true, false, G74, 128, 256>,
+                                                 sepconv_wide_kernel<bf16_t, false, false, G19, 736, 512, 1024, 64>,
+                                                 sepconv_wide_kernel<f16_t, false, false, G19, 736, 512, 1024, 64>};
 #undef BQ_WIDE_SET
-    const bool b3 = g.W == G74::IW;
-    const int ki = b3 ? 20 + (g.K == 128 ? 2 : 0) + (dtype == 2 ? 1 : 0)
+    const bool b3 = g.W == G74::IW, b13 = g.Nstore == 1024;
+    const int ki = b13 ? 24 + (dtype == 2 ? 1 : 0)
+                 : b3 ? 20 + (g.K == 128 ? 2 : 0) + (dtype == 2 ? 1 : 0)
                  : g.K == 256 ? 16 + (dtype == 2 ? 2 : 0) + (relu_in ? 1 : 0)
                               : (p.residual ? 8 : 0) + (dtype == 2 ? 4 : 0) + (big ? 2 : 0) + (relu_in ? 1 : 0);
     auto kern = kerns[ki];
     const int tpi = b3 ? G74::TPI : big ? G37::TPI : G19::TPI;
     const bool res = p.residual != nullptr;
-    const int lds = b3 ? G74::lds_bytes(false) : big ? G37::lds_bytes(res) : G19::lds_bytes(res);
-    static BqLdsAttr attr[24];
+    const int lds = b3 ? G74::lds_bytes(false) : big ? G37::lds_bytes(res) : G19::lds_bytes(res);   // (b13: G19 without a residual)
+    static BqLdsAttr attr[26];
     if (const int e = attr[ki].ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     // one persistent workgroup per CU (a multiple of 8: every workgroup stays inside its XCD's run of tiles)
     const int ntiles = p.n * tpi;
@@ -853,6 +866,11 @@ int launch_sepconv_wide(int dtype, int prod, const GemmParams& g, const void* wp
     }
 #endif
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WN), lds, s, p);
+    if (b13) {                              // the second 512 columns: weights 32 n-fragments on, tables and output 512 channels on
+        p.wp = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(wp16) + (size_t)NPlan<512>::NFT * 1024);
+        p.scale += 512; p.bias += 512; p.out += 512;
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WN), lds, s, p);
+    }
 #ifdef BQ_EXPERIMENTS
     if (state == 1) {
         std::vector<unsigned long long> h(64 * WN * 32 * STAMP_TILES);

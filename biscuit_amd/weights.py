@@ -280,9 +280,10 @@ def pack_fragments32(wkn, kpad, npad):
 def wide_layers():
     """The separable convolutions of kernels_wide.hip (8 waves, 16x16x32 fragment order with interleaved n-fragment pairs):
     the 26 layers 728 -> 728 -- block4_sepconv2 (37x37 maps), blocks 5-12 and block13_sepconv1 (19x19 maps) --,
-    block4_sepconv1 (256 -> 728, 37x37) and block3_sepconv1 / 2 (128 / 256 -> 256, 74x74)."""
+    block4_sepconv1 (256 -> 728, 37x37), block3_sepconv1 / 2 (128 / 256 -> 256, 74x74) and block13_sepconv2 (728 -> 1024,
+    19x19, as two launches of 512 columns)."""
     return (['block3_sepconv1', 'block3_sepconv2', 'block4_sepconv1', 'block4_sepconv2'] +
-            [f'block{b}_sepconv{i}' for b in range(5, 13) for i in (1, 2, 3)] + ['block13_sepconv1'])
+            [f'block{b}_sepconv{i}' for b in range(5, 13) for i in (1, 2, 3)] + ['block13_sepconv1', 'block13_sepconv2'])
 
 
 def fold_bn(w, name):

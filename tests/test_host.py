@@ -152,9 +152,9 @@ def test_blob_directory_roundtrip():
         nm, off, ln = struct.unpack_from('<48sQQ', blob, 16 + 64 * i)
         names[nm.rstrip(b'\0').decode()] = (off, ln)
         assert off % 256 == 0 and off + ln <= len(blob)
-    # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 29 wide layers and the 32x32x16
+    # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 30 wide layers and the 32x32x16
     # copy of the two fused shortcuts (16-bit blobs only)
-    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 29 + 2
+    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 30 + 2
     assert names['block3_res/wp32'][1] == 8 * 8 * 64 * 8 * 2 and names['block2_res/wp32'][1] == 4 * 4 * 64 * 8 * 2
     assert 'block4_res/wp32' not in names and 'block13_res/wp32' not in names
     assert names['block5_sepconv1/wp16'][1] == 23 * 48 * 64 * 8 * 2 and 'block4_sepconv2/wp16' in names
