@@ -590,10 +590,12 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         const int cd = c + 1 < NCH ? c + 1 : 0;                 // chunk the depthwise stage builds
         {
             const int cc = c + 2 < NCH ? c + 2 : c + 2 - NCH;   // chunk the DMA fetches (c >= NCH-2: of the next tile)
+#if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 8))          // timing ablation (wrong results): 8 = no halo DMA in the loop
             if (c + 2 < NCH || has_next) {
                 if (c + 2 >= NCH) halo_zero(CUR);
                 halo_dma(cc, CUR);
             }
+#endif
         }
         if constexpr (has_res) { if (c < NRES) res_dma(c); }
         if constexpr (BPRE) {                                   // the next chunk's fragments (past the end: the next tile's first chunk)
