@@ -74,7 +74,7 @@ def main():
         for (kn, wg), (n, dur) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:16]:
             lines.append(f'| `{kn}` | {wg} | {n} | {dur/n/1e3:.1f} | {dur/1e6:.2f} |')
         # the 728 -> 728 @19x19 layer class = the Geo<19,4> instances with K = 736 (persistent: one workgroup per CU)
-        dom = [(n, dur) for (kn, wg), (n, dur) in acc.items() if 'sepconv_wide_kernel' in kn and 'GeoI19' in kn and kn.rstrip('>').endswith('736')]
+        dom = [(n, dur) for (kn, wg), (n, dur) in acc.items() if 'sepconv_wide_kernel' in kn and 'GeoI19' in kn and ',,,736,736,736,' in kn]
         if dom:
             n = sum(x[0] for x in dom); dur = sum(x[1] for x in dom)
             lines += ['', f'Dominant layer class (sepconv 728->728 @19x19, kernels_wide.hip, all its instances: with / without a '
@@ -110,7 +110,7 @@ def main():
             lines.append(f'| `{kn}` | {f[1] or w[1]} | {f[0]:.0f} | {w[0]:.0f} | {mb:.1f} | {(f[2] or w[2])/1e3:.1f} |')
         lines.append('')
         # the dominant kernel of bench.py (728 -> 728 separable conv at 19x19, n = 256 -> 963 workgroups)
-        dom = [(kn, d) for kn, d in names.items() if 'sepconv_wide_kernel' in kn and 'GeoI19' in kn and kn.split(' [')[0].rstrip('>').endswith('736')]
+        dom = [(kn, d) for kn, d in names.items() if 'sepconv_wide_kernel' in kn and 'GeoI19' in kn and ',,,736,736,736,' in kn]
         if dom:
             import json
             nl = sum((d.get('FETCH_SIZE') or d.get('WRITE_SIZE'))[1] for _, d in dom)
