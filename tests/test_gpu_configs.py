@@ -245,6 +245,34 @@ def test_config5_harness_tfrecords_checkpoint_cli_threshold(tmp_path):
     eng.close(); eng01.close()
 
 
+def test_jpeg_tfrecords_feed_the_same_tiles(tmp_path):
+    """Slideflow's other tile format: JPEG TFRecords through the reader's own baseline decoder (csrc/jpeg_baseline.h) and
+    `evaluate` give exactly what the Pillow-decoded tiles give in memory -- the decoder is held to libjpeg's bytes
+    (tests/test_jpeg.py), so the network sees the same image."""
+    from biscuit_amd import tfrecord as tfr
+    from biscuit_amd.engine import Engine
+    from biscuit_amd.inference import Slide, evaluate, slides_from_tfrecords
+    d = str(tmp_path)
+    n_slides, per = 3, 9
+    tiles, sidx, y = make_slides(n_slides, per, seed=5)
+    paths, mem_slides = [], []
+    for i in range(n_slides):
+        p = f'{d}/j{i}.tfrecords'
+        tfr.write_slide(p, f'j{i}', tiles[sidx == i], fmt='JPEG')
+        paths.append(p)
+        dec = np.stack([tfr.decode_image(tfr.parse_example(r)['image_raw']) for r in tfr.read_records(p)])   # Pillow
+        assert not np.array_equal(dec, tiles[sidx == i])                 # lossy: the decoded tiles are their own images
+        mem_slides.append(Slide(f'j{i}', dec, per, y_true=int(y[i])))
+    eng = Engine(synthetic_weights(1), dtype='f16', max_batch=16, max_mc=5)
+    from_files = evaluate(eng, slides_from_tfrecords(paths, {f'j{i}': int(y[i]) for i in range(n_slides)}), outcome='cohort',
+                          mc_n=5, seed=7, batch=16)
+    in_memory = evaluate(eng, mem_slides, outcome='cohort', mc_n=5, seed=7, batch=16)
+    for col in ('cohort-y_pred1', 'cohort-uncertainty1'):
+        assert np.array_equal(from_files.tile_df[col].to_numpy(), in_memory.tile_df[col].to_numpy()), col
+    assert np.array_equal(from_files.slide_pred, in_memory.slide_pred)
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------ stress weights
 @pytest.fixture(scope='module')
 def hard():
