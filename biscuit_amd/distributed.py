@@ -34,16 +34,19 @@ def global_tile_offsets(tile_counts):
     return np.concatenate([[0], np.cumsum(counts)[:-1]]) if len(counts) else counts
 
 
-def init_from_env(device_type='cuda', backend=None, local_device=None):
+def init_from_env(device_type='cuda', backend=None, local_device=None, single_rank_group=False):
     """Initialise torch.distributed from the launcher's rendezvous variables (torchrun's contract: RANK, WORLD_SIZE,
     LOCAL_RANK, MASTER_ADDR, MASTER_PORT -- the only environment this package reads).
 
     backend: None = "nccl" (RCCL) for cuda, "gloo" for cpu; local_device: None = LOCAL_RANK.  Both are explicit
-    arguments so that a caller -- a test running two ranks on one GPU -- states them itself."""
+    arguments so that a caller -- a test running two ranks on one GPU -- states them itself.  single_rank_group: create the
+    process group even for a world of one (a one-GPU box can then run the collectives through a real RCCL communicator;
+    RCCL refuses two ranks on one device)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0')) if local_device is None else int(local_device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
+        os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = backend or ('nccl' if device_type == 'cuda' else 'gloo')
         if device_type == 'cuda':
@@ -68,7 +71,7 @@ def gather_slide_results(local_ids, mean_pred, mean_unc, count, n_slides, cap, d
     out_pred = np.full(n_slides, np.nan)
     out_unc = np.full(n_slides, np.nan)
     out_cnt = np.zeros(n_slides, dtype=np.int64)
-    if world == 1:
+    if not dist.is_initialized():             # (a process group of one rank still takes the collective below)
         out_pred[local_ids] = np.asarray(mean_pred, dtype=np.float64)
         out_unc[local_ids] = np.asarray(mean_unc, dtype=np.float64)
         out_cnt[local_ids] = np.asarray(count, dtype=np.int64)

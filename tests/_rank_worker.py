@@ -1,6 +1,6 @@
 """Child process of the multi-rank GPU tests: one rank of ``inference.evaluate`` with the real ``Engine``
-(several ranks may share one GPU: argv[6] = local device, argv[7] = process-group backend, e.g. "0 gloo").  Writes its
-view of the result to ``argv[1]``.rank{r}.npz."""
+(several ranks may share one GPU: argv[6] = local device, argv[7] = process-group backend, e.g. "0 gloo"; argv[8] = "group1":
+a process group even for a world of one).  Writes its view of the result to ``argv[1]``.rank{r}.npz."""
 import os
 import sys
 
@@ -25,14 +25,17 @@ def main():
     from biscuit_amd.engine import Engine
     from biscuit_amd.inference import evaluate
     from biscuit_amd.weights import synthetic_weights
-    rank, world, local = D.init_from_env('cuda', backend=backend, local_device=local_device)
+    group1 = len(sys.argv) > 8 and sys.argv[8] == 'group1'
+    rank, world, local = D.init_from_env('cuda', backend=backend, local_device=local_device, single_rank_group=group1)
     eng = Engine(synthetic_weights(1), dtype=dtype, max_batch=batch, max_mc=mc_n, device=local)
     res = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch, rank=rank, world=world)
     np.savez(f'{out}.rank{rank}.npz', slide_pred=res.slide_pred, slide_unc=res.slide_unc, slide_count=res.slide_count,
              local=np.array(res.local_slides), tile_slide=np.array(res.tile_df['slide'], dtype=str),
              tile_pred=res.tile_df['cohort-y_pred1'].to_numpy(), tile_unc=res.tile_df['cohort-uncertainty1'].to_numpy())
     import torch.distributed as dist
-    if world > 1:
+    if dist.is_initialized():
+        if group1:
+            np.savez(f'{out}.group.npz', backend=dist.get_backend(), size=dist.get_world_size())
         dist.barrier()
         dist.destroy_process_group()
 

@@ -74,6 +74,33 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
     eng.close()
 
 
+def test_rccl_communicator_carries_the_gather(tmp_path):
+    """The `nccl` branch of the N > 1 path on hardware, as far as a one-GPU box allows (RCCL refuses two ranks on one device):
+    a real RCCL communicator of ONE rank carries `gather_slide_results`' all-gather (a float64 CUDA buffer through
+    ncclAllGather) and the closing barrier; the result equals the group-less run bit for bit."""
+    from _rank_worker import build_slides
+    from biscuit_amd.engine import Engine
+    from biscuit_amd.inference import evaluate
+    counts = [5, 0, 9, 3]
+    mc_n, batch = 4, 8
+    out = str(tmp_path / 'res')
+    env = dict({k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')},
+               RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_rank_worker.py'), out, 'f16', str(mc_n), str(batch),
+                        ','.join(map(str, counts)), '0', 'nccl', 'group1'], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    g = np.load(f'{out}.group.npz')
+    assert str(g['backend']) == 'nccl' and int(g['size']) == 1
+    r0 = np.load(f'{out}.rank0.npz')
+    eng = Engine(synthetic_weights(1), dtype='f16', max_batch=batch, max_mc=mc_n)
+    single = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch)
+    assert np.array_equal(r0['slide_pred'], single.slide_pred, equal_nan=True)
+    assert np.array_equal(r0['slide_unc'], single.slide_unc, equal_nan=True)
+    assert list(r0['slide_count']) == counts
+    eng.close()
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the parent spawns two ranks before touching the
     GPU and relays rank 0's JSON line (here both ranks share GPU 0: --local-device 0 --dist-backend gloo)."""
