@@ -621,10 +621,17 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
         static_for<0, KSC * MF * RN>([&](auto qc) {
             constexpr int Q = decltype(qc)::value;
             constexpr int D = Q / (MF * RN), J = (Q % (MF * RN)) / MF, I = Q % MF;
+#if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 16))         // timing ablation (wrong results): 16 = no A-fragment reads
             if constexpr (Q == 0) {                             // A fragments of the chunk's first k-step
 #pragma unroll
                 for (int i = 0; i < MF; ++i) a[i] = *reinterpret_cast<const uint4*>(smem + a_cur + i * 16 * A_STR);
             }
+#else
+            if constexpr (Q == 0) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) asm volatile("" : "=v"(a[i].x), "=v"(a[i].y), "=v"(a[i].z), "=v"(a[i].w));
+            }
+#endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 2))          // timing ablations (wrong results): 2 = no depthwise
             if constexpr (DMODE == 1) dw_ops<T, RELU, PW, KP, NSTEP, dw_before<NSLOTQ, NDW>(Q), dw_before<NSLOTQ, NDW>(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
             if constexpr (DMODE == 2) dw_ops<T, RELU, PW, KP, NSTEP, dw_before<NSLOTQ, NDW>(2 * Q), dw_before<NSLOTQ, NDW>(2 * Q + 2)>(st, smem, raw_addr, tap_addr, awn);
@@ -640,8 +647,10 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
                 bq[J] = load_b(nx < KST ? nx : 0, J);           // past the end: k-step 0, the next tile's first
             }
 #endif
+#if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 16))
             if constexpr (J == RN - 1 && D + 1 < KSC)           // last use of this A fragment: fetch the next k-step's
                 a[I] = *reinterpret_cast<const uint4*>(smem + a_cur + I * 16 * A_STR + (D + 1) * 64);
+#endif
             __builtin_amdgcn_sched_barrier(0);                  // the source order of this loop IS the schedule
         });
         WSTAMP(6 + c);
