@@ -135,8 +135,11 @@ struct WideParams {
 #ifdef BQ_EXPERIMENTS
 constexpr int STAMP_TILES = 8;        // tiles of a workgroup that get a row of 32 stamps each
 #define WSTAMP(ev) do { if (stp && stamp_it < STAMP_TILES) stp[stamp_it * 32 + (ev)] = __builtin_amdgcn_s_memtime(); } while (0)
+// the 100 MHz real-time counter next to the cycle counter: events 30 (tile start) and 31 (tile end) -> the in-kernel clock
+#define WSTAMP_RT(ev) do { if (stp && stamp_it < STAMP_TILES) stp[stamp_it * 32 + (ev)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define WSTAMP(ev) do { } while (0)
+#define WSTAMP_RT(ev) do { } while (0)
 #endif
 
 // One LDS-DMA instruction: lanes in `mask` copy 16 bytes each from sbase + voff to LDS at lds_dst + 16*lane.
@@ -669,6 +672,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
     for (;;) {
         has_next = vb + nwg < ntiles;
         WSTAMP(18);
+        WSTAMP_RT(30);
         if constexpr (NCH > 2) {
             chunk(I0{}, K2{}, I1{}, std::true_type{}, 0);
             chunk(I1{}, K2{}, I1{}, std::false_type{}, 1);
@@ -783,6 +787,7 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             }
         }
         WSTAMP(22);
+        WSTAMP_RT(31);
 #ifdef BQ_EXPERIMENTS
         ++stamp_it;
 #endif

@@ -18,6 +18,12 @@ for it in range(8):
     gap = med(s[:, 18] - t[:, it - 1, 22]) if it else med(s[:, 18] - s[:, 5])
     print(f'tile {it}: total {med(s[:, 22] - s[:, 18])}  gap before {gap}  chunks {chunks}  nops {med(s[:, 20] - s[:, 17])}  epilogue {med(s[:, 22] - s[:, 20])}')
     # spread over the waves of a workgroup: when does the last wave finish its epilogue after the first?
+# in-kernel clock: cycles (s_memtime) per 10 ns tick of s_memrealtime, first tile start -> last stamped tile's end
+last = max(it for it in range(8) if (t[:, it, 22] > 0).all())
+cyc = t[:, last, 22] - t[:, 0, 18]
+rt = t[:, last, 31] - t[:, 0, 30]
+if (rt > 0).all():
+    print(f'in-kernel clock over tiles 0..{last}: median {np.median(cyc / rt) * 0.1:.3f} GHz (min {np.min(cyc / rt) * 0.1:.3f}, max {np.max(cyc / rt) * 0.1:.3f})')
 w = a[:, :, :, :]
 blocks = [b for b in range(64) if (a[b, :, 0, 0] > 0).all()]
 for it in range(2):
