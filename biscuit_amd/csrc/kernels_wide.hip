@@ -42,9 +42,6 @@
 #ifndef WIDE_ABLATE
 #define WIDE_ABLATE 0
 #endif
-#ifndef WIDE_TAP_ASM
-#define WIDE_TAP_ASM 0
-#endif
 
 namespace {
 using namespace bqk;
@@ -213,20 +210,10 @@ __device__ __forceinline__ void tap2(float& o0, float& o1, const float2& tw, con
         // behind an inline-asm v_fma_mix -- does not pad the next instruction that reads the result with an s_nop (it takes
         // every asm result for a partial-register write: one s_nop per tap, 70 per chunk in the 10-pixel runs of the 74x74
         // instance)
-#if WIDE_TAP_ASM
-        if constexpr (FIRST) {
-            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(o0) : "v"(w), "v"(tw.x));
-            asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(o1) : "v"(w), "v"(tw.y));
-        } else {
-            o0 = H16<T>::fma_lo(w, tw.x, o0);
-            o1 = H16<T>::fma_hi(w, tw.y, o1);
-        }
-#else
         typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
         const f16x2v h = __builtin_bit_cast(f16x2v, w);
         o0 = __builtin_fmaf((float)h.x, tw.x, FIRST ? 0.f : o0);
         o1 = __builtin_fmaf((float)h.y, tw.y, FIRST ? 0.f : o1);
-#endif
     } else {
         o0 = fmaf(tw.x, w.x, FIRST ? 0.f : o0);
         o1 = fmaf(tw.y, w.y, FIRST ? 0.f : o1);
