@@ -365,6 +365,26 @@ def test_hard_weights_throughput_mode_holds_tolerance(hard):
     assert dm < NORTH_STAR_TOL and ds < NORTH_STAR_TOL and dsp < NORTH_STAR_TOL and dsu < NORTH_STAR_TOL
 
 
+@pytest.mark.parametrize('weight_seed', [4, 7])
+def test_hard_weights_other_draws_hold_the_tolerance(weight_seed):
+    """The same claim on other draws of the stress weights: of eight seeds (tools/parity_seeds.py, profiles/r03_parity_seeds.log:
+    f16 tile max|d mean| 2.2e-4 .. 4.6e-4, slide 4e-5 .. 2.1e-4; bf16 1.5e-3 .. 3.9e-3) these two are the worst for f16."""
+    from biscuit_amd.engine import Engine
+    w = synthetic_weights(weight_seed, hard=True)
+    tiles, sidx, _ = make_slides(4, 16, seed=100 + weight_seed)
+    d, sl = dev(tiles), dev(sidx).long()
+    e32, e16 = Engine(w, dtype='f32', max_batch=64, max_mc=30), Engine(w, dtype='f16', max_batch=64, max_mc=30)
+    (m32, s32), (m16, s16) = e32.mc_infer(d, 30, 1234), e16.mc_infer(d, 30, 1234)
+
+    def smean(x):
+        return torch.zeros(4, device='cuda', dtype=torch.float64).index_add_(0, sl, x.double()) / 16
+    deltas = (float((m32 - m16).abs().max()), float((s32 - s16).abs().max()),
+              float((smean(m32[:, 1]) - smean(m16[:, 1])).abs().max()), float((smean(s32[:, 1]) - smean(s16[:, 1])).abs().max()))
+    print(f'hard weights seed {weight_seed}, f16 vs fp32 kernels: tile {deltas[0]:.3e} / {deltas[1]:.3e}; slide {deltas[2]:.3e} / {deltas[3]:.3e}')
+    assert max(deltas) < NORTH_STAR_TOL
+    e32.close(); e16.close()
+
+
 def test_hard_weights_bf16_kernels_reported(hard):
     """The same figure for the bf16 mode, which BASELINE config 2 names: with O(1) logits it does NOT stay inside 1e-3
     (measured 2.7e-3 on the tile mean, 9e-4 on the tile std, 1.4e-3 on the slide mean of 16 tiles): the error is the
