@@ -36,6 +36,7 @@ ABI = {
     'bq_load_weights': (_i, [_vp, _vp, _sz]),
     'bq_stage': (_i, [_vp, _vp, _i, _vp, _vp]),
     'bq_stage_f32': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'bq_png_unfilter': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     'bq_stream_create_masked': (_i, [_vp, C.POINTER(C.c_uint32), _i, C.POINTER(_vp)]),
     'bq_stream_destroy': (_i, [_vp, _vp]),
     'bq_stain_reinhard_fast': (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp]),

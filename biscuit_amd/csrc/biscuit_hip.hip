@@ -763,6 +763,12 @@ int bq_stain_lab_stats(bq_ctx* c, const uint8_t* d_tiles, int n, float* d_stats6
     return BQ_OK;
 }
 
+int bq_png_unfilter(bq_ctx* c, const uint8_t* d_rows, int n, int px, uint8_t* d_out, bq_stream_t stream) {
+    if (!c || !d_rows || !d_out || n < 0 || px <= 0) return fail(c, BQ_ERR_ARG, "bq_png_unfilter: bad argument");
+    if (launch_png_unfilter(d_rows, n, px, d_out, (hipStream_t)stream)) return fail(c, BQ_ERR_HIP, "png unfilter launch failed");
+    return BQ_OK;
+}
+
 int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, bq_stream_t* out) {
     if (!c || !cu_mask || mask_words <= 0 || !out) return fail(c, BQ_ERR_ARG, "bq_stream_create_masked: bad argument");
     hipStream_t s = nullptr;

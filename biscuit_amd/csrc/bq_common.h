@@ -105,6 +105,8 @@ int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, d
 int launch_reinhard(const uint8_t* tiles, int n, int px, const float* d_lut, const float* consts27,
                     const float* tgt_mean, const float* tgt_std, uint8_t* dst, float* d_stats, hipStream_t s);
 int launch_stage_f32(const float* tiles, int n, int px, void* out, int dtype, hipStream_t s);
+// kernels_png.hip: PNG scanline un-filtering (rows: [n][px][1 + 3 px] filter byte + filtered RGB bytes -> out uint8 NHWC)
+int launch_png_unfilter(const unsigned char* rows, int n, int px, unsigned char* out, hipStream_t s);
 int launch_stem1(const void* in_nchw, int n, const float* w27x32, const float* scale,
                  const float* bias, void* out_nhwc, int dtype, hipStream_t s);
 int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, int Wi, int C,

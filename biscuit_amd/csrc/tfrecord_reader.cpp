@@ -436,8 +436,9 @@ int bqio_inflate2(const uint8_t* za, size_t na, uint8_t* out_a, size_t len_a, co
 
 int64_t bqio_inflate_fallbacks(void) { return (int64_t)g_inflate_fallbacks.load(); }
 
-int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc, int n_threads,
-                int64_t* bad_index) {
+// rows: leave the PNG scanline filters in (bqio_decode_rows); a tile's output is then px rows of 1 + 3 px bytes
+static int decode_impl(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc, int n_threads,
+                       int64_t* bad_index, bool rows) {
     if (!r || first < 0 || count < 0 || first + count > (int64_t)r->records.size() || tile_px <= 0 || (count && !out))
         return BQIO_ERR_ARG;
     if (bad_index) *bad_index = -1;
@@ -447,10 +448,19 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
     std::atomic<int64_t> next(0);
     std::atomic<int> status(BQIO_OK);
     std::atomic<int64_t> bad(-1);
-    const size_t tile_bytes = (size_t)tile_px * tile_px * 3;
+    const size_t row_bytes = (size_t)tile_px * 3 + (rows ? 1 : 0);
+    const size_t tile_bytes = (size_t)tile_px * row_bytes;
     auto work = [&]() {
         std::vector<PngJob> jobs(2);                      // two tiles at a time: their streams are inflated in one loop
         std::unique_ptr<bqjpg::Scratch> jpg;              // built on the first JPEG record
+        std::vector<uint8_t> rgb;                         // rows mode: a tile decoded here on the host, before it is re-rowed
+        // rows mode, a tile that is not an 8-bit RGB PNG: its pixels as px rows of filter type 0
+        auto as_plain_rows = [&](const uint8_t* src, uint8_t* dst) {
+            for (int y = 0; y < tile_px; ++y) {
+                dst[(size_t)y * row_bytes] = 0;
+                memcpy(dst + (size_t)y * row_bytes + 1, src + (size_t)y * tile_px * 3, (size_t)tile_px * 3);
+            }
+        };
         auto fail = [&](int e, int64_t i) {
             int expect = BQIO_OK;
             if (status.compare_exchange_strong(expect, e)) bad.store(first + i);
@@ -471,8 +481,11 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
                         break;
                     case BQIO_IMG_JPEG: {
                         if (!jpg) jpg.reset(new bqjpg::Scratch());
-                        const int j = bqjpg::decode(ex[k].image.p, ex[k].image.n, tile_px, out + (size_t)(i0 + k) * tile_bytes, *jpg);
+                        uint8_t* o = out + (size_t)(i0 + k) * tile_bytes;
+                        if (rows) rgb.resize((size_t)tile_px * tile_px * 3);
+                        const int j = bqjpg::decode(ex[k].image.p, ex[k].image.n, tile_px, rows ? rgb.data() : o, *jpg);
                         e = j == bqjpg::OK ? BQIO_OK : j == bqjpg::WRONG_SIZE ? BQIO_ERR_FORMAT : BQIO_ERR_UNSUPPORTED;
+                        if (rows && e == BQIO_OK) as_plain_rows(rgb.data(), o);
                         break;
                     }
                     default: e = BQIO_ERR_UNSUPPORTED;
@@ -488,8 +501,22 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
                 ok[0] = bqinf::inflate_zlib(jobs[0].zbuf.data(), jobs[0].z_n, jobs[0].raw.data(), jobs[0].raw_n, jobs[0].tables);
             for (int j = 0; j < npng; ++j) {
                 const int k = png[j];
-                int e = (ok[j] || inflate_second_opinion(jobs[j])) ? png_finish(jobs[j], out + (size_t)(i0 + k) * tile_bytes)
-                                                                   : BQIO_ERR_CORRUPT;
+                uint8_t* o = out + (size_t)(i0 + k) * tile_bytes;
+                int e = BQIO_ERR_CORRUPT;
+                if (ok[j] || inflate_second_opinion(jobs[j])) {
+                    PngJob& J = jobs[j];
+                    if (!rows) e = png_finish(J, o);
+                    else if (J.ctype == 2) {              // 8-bit RGB: the inflated stream IS the row format; only the filter types are checked
+                        e = BQIO_OK;
+                        for (uint32_t y = 0; y < J.h; ++y)
+                            if (J.raw[(J.stride + 1) * y] > 4) e = BQIO_ERR_CORRUPT;
+                        if (e == BQIO_OK) memcpy(o, J.raw.data(), J.raw_n);
+                    } else {                              // grey, palette, RGBA: un-filtered and converted here
+                        rgb.resize((size_t)tile_px * tile_px * 3);
+                        e = png_finish(J, rgb.data());
+                        if (e == BQIO_OK) as_plain_rows(rgb.data(), o);
+                    }
+                }
                 if (e != BQIO_OK) { fail(e, i0 + k); return; }
             }
         }
@@ -506,6 +533,16 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
                                            : "corrupt record or PNG";
     }
     return e;
+}
+
+int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc, int n_threads,
+                int64_t* bad_index) {
+    return decode_impl(r, first, count, tile_px, out, loc, n_threads, bad_index, false);
+}
+
+int bqio_decode_rows(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out_rows, int64_t* loc, int n_threads,
+                     int64_t* bad_index) {
+    return decode_impl(r, first, count, tile_px, out_rows, loc, n_threads, bad_index, true);
 }
 
 int bqio_decode_jpeg(const uint8_t* data, size_t len, int tile_px, uint8_t* out) {

@@ -108,6 +108,17 @@ class Engine:
         self._check(self._lib.bq_stage(self._ctx, _ptr(tiles_u8), n, _ptr(out), self._stream()))
         return out
 
+    def png_unfilter(self, rows_u8):
+        """PNG scanline filters reversed on the device (kernels_png.hip): uint8 [n,px,1+3*px] -- per row the filter-type byte
+        and the filtered RGB bytes, as `tfrecord_native.NativeReader.decode(rows=True)` delivers them -- -> uint8 NHWC
+        [n,px,px,3].  Bit-exact with a host PNG decoder."""
+        assert rows_u8.dtype == torch.uint8 and rows_u8.is_cuda and rows_u8.is_contiguous() and rows_u8.dim() == 3
+        n, px, rs = rows_u8.shape
+        assert rs == 1 + 3 * px, rows_u8.shape
+        out = torch.empty((n, px, px, 3), dtype=torch.uint8, device=self.device)
+        self._check(self._lib.bq_png_unfilter(self._ctx, _ptr(rows_u8), n, px, _ptr(out), self._stream()))
+        return out
+
     def reinhard_fast(self, tiles_u8, target_means, target_stds, out=None):
         """`reinhard_fast` stain normalisation (hp.py:19; results.py:251-252 `wsi_normalizer.rgb_to_rgb`):
         uint8 NHWC [n,299,299,3] -> uint8 NHWC.  target_means/target_stds: the CIE-LAB `norm_fit` of the

@@ -36,22 +36,37 @@ class Slide:
         return t
 
 
-def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None):
+class PngRows:
+    """A slide's tiles as the tile reader leaves them when the GPU reverses the PNG scanline filters: uint8
+    [T,px,1+3*px] (host, usually pinned).  ``evaluate`` copies them to the device and calls ``Engine.png_unfilter``."""
+    def __init__(self, rows):
+        self.rows = rows
+
+
+def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None, gpu_unfilter=None):
     """One ``Slide`` per ``*.tfrecords`` file (Slideflow writes one file per slide).  Tiles are
     decoded lazily when the slide's turn comes (``evaluate`` decodes one slide ahead on a host thread);
     only the record headers are scanned up front.  labels: {slide name (file stem): 0/1}.
     ``pinned`` (default: when a GPU is present) decodes into page-locked memory so the H2D copy is
-    asynchronous and overlaps the next slide's decode."""
+    asynchronous and overlaps the next slide's decode.  ``gpu_unfilter`` (default off): the host stops at the inflated PNG
+    scanlines and the GPU reverses their filters (``Engine.png_unfilter``) -- 12-30 % more tiles per host core, for 1.4 ms
+    of GPU time per launch of up to 512 tiles (host side): worth it where the host cores, not the GPU,
+    bound the run."""
     import os
     from . import tfrecord
     if pinned is None:
         pinned = torch.cuda.is_available()
+    gpu_unfilter = bool(gpu_unfilter)
     out = []
     for path in paths:
         name = os.path.splitext(os.path.basename(path))[0]
         count = tfrecord.count_records(path)
 
         def loader(pth=path, n=count):
+            if gpu_unfilter and n:
+                t = torch.empty((n, tile_px, 1 + 3 * tile_px), dtype=torch.uint8, pin_memory=bool(pinned))
+                tfrecord.read_slide(pth, tile_px, out=t.numpy(), rows=True)
+                return PngRows(t)
             if pinned and n:
                 t = torch.empty((n, tile_px, tile_px, 3), dtype=torch.uint8, pin_memory=True)
                 tfrecord.read_slide(pth, tile_px, out=t.numpy())
@@ -202,7 +217,10 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 pending = prefetch.submit(on_prep(slides[mine[li + 1]].load)) if li + 1 < len(mine) else None
             else:
                 loaded = s.load()
-            t = _to_device(loaded, dev)
+            if isinstance(loaded, PngRows):      # filtered PNG scanlines: H2D, then the filters are reversed on the device
+                t = engines[0].png_unfilter(_to_device(loaded.rows, dev))
+            else:
+                t = _to_device(loaded, dev)
             assert t.shape[0] == s.n_tiles, (s.name, t.shape, s.n_tiles)
             if s.n_tiles == 0:
                 continue

@@ -165,8 +165,11 @@ def decode_image(raw, tile_px=299):
     return img
 
 
-def read_slide(path, tile_px=299, verify='length', native=None, out=None, threads=None):
+def read_slide(path, tile_px=299, verify='length', native=None, out=None, threads=None, rows=False):
     """One slide's TFRecord -> (slide name, tiles uint8 [T,px,px,3], loc int64 [T,2]).
+
+    ``rows=True``: tiles as [T,px,1+3*px] -- per row a PNG filter-type byte and the (still filtered) RGB bytes, for
+    ``Engine.png_unfilter`` on the GPU; whatever is not an 8-bit RGB PNG arrives decoded, as rows of filter type 0.
 
     ``native=None`` uses libbiscuit_io.so (C++ framing / protobuf / PNG decode on a thread pool) when it
     is built and falls back to the pure-Python reader otherwise; a slide with a record the native decoder
@@ -180,9 +183,10 @@ def read_slide(path, tile_px=299, verify='length', native=None, out=None, thread
         with tn.NativeReader(path, verify) as r:
             n = len(r)
             if n == 0:
-                return r.slide, np.zeros((0, tile_px, tile_px, 3), np.uint8), np.zeros((0, 2), np.int64)
+                return r.slide, np.zeros((0, tile_px, 1 + 3 * tile_px) if rows else (0, tile_px, tile_px, 3), np.uint8), \
+                    np.zeros((0, 2), np.int64)
             try:
-                tiles, locs = r.decode(0, n, tile_px, out=out, threads=threads)
+                tiles, locs = r.decode(0, n, tile_px, out=out, threads=threads, rows=rows)
                 return r.slide, tiles, locs
             except tn.UnsupportedImage:
                 name = r.slide            # outside the native decoders' subset: Pillow below
@@ -194,8 +198,13 @@ def read_slide(path, tile_px=299, verify='length', native=None, out=None, thread
         tiles.append(decode_image(ex['image_raw'], tile_px))
         locs.append((ex.get('loc_x', [0])[0], ex.get('loc_y', [0])[0]))
     if not tiles:
-        return name, np.zeros((0, tile_px, tile_px, 3), np.uint8), np.zeros((0, 2), np.int64)
+        return name, np.zeros((0, tile_px, 1 + 3 * tile_px) if rows else (0, tile_px, tile_px, 3), np.uint8), \
+            np.zeros((0, 2), np.int64)
     tiles = np.stack(tiles)
+    if rows:                                    # decoded here: rows of filter type 0
+        plain = np.zeros((len(tiles), tile_px, 1 + 3 * tile_px), np.uint8)
+        plain[:, :, 1:] = tiles.reshape(len(tiles), tile_px, 3 * tile_px)
+        tiles = plain
     if out is not None:
         out[...] = tiles
         tiles = out

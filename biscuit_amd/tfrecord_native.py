@@ -28,6 +28,7 @@ ABI = {
     'bqio_image_format': (_i, [_vp, _i64]),
     'bqio_image_bytes': (_i, [_vp, _i64, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
     'bqio_decode': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
+    'bqio_decode_rows': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
     'bqio_masked_crc32c': (C.c_uint32, [C.c_char_p, C.c_size_t]),
     'bqio_inflate': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t]),
     'bqio_inflate2': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp, C.c_size_t,
@@ -160,18 +161,21 @@ class NativeReader:
             raise IOError(self._lib.bqio_last_error(self._h).decode())
         return C.string_at(p, n.value)
 
-    def decode(self, first=0, count=None, tile_px=299, out=None, threads=None):
+    def decode(self, first=0, count=None, tile_px=299, out=None, threads=None, rows=False):
         """-> (tiles uint8 [count,px,px,3], loc int64 [count,2]).  `out`: optional C-contiguous uint8
-        array / tensor-backed numpy view to decode into (e.g. pinned memory)."""
+        array / tensor-backed numpy view to decode into (e.g. pinned memory).
+        rows=True: the PNG scanline filters stay in -- [count,px,1+3*px], filter-type byte + filtered bytes per row, for
+        `Engine.png_unfilter` on the GPU (tiles that are not 8-bit RGB PNGs arrive decoded, as rows of filter type 0)."""
         total = len(self)
         count = total - first if count is None else count
+        shape = (count, tile_px, 1 + 3 * tile_px) if rows else (count, tile_px, tile_px, 3)
         if out is None:
-            out = np.empty((count, tile_px, tile_px, 3), np.uint8)
-        assert out.dtype == np.uint8 and out.flags['C_CONTIGUOUS'] and out.size == count * tile_px * tile_px * 3
+            out = np.empty(shape, np.uint8)
+        assert out.dtype == np.uint8 and out.flags['C_CONTIGUOUS'] and out.size == int(np.prod(shape))
         loc = np.zeros((count, 2), np.int64)
         bad = _i64(-1)
-        e = self._lib.bqio_decode(self._h, first, count, tile_px, out.ctypes.data, loc.ctypes.data,
-                                  threads or default_threads(), C.byref(bad))
+        fn = self._lib.bqio_decode_rows if rows else self._lib.bqio_decode
+        e = fn(self._h, first, count, tile_px, out.ctypes.data, loc.ctypes.data, threads or default_threads(), C.byref(bad))
         if e == ERR_UNSUPPORTED:
             raise UnsupportedImage(bad.value)
         if e == ERR_FORMAT:       # same exception the Python reader raises for a tile of the wrong size

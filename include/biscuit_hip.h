@@ -98,6 +98,12 @@ int bq_stain_reinhard_fast(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, cons
  * normaliser's fit() stores as norm_fit for a target image. */
 int bq_stain_lab_stats(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, float* d_stats6, bq_stream_t stream);
 
+/* Input side, PNG tiles: the reversal of the PNG scanline filters on the device.  d_rows:
+ * [n][px][1 + 3*px] bytes -- per row the filter-type byte and the filtered RGB bytes, i.e. the inflated IDAT stream of an
+ * 8-bit RGB non-interlaced PNG, as libbiscuit_io's bqio_decode_rows delivers it (include/biscuit_io.h).  d_out: uint8 NHWC
+ * [n][px][px][3], the tiles bq_stage / bq_mc_infer take.  Bit-exact with a host PNG decoder (tests/test_png_unfilter.py). */
+int bq_png_unfilter(bq_ctx* ctx, const uint8_t* d_rows, int n, int px, uint8_t* d_out_nhwc, bq_stream_t stream);
+
 /* Variant for callers that already hold standardised float32 NHWC tiles (the
  * UncertaintyInterface contract, results.py:256-257): converts to planar NCHW. */
 int bq_stage_f32(bq_ctx* ctx, const float* d_tiles_nhwc_f32, int n, void* d_out_nchw,

@@ -57,6 +57,14 @@ int bqio_image_bytes(bqio_reader* r, int64_t index, const uint8_t** data, size_t
 int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc,
                 int n_threads, int64_t* bad_index);
 
+/* The same records with the PNG scanline filters LEFT IN, for a caller that reverses them on the GPU (bq_png_unfilter,
+ * include/biscuit_hip.h): out_rows[count][tile_px][1 + 3*tile_px] -- per row the filter-type byte (0..4) and the filtered RGB
+ * bytes, which for an 8-bit RGB non-interlaced PNG is the inflated IDAT stream as it is (a third of a photo-like tile's decode
+ * time stays off the host).  Tiles of any other kind -- grey / palette / RGBA PNGs, JPEGs -- are decoded completely here and
+ * delivered as rows of filter type 0.  Errors as bqio_decode. */
+int bqio_decode_rows(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out_rows, int64_t* loc,
+                     int n_threads, int64_t* bad_index);
+
 /* One JPEG file (as bqio_image_bytes returns it) -> out[tile_px][tile_px][3], the decoder
  * bqio_decode uses, exported for tests.  BQIO_OK / BQIO_ERR_UNSUPPORTED / BQIO_ERR_FORMAT. */
 int bqio_decode_jpeg(const uint8_t* data, size_t len, int tile_px, uint8_t* out);
