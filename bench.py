@@ -570,7 +570,14 @@ def tfrecord_leg(pool_e, args, n_slides=8, tiles_per_slide=256):
         dt = time.perf_counter() - t0
         n = n_slides * tiles_per_slide
         assert int(res.slide_count.sum()) == n
+        # the same with the PNG scanline filters reversed on the GPU (opt-in: kernels_png.hip)
+        gslides = slides_from_tfrecords(paths, {f's{s}': s % 2 for s in range(n_slides)}, gpu_unfilter=True)
+        evaluate(pool_e, gslides[:1], mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False)
+        t0 = time.perf_counter()
+        evaluate(pool_e, gslides, mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False)
+        gdt = time.perf_counter() - t0
         return {'tiles': n, 'value': n / dt, 'unit': 'tiles/s', 'decode_only_tiles_per_s': n / dec,
+                'gpu_unfilter_value': n / gdt,
                 'jpeg_decode_only_tiles_per_s': tiles_per_slide / jdec,
                 'host_cores': usable_cores(), 'png_bytes_per_tile': nbytes / n,
                 'jpeg_bytes_per_tile': os.path.getsize(jp) / tiles_per_slide,
