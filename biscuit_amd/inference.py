@@ -48,10 +48,10 @@ def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None
     decoded lazily when the slide's turn comes (``evaluate`` decodes one slide ahead on a host thread);
     only the record headers are scanned up front.  labels: {slide name (file stem): 0/1}.
     ``pinned`` (default: when a GPU is present) decodes into page-locked memory so the H2D copy is
-    asynchronous and overlaps the next slide's decode.  ``gpu_unfilter`` (default off): the host stops at the inflated PNG
-    scanlines and the GPU reverses their filters (``Engine.png_unfilter``) -- 12-30 % more tiles per host core, for 0.4-0.6
-    ms of GPU time per launch of up to 512 tiles (host side): worth it where the host cores, not the
-    GPU, bound the run."""
+    asynchronous and overlaps the next slide's decode.  ``gpu_unfilter`` (default off; tiles up to 341 px): the host stops at
+    the inflated PNG scanlines and the GPU reverses their filters (``Engine.png_unfilter``) -- 12-30 % more tiles per host
+    core for 0.4-0.6 ms of GPU time per launch of up to 512 tiles (host side): for hosts whose cores,
+    not the GPU, bound the run."""
     import os
     from . import tfrecord
     if pinned is None:
