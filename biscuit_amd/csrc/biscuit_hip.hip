@@ -99,7 +99,8 @@ struct WsLayout {
 WsLayout ws_layout(const bq_ctx* c, int n, int mc) {
     const size_t es = esize(c);
     WsLayout L{};
-    size_t off = 0;
+    size_t off = 4096;   // front pad: the streaming kernel's window column -1 of an image's first row reads (and discards) the
+                         // 16-bit pixel in front of the tensor
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     L.a = take((size_t)n * kMaxAct * es);
     L.b = take((size_t)n * kMaxAct * es);
@@ -227,6 +228,16 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
     const bool will_split = !no_split && (split_env || L.kpad >= 1024) && is16(dtype) && dwp &&
                             L.nfp % 4 == 0 && a.dwtmp && nsplit == 1;
     ProfScope ps(c, s, will_split ? std::string("split_") + cls : std::string(cls), will_split ? 0.0 : flops, will_split ? 0.0 : bytes);
+    // round 4: the 147x147 separable convolutions of block 2 on the streaming kernel (kernels_stream.hip)
+    static const bool no_stream = bq_exp_env("BQ_NO_STREAM") != nullptr;
+    if (!no_stream && dwp && L.wp16 && !a.residual && nsplit == 1 && a.H == a.Hi && a.W == a.Wi && a.ldi == L.kpad &&
+        a.ldo == L.cout && stream_supported(dtype, L.kpad, L.cout, a.prod == PROD_DW_RELU, a.n, a.H, a.W)) {
+        const int e = launch_sepconv_stream(dtype, L.kpad, L.cout, a.prod == PROD_DW_RELU, a.in, L.wp16, L.dw, L.scale, L.bias,
+                                            a.out, a.n, a.H, a.W, a.relu, c->num_cus, s);
+        if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(stream) ") + a.layer + ": " +
+                                                   hipGetErrorString((hipError_t)e));
+        return BQ_OK;
+    }
     static const bool no_tile = bq_exp_env("BQ_NO_TILE") != nullptr;
     static const int tile_mask = bq_exp_env("BQ_TILE_MASK") ? atoi(bq_exp_env("BQ_TILE_MASK")) : 15;  // kinds enabled (bit k)
     if (!no_tile && is16(dtype) && !a.residual) {

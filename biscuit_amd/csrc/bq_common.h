@@ -93,6 +93,10 @@ bool pipe_supported(int dtype, int prod, int nfp, int W, int K);
 int launch_sepconv_pipe(int dtype, int prod, const GemmParams& p, hipStream_t s);
 bool wide_supported(int dtype, int prod, int nfp, int H, int W, int K, int Nstore, int ldi, int ldo, long long M, bool residual);
 int launch_sepconv_wide(int dtype, int prod, const GemmParams& p, const void* wp16, int num_cus, hipStream_t s);
+bool stream_supported(int dtype, int cin, int cout, bool relu_in, long long n, int H, int W);
+int launch_sepconv_stream(int dtype, int cin, int cout, bool relu_in, const void* in, const void* wp16, const float* dw,
+                          const float* scale, const float* bias, void* out, int n, int H, int W, int relu, int num_cus,
+                          hipStream_t s);
 int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
 int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s);
 int launch_tile_conv(int dtype, int kind, const void* in, const void* wp, const float* dw, const float* scale,

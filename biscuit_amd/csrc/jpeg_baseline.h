@@ -87,15 +87,19 @@ inline bool build_huff(Huff& H, const uint8_t counts[16], const uint8_t* vals, i
     return true;
 }
 
-// Entropy-coded bytes of one restart interval with the stuffed zeros removed (and at least 16 readable bytes behind them).
-// The accumulator is refilled eight bytes at a time whether or not they belong to the interval; `clean()` says afterwards
-// whether a bit from beyond its end was consumed, which is what a damaged stream does.
+// Entropy-coded bytes of one restart interval with the stuffed zeros removed.  The accumulator is refilled eight bytes at
+// a time whether or not they belong to the interval; `clean()` says afterwards whether a bit from beyond its end was
+// consumed, which is what a damaged stream does.  A refill moves `p` by at most 7 bytes and a block refills at most 65
+// times, so with ECS_PAD readable bytes behind the LAST interval and `overrun()` checked before every block the reader
+// never leaves the buffer, however short a damaged scan is (a scan cut down to nothing in front of a valid EOI walked
+// `p` hundreds of bytes per block past the data before `clean()` was ever asked: round-3 advisory).
 struct Bits {
     const uint8_t *p, *start;
     uint64_t acc = 0;
     int have = 0;
     int64_t nbits = 0;
     void open(const uint8_t* data, size_t n) { p = start = data; acc = 0; have = 0; nbits = (int64_t)n * 8; }
+    bool overrun() const { return (int64_t)(p - start) * 8 > nbits + 64; }   // already 8 bytes past the interval's end
     inline void fill() {         // to 56..63 bits
         uint64_t v;
         memcpy(&v, p, 8);
@@ -107,6 +111,8 @@ struct Bits {
     inline void drop(int n) { acc <<= n; have -= n; }
     bool clean() const { return (int64_t)(p - start) * 8 - have <= nbits; }
 };
+
+constexpr size_t ECS_PAD = 65 * 7 + 8 + 16 + 64;   // one block's worth of refills behind an interval that just passed overrun()
 
 inline int decode_symbol(Bits& B, const Huff& H) {
     const uint32_t e = H.look[B.peek(LOOK)];
@@ -413,6 +419,7 @@ inline void ycc_row(const Scratch& S, const uint8_t* yy, const uint8_t* cb, cons
 inline bool decode_block(Bits& B, const Huff& dc, const Huff& ac, const uint16_t* q, int& pred, uint8_t* out, size_t stride) {
     alignas(16) int16_t coef[8][8];
     int16_t* cf = &coef[0][0];
+    if (B.overrun()) return false;       // the stream ended blocks ago: refuse before reading further (see Bits)
     B.fill();
     int s = decode_symbol(B, dc);
     if (s < 0) return false;
@@ -576,7 +583,7 @@ inline int decode(const uint8_t* data, size_t n, int px, uint8_t* out, Scratch& 
 
     // ---- entropy-coded segment: drop the stuffed zeros, split at the restart markers ---------------------------------
     S.ecs.clear(); S.seg.clear();
-    S.ecs.reserve(n - scan + 16);
+    S.ecs.reserve(n - scan + ECS_PAD);
     S.seg.push_back(0);
     {
         size_t i = scan;
@@ -601,7 +608,7 @@ inline int decode(const uint8_t* data, size_t n, int px, uint8_t* out, Scratch& 
         if (!ended) return UNSUPPORTED;
     }
     S.seg.push_back(S.ecs.size());
-    S.ecs.insert(S.ecs.end(), 32, (uint8_t)0);
+    S.ecs.insert(S.ecs.end(), ECS_PAD, (uint8_t)0);
     const int64_t total_mcu = (int64_t)mcux * mcuy;
     const int64_t per_seg = restart ? restart : total_mcu;
     if ((int64_t)(S.seg.size() - 1) != (total_mcu + per_seg - 1) / per_seg) return UNSUPPORTED;

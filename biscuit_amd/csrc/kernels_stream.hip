@@ -1,0 +1,272 @@
+// Streaming separable-convolution kernel for the big, HBM-bound entry-flow layers (block 2 at 147x147: 64 -> 128 and
+// 128 -> 128; block 3 at 74x74: 128 -> 256), 16-bit storage, round 4.
+//
+// The tile kernels these layers ran on (kernels_tile.hip) are one fat workgroup per CU that walks barrier-separated
+// phases -- halo registers -> LDS, barrier, depthwise, matrix stage, staged epilogue -- so all 256 CUs load, compute and
+// store in lock step and nothing overlaps (3.4-4.2 TB/s).  Here every WAVE is an independent worker and there is no
+// workgroup barrier after the weights have been copied to LDS:
+//  * a work item is a vertical strip of an image: <= 16 output columns x a band of ~25 rows.  The wave walks DOWN the
+//    strip one output row per step.
+//  * lane = channel pair.  The 3-row window of the depthwise convolution lives in REGISTERS as packed 16-bit pairs
+//    (3 x 18 dwords): a step fetches ONE new input row of 18 pixels with coalesced `global_load_dword`s (64 lanes x 4 B =
+//    the 256 contiguous bytes of a 128-channel pixel), one step ahead of its use.  No halo image in LDS, no staging pass,
+//    every input row of a strip is read once (17/15 columns per output column; rows 27/25).
+//  * the 16 depthwise results of a step (fp32 taps and accumulation, the tap order of the tile kernels, rounded to the
+//    storage type) go to a 4 KB wave-private A tile in LDS -- the transposition from (lane = channel pair) to the MFMA
+//    operand (lane = pixel, 8 consecutive channels) -- and come back as the B operand of v_mfma_f32_16x16x32
+//    (D[cout][pixel]); the weights (A operand, 16x16x32 fragment order with interleaved fragment pairs: "<layer>/wp16")
+//    sit in LDS once per workgroup.
+//  * epilogue straight from the accumulators: with the pair interleave a lane holds 8 consecutive channels of its pixel
+//    per fragment pair -> folded BN, ReLU, one 16-byte store; a pair's store covers 64 contiguous bytes of 16 pixels.
+//  * 12 waves per CU (3 per SIMD, <= 168 registers) drift apart by themselves: one wave's loads and stores run under
+//    the others' depthwise and matrix work.
+#include "gemm_common.h"
+
+namespace {
+using namespace bqk;
+
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct StreamParams {
+    const T* in;           // NHWC [n][H][W][CIN]
+    const uint4* wp16;     // [CIN/32][COUT/16][64] x 16 B (weights.py: pack_fragments16)
+    const float* dw;       // [9][CIN] fp32
+    const float* scale;    // [COUT] folded BN
+    const float* bias;
+    T* out;                // NHWC [n][H][W][COUT]
+    int n, H, W;
+    int nstrips, nbands;   // strips per row (<= 16 columns each), bands per image
+    int items;             // n * nbands * nstrips
+    int relu;
+};
+
+template <typename T> __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c);
+template <> __device__ __forceinline__ f32x4 mma16<f16_t>(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16<bf16_t>(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// halves of a packed dword as an fp32 pair, by plain conversions (the asm forms of H16<> cost an s_nop each here: hipcc pads
+// every asm result it cannot see the latency of)
+typedef _Float16 h16x2s __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ f32x2s unpack2(unsigned u);
+template <> __device__ __forceinline__ f32x2s unpack2<f16_t>(unsigned u) {
+    return __builtin_convertvector(__builtin_bit_cast(h16x2s, u), f32x2s);
+}
+template <> __device__ __forceinline__ f32x2s unpack2<bf16_t>(unsigned u) {
+    return (f32x2s){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+
+// first column and width of strip s when W columns are cut into ns strips of nearly equal width (<= 16)
+__device__ __forceinline__ void strip_span(int s, int W, int ns, int& x0, int& nc) {
+    const int base = W / ns, rem = W - base * ns;
+    x0 = s * base + (s < rem ? s : rem);
+    nc = base + (s < rem ? 1 : 0);
+}
+
+template <typename T, int CIN, int COUT, bool RELU_IN, int NW>
+__global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamParams<T> p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
+    constexpr int NT = NW * 64;
+    constexpr int KS = CIN / 32, NF = COUT / 16, NQ = COUT / 32;
+    constexpr int HALVES = 128 / CIN;           // 1: a lane is a channel pair of all 128; 2: lanes 32-63 take columns 8-15
+    constexpr int NCOL = 16 / HALVES;           // output columns per lane
+    constexpr int NWIN = NCOL + 2;              // window columns per lane
+    constexpr int AST = CIN * 2 + 16;           // A row stride: an odd number of 16-byte slots
+    constexpr int W_BYTES = KS * NF * 1024;
+    constexpr int SB_OFF = W_BYTES;             // scale[COUT] | bias[COUT], fp32
+    constexpr int A_OFF = SB_OFF + 2 * COUT * 4;
+    constexpr int A_BYTES = 16 * AST;
+    static_assert(CIN == 64 || CIN == 128, "lane = channel pair of <= 128 channels");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int i = tid; i < W_BYTES / 16; i += NT) *reinterpret_cast<uint4*>(smem + i * 16) = p.wp16[i];
+    for (int i = tid; i < COUT; i += NT) {
+        reinterpret_cast<float*>(smem + SB_OFF)[i] = p.scale[i];
+        reinterpret_cast<float*>(smem + SB_OFF)[COUT + i] = p.bias[i];
+    }
+    const int cpair = HALVES == 1 ? lane : (lane & 31);
+    const int chalf = HALVES == 1 ? 0 : (lane >> 5);
+    f32x2s tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tap[t] = *reinterpret_cast<const f32x2s*>(p.dw + t * CIN + 2 * cpair);
+    __syncthreads();                            // the only workgroup barrier of the kernel
+
+    unsigned char* const At = smem + A_OFF + wave * A_BYTES;
+    const int px = lane & 15, g = lane >> 4;
+    const int a_write = (chalf * NCOL) * AST + cpair * 4;
+    const int a_read = px * AST + g * 16;
+    const float* const sb = reinterpret_cast<const float*>(smem + SB_OFF) + 8 * g;
+    const unsigned lo2 = p.relu ? 0u : 0x80008000u;     // ReLU = packed signed 16-bit max with 0 (0x8000: no-op)
+    const int wgx = xcd_tile(blockIdx.x, gridDim.x);
+    const int lane_el = chalf * NCOL * CIN + 2 * cpair;  // element offset of this lane's first window column
+    // buffer resource of the output tensor (raw buffer, 32-bit byte offsets: launch_stream checks the size)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)((size_t)p.n * p.H * p.W * COUT * sizeof(T)), 0x00020000);
+
+    for (int it = 0;; ++it) {
+        const int item = __builtin_amdgcn_readfirstlane((it * (int)gridDim.x + wgx) * NW + wave);
+        if (item >= p.items) break;
+        const int strip = item % p.nstrips;
+        const int t1 = item / p.nstrips;
+        const int band = t1 % p.nbands;
+        const int img = t1 / p.nbands;
+        int x0, nc, y0, nr;
+        strip_span(strip, p.W, p.nstrips, x0, nc);
+        strip_span(band, p.H, p.nbands, y0, nr);
+        const int y1 = y0 + nr;
+        // window column j of this lane is image column xl + j; outside [0, W) it reads as zero ('same' padding); columns
+        // past the strip's own 16 + 1 are never used for a stored pixel
+        const int xl = x0 - 1 + chalf * NCOL;
+        unsigned cmask = 0;
+#pragma unroll
+        for (int j = 0; j < NWIN; ++j) cmask |= ((unsigned)(xl + j) < (unsigned)p.W) ? (1u << j) : 0u;
+        const T* const img_in = p.in + ((size_t)img * p.H * p.W + (x0 - 1)) * CIN + lane_el;
+
+        unsigned r0[NWIN], r1[NWIN], r2[NWIN], nx[NWIN];
+        auto load_row = [&](int y, unsigned (&dst)[NWIN]) {        // row clamped into the image: always valid memory
+            const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
+            const T* rp = img_in + (size_t)yc * p.W * CIN;
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) dst[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
+        };
+        auto mask_row = [&](int y, const unsigned (&src)[NWIN], unsigned (&dst)[NWIN]) {
+            const unsigned m = (unsigned)y < (unsigned)p.H ? cmask : 0u;
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) {
+                unsigned v = ((m >> j) & 1u) ? src[j] : 0u;
+                if (RELU_IN) v = relu_pk16(v);
+                dst[j] = v;
+            }
+        };
+        load_row(y0 - 1, nx); mask_row(y0 - 1, nx, r0);
+        load_row(y0, nx);     mask_row(y0, nx, r1);
+        load_row(y0 + 1, nx);
+
+        // Stores are raw buffer stores: a lane whose pixel lies outside the strip gets an offset beyond the buffer and the
+        // hardware drops its store.  Under `if (px < nc)` hipcc cannot count the stores in vmcnt any more and the wait for
+        // the next input row becomes a wait for this row's stores as well (vmcnt retires in order).
+        unsigned ooff = px < nc ? (unsigned)(((((size_t)img * p.H + y0) * p.W + x0 + px) * COUT + 8 * g) * sizeof(T)) : 0xfffffff0u;
+        const unsigned ostep = px < nc ? (unsigned)((size_t)p.W * COUT * sizeof(T)) : 0u;
+        for (int y = y0; y < y1; ++y, ooff += ostep) {
+            mask_row(y + 1, nx, r2);
+            // the row after next, one whole step ahead of its use (the last step re-reads row y1: an L2 hit, branch-free)
+            load_row(y + 2 < y1 ? y + 2 : y1, nx);
+
+            // ---- depthwise 3x3: nine tap pairs in registers, window in registers
+#pragma unroll
+            for (int x = 0; x < NCOL; ++x) {
+                f32x2s a = {0.f, 0.f};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const unsigned (&r)[NWIN] = dy == 0 ? r0 : (dy == 1 ? r1 : r2);
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const unsigned u = r[x + dx];
+                        a = __builtin_elementwise_fma(tap[dy * 3 + dx], unpack2<T>(u), a);
+                    }
+                }
+                *reinterpret_cast<unsigned*>(At + a_write + x * AST) = H16<T>::pack2(a.x, a.y);
+            }
+            // ---- pointwise: D[cout][pixel] += W[cout][k] * A[pixel][k] (LDS operations of a wave complete in order)
+            f32x4 acc[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 b = *reinterpret_cast<const uint4*>(At + a_read + ks * 64);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((ks * NF + f) * 64 + lane) * 16);
+                    acc[f] = mma16<T>(wf, b, acc[f]);
+                }
+            }
+            // ---- epilogue: lane (pixel px, group g) holds channels 32 q + 8 g .. + 7 of fragment pair q
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float4 s0 = *reinterpret_cast<const float4*>(sb + 32 * q);
+                const float4 s1 = *reinterpret_cast<const float4*>(sb + 32 * q + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(sb + COUT + 32 * q);
+                const float4 b1 = *reinterpret_cast<const float4*>(sb + COUT + 32 * q + 4);
+                const f32x4 u = acc[2 * q], v = acc[2 * q + 1];
+                uint4 o;
+                o.x = H16<T>::pack2(fmaf(u[0], s0.x, b0.x), fmaf(u[1], s0.y, b0.y));
+                o.y = H16<T>::pack2(fmaf(u[2], s0.z, b0.z), fmaf(u[3], s0.w, b0.w));
+                o.z = H16<T>::pack2(fmaf(v[0], s1.x, b1.x), fmaf(v[1], s1.y, b1.y));
+                o.w = H16<T>::pack2(fmaf(v[2], s1.z, b1.z), fmaf(v[3], s1.w, b1.w));
+                asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
+                asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
+                asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.z) : "v"(o.z), "v"(lo2));
+                asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.w) : "v"(o.w), "v"(lo2));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), orsrc, (int)ooff + 64 * q, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+        }
+    }
+}
+
+template <typename T, int CIN, int COUT, bool RELU_IN>
+int launch_stream(StreamParams<T> p, int num_cus, hipStream_t s) {
+#ifndef STREAM_NW
+#define STREAM_NW 12
+#endif
+    constexpr int NW = STREAM_NW;
+    constexpr size_t lds = (size_t)(CIN / 32) * (COUT / 16) * 1024 + 2 * COUT * 4 + (size_t)NW * 16 * (CIN * 2 + 16);
+    static_assert(lds <= 160 * 1024, "stream kernel LDS budget");
+    auto kern = sepconv_stream_kernel<T, CIN, COUT, RELU_IN, NW>;
+    static BqLdsAttr attr;
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
+    p.nstrips = (p.W + 15) / 16;
+    // bands of ~25 rows (2 halo rows per band); small batches get shorter bands so that every CU still has work
+    const int waves = num_cus * NW;
+    int nb = (p.H + 24) / 25;
+    const long long base_items = (long long)p.n * p.nstrips;
+    if (base_items * nb < waves) {
+        nb = (int)((waves + base_items - 1) / base_items);
+        if (nb > p.H / 4) nb = p.H / 4;
+        if (nb < 1) nb = 1;
+    }
+    p.nbands = nb;
+    p.items = (int)(base_items * nb);
+    int grid = (p.items + NW - 1) / NW;
+    if (grid > num_cus) grid = num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_stream_t(int cin, int cout, bool relu_in, const void* in, const void* wp16, const float* dw, const float* scale,
+                    const float* bias, void* out, int n, int H, int W, int relu, int num_cus, hipStream_t s) {
+    StreamParams<T> p;
+    p.in = reinterpret_cast<const T*>(in);
+    p.wp16 = reinterpret_cast<const uint4*>(wp16);
+    p.dw = dw; p.scale = scale; p.bias = bias;
+    p.out = reinterpret_cast<T*>(out);
+    p.n = n; p.H = H; p.W = W; p.relu = relu;
+    p.nstrips = p.nbands = p.items = 0;
+    if (cin == 64 && cout == 128 && !relu_in) return launch_stream<T, 64, 128, false>(p, num_cus, s);
+    if (cin == 128 && cout == 128 && !relu_in) return launch_stream<T, 128, 128, false>(p, num_cus, s);
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace
+
+bool stream_supported(int dtype, int cin, int cout, bool relu_in, long long n, int H, int W) {
+    return dtype != 0 && !relu_in && cout == 128 && (cin == 64 || cin == 128) && H >= 4 && W >= 1 &&
+           n * H * W * (long long)cout * 2 < 0xfffffff0ll;
+}
+
+int launch_sepconv_stream(int dtype, int cin, int cout, bool relu_in, const void* in, const void* wp16, const float* dw,
+                          const float* scale, const float* bias, void* out, int n, int H, int W, int relu, int num_cus,
+                          hipStream_t s) {
+    return dtype == 2 ? launch_stream_t<f16_t>(cin, cout, relu_in, in, wp16, dw, scale, bias, out, n, H, W, relu, num_cus, s)
+                      : launch_stream_t<bf16_t>(cin, cout, relu_in, in, wp16, dw, scale, bias, out, n, H, W, relu, num_cus, s);
+}

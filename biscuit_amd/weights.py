@@ -286,6 +286,10 @@ def wide_layers():
             [f'block{b}_sepconv{i}' for b in range(5, 13) for i in (1, 2, 3)] + ['block13_sepconv1', 'block13_sepconv2'])
 
 
+# kernels_stream.hip (round 4): the 147x147 separable convolutions of block 2 take the same 16x16x32 fragment order
+STREAM_LAYERS = ('block2_sepconv1', 'block2_sepconv2')
+
+
 def fold_bn(w, name):
     s = w[name + '/gamma'] / np.sqrt(w[name + '/moving_variance'] + np.float32(BN_EPS))
     b = w[name + '/beta'] - w[name + '/moving_mean'] * s
@@ -341,7 +345,7 @@ def pack_blob(w, dtype='bf16'):
         dw[:, :cin] = w[name + '/depthwise_kernel'].reshape(9, cin)
         add(name + '/dw', dw)
         npad = add_mat(name, w[name + '/pointwise_kernel'].reshape(cin, cout), cp)
-        if half and name in wide and cp % 32 == 0:
+        if half and (name in wide or name in STREAM_LAYERS) and cp % 32 == 0:
             add(name + '/wp16', to_bits(pack_fragments16(w[name + '/pointwise_kernel'].reshape(cin, cout), cp, npad)))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)

@@ -9,7 +9,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FLAGS = ['-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined']
+FLAGS = ['-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined',
+         '-D_GLIBCXX_SANITIZE_VECTOR']        # poisons size()..capacity() of std::vector: over-reads of a reused buffer show
 
 
 def _build(src, out, libs=()):
