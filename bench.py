@@ -53,6 +53,9 @@ PEAK_BF16 = 2.5e15                                # FLOP/s dense bf16 = f16 MFMA
 HALF = ('f16', 'bf16')                            # the 16-bit storage / matrix-core types
 PEAK_F32 = 157.3e12
 TILES_PER_SLIDE = 1000
+# profiling classes of the entry side (stage, stem, block1_conv2, blocks 2 and 3 with their fused ends): `entry_side_ms`
+ENTRY_SIDE = ('stage_u8', 'stem_conv1', 'conv3x3_k32_n64_147', 'sepconv_k64_n128_147', 'sepconv_k128_n128_147',
+              'respool_147', 'blocktail_147', 'sepconv_k128_n256_74', 'sepconv_k256_n256_74', 'respool_74', 'blocktail_74')
 NORM_FIT = {'target_means': [65.0, 12.0, -8.0], 'target_stds': [14.0, 7.0, 6.0]}   # a plausible H&E fit (synthetic)
 
 
@@ -192,8 +195,10 @@ def run(args):
         one = torch.ones(1, dtype=torch.int32, device=coll_dev)
         dist.all_reduce(one)
         coll_ranks = int(one.item())
+    # rccl_ranks = ranks an RCCL communicator really spanned in this run: 0 when no process group exists (N = 1) or the
+    # group is a CPU backend
     coll = {'backend': dist.get_backend() if world > 1 else None, 'ranks_seen': coll_ranks,
-            'rccl_ranks': coll_ranks if (world > 1 and dist.get_backend() == 'nccl') else (1 if world == 1 else 0)}
+            'rccl_ranks': coll_ranks if (world > 1 and dist.get_backend() == 'nccl') else 0}
 
     weights = synthetic_weights(1)
     pool_e = EnginePool(weights, n_streams=args.streams, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc,
@@ -399,10 +404,22 @@ def run(args):
                            'launches_per_step': dom.launches / psteps, 'avg_launch_ms': dom.ms / dom.launches,
                            'share_of_step': dom.ms / tot,
                            'algorithmic_flops_per_launch': dom.flops, 'algorithmic_bytes_per_launch': dom.bytes}
-        out['kernels'] = [{'name': e.name, 'launches_per_step': e.launches / psteps,
-                           'ms_per_launch': e.ms / e.launches, 'share': e.ms / tot,
-                           'tflops': e.flops / (e.ms / e.launches * 1e-3) / 1e12,
-                           'gbps': e.bytes / (e.ms / e.launches * 1e-3) / 1e9} for e in ents[:48]]
+        pk_f = (PEAK_BF16 if es == 2 else PEAK_F32) / 1e12
+
+        def kern(e):
+            tf = e.flops / (e.ms / e.launches * 1e-3) / 1e12
+            gb = e.bytes / (e.ms / e.launches * 1e-3) / 1e9
+            return {'name': e.name, 'launches_per_step': e.launches / psteps, 'ms_per_launch': e.ms / e.launches,
+                    'share': e.ms / tot, 'tflops': tf, 'gbps': gb,
+                    # fraction of the roofline that binds the launch: the larger of its MFMA and HBM fractions
+                    'frac_of_bound': max(tf / pk_f, gb / (PEAK_HBM / 1e9))}
+        out['kernels'] = [kern(e) for e in ents[:48]]
+        # the HBM-bound entry side of the network (staging, stem, blocks 1-3): ms per step and the same bytes at the
+        # measured copy rate
+        entry = [e for e in ents if e.name.startswith(ENTRY_SIDE)]
+        out['entry_side_ms'] = sum(e.ms for e in entry) / psteps
+        out['entry_side_floor_ms'] = sum(e.bytes * e.launches for e in entry) / psteps / PEAK_HBM_MEASURED * 1e3
+        out['entry_side_kernels'] = sorted(e.name for e in entry)
 
     if solo and not args.no_extras:
         out['b1_latency'] = b1_latency(eng, args.mc)

@@ -117,15 +117,23 @@ WsLayout ws_layout(const bq_ctx* c, int n, int mc) {
 }
 
 // ---- profiling -----------------------------------------------------------------
+// A class sums the algorithmic FLOPs and bytes of its launches: the instances of one class differ (8 of the 25
+// 728 -> 728 layers read a residual, 406 against 270 MB), and bq_profile_read reports the launch-weighted average.
 int prof_class(bq_ctx* c, const std::string& name, double flops, double bytes) {
+    int k = -1;
     for (size_t i = 0; i < c->prof_names.size(); ++i)
-        if (c->prof_names[i] == name) return (int)i;
-    c->prof_names.push_back(name);
-    c->prof_flops.push_back(flops);
-    c->prof_bytes.push_back(bytes);
-    c->prof_launches.push_back(0);
-    c->prof_ms.push_back(0.0);
-    return (int)c->prof_names.size() - 1;
+        if (c->prof_names[i] == name) { k = (int)i; break; }
+    if (k < 0) {
+        c->prof_names.push_back(name);
+        c->prof_flops.push_back(0.0);
+        c->prof_bytes.push_back(0.0);
+        c->prof_launches.push_back(0);
+        c->prof_ms.push_back(0.0);
+        k = (int)c->prof_names.size() - 1;
+    }
+    c->prof_flops[k] += flops;
+    c->prof_bytes[k] += bytes;
+    return k;
 }
 
 struct ProfScope {
@@ -415,10 +423,34 @@ int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void*
                          e.Hi, e.Hi, ci, co, 1}, s));
         TAP(nm, A, e.Hi, e.Hi, e.cout, co);
         snprintf(nm, sizeof nm, "block%d_sepconv2", e.block);
+        snprintf(rn, sizeof rn, "block%d_res", e.block);
+        void* dst = e.block == 4 ? out4 : nxt;
+        {   // round 4: the block's tail in one kernel (kernels_stream.hip) -- sepconv2 + BN, max-pool, shortcut conv + BN, add --
+            // unless the tensors it no longer writes were asked for
+            static const bool no_tail = bq_exp_env("BQ_NO_TAIL") != nullptr;
+            auto l2 = c->layers.find(nm), lr = c->layers.find(rn);
+            const bool want_mid = tap && tap->want && (strcmp(tap->want, nm) == 0 || strcmp(tap->want, rn) == 0);
+            if (!no_tail && !want_mid && l2 != c->layers.end() && lr != c->layers.end() && l2->second.wp16 && lr->second.wp16 &&
+                e.cout == co && e.cin == ci && tail_supported(dt, co, co, ci, n, e.Hi, e.Hi)) {
+                const double M = (double)n * e.Hi * e.Hi, Mo = (double)n * Ho * Ho;
+                char cls[64];
+                snprintf(cls, sizeof cls, "blocktail_%d_c%d", e.Hi, e.cout);
+                {
+                    ProfScope ps(c, s, cls, 2.0 * M * co * co + 18.0 * M * co + 2.0 * Mo * ci * co + 9.0 * Mo * co,
+                                 es * (M * co + Mo * ci + Mo * co) + es * ((double)co * co + (double)ci * co));
+                    const int er = launch_block_tail(dt, co, co, ci, A, l2->second.wp16, l2->second.dw, l2->second.scale,
+                                                     l2->second.bias, cur, lr->second.wp16, lr->second.scale, lr->second.bias, dst,
+                                                     n, e.Hi, e.Hi, c->num_cus, s);
+                    if (er) return fail(c, BQ_ERR_HIP, std::string("launch(block tail) ") + nm + ": " + hipGetErrorString((hipError_t)er));
+                }
+                snprintf(nm, sizeof nm, "block%d_out", e.block);
+                TAP(nm, dst, Ho, Ho, e.cout, co);
+                void* t = cur; cur = nxt; nxt = t;
+                continue;
+            }
+        }
         RUN(run_conv(c, {nm, PROD_DW, A, C, nullptr, nullptr, n, e.Hi, e.Hi, e.Hi, e.Hi, co, co, 0}, s));
         TAP(nm, C, e.Hi, e.Hi, e.cout, co);
-        void* dst = e.block == 4 ? out4 : nxt;
-        snprintf(rn, sizeof rn, "block%d_res", e.block);
         snprintf(tn, sizeof tn, "maxpool_add_%d_c%d", e.Hi, e.cout);
         int tapped = 0;
         RUN(block_end(c, rn, tn, cur, C, dst, n, e.Hi, ci, co, e.cout, s, tap, &tapped));
@@ -922,8 +954,9 @@ int bq_profile_read(bq_ctx* c, bq_prof_entry* out, int max_entries) {
         strncpy(out[k].name, c->prof_names[i].c_str(), sizeof out[k].name - 1);
         out[k].launches = c->prof_launches[i];
         out[k].ms = c->prof_ms[i];
-        out[k].flops = c->prof_flops[i];
-        out[k].bytes = c->prof_bytes[i];
+        const double nl = c->prof_launches[i] > 0 ? (double)c->prof_launches[i] : 1.0;
+        out[k].flops = c->prof_flops[i] / nl;      // per launch, averaged over the class's launches
+        out[k].bytes = c->prof_bytes[i] / nl;
     }
     return k;
 }

@@ -97,6 +97,10 @@ bool stream_supported(int dtype, int cin, int cout, bool relu_in, long long n, i
 int launch_sepconv_stream(int dtype, int cin, int cout, bool relu_in, const void* in, const void* wp16, const float* dw,
                           const float* scale, const float* bias, void* out, int n, int H, int W, int relu, int num_cus,
                           hipStream_t s);
+bool tail_supported(int dtype, int cin, int cout, int cx, long long n, int H, int W);
+int launch_block_tail(int dtype, int cin, int cout, int cx, const void* y1, const void* wp16, const float* dw,
+                      const float* scale, const float* bias, const void* x, const void* wr16, const float* rscale,
+                      const float* rbias, void* out, int n, int H, int W, int num_cus, hipStream_t s);
 int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
 int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s);
 int launch_tile_conv(int dtype, int kind, const void* in, const void* wp, const float* dw, const float* scale,

@@ -22,6 +22,12 @@
 //    the others' depthwise and matrix work.
 #include "gemm_common.h"
 
+// ablation switches of tools/ubench/stream_bench.hip (timing only, wrong results): 1 no stores, 2 no depthwise arithmetic,
+// 4 no MFMAs, 8 no input loads.  The product build has none of them.
+#ifndef STREAM_ABL
+#define STREAM_ABL 0
+#endif
+
 namespace {
 using namespace bqk;
 
@@ -135,7 +141,10 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
             const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
             const T* rp = img_in + (size_t)yc * p.W * CIN;
 #pragma unroll
-            for (int j = 0; j < NWIN; ++j) dst[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
+            for (int j = 0; j < NWIN; ++j) {
+                if constexpr (STREAM_ABL & 8) dst[j] = (unsigned)(size_t)rp + j;
+                else dst[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
+            }
         };
         auto mask_row = [&](int y, const unsigned (&src)[NWIN], unsigned (&dst)[NWIN]) {
             const unsigned m = (unsigned)y < (unsigned)p.H ? cmask : 0u;
@@ -153,7 +162,7 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
         // Stores are raw buffer stores: a lane whose pixel lies outside the strip gets an offset beyond the buffer and the
         // hardware drops its store.  Under `if (px < nc)` hipcc cannot count the stores in vmcnt any more and the wait for
         // the next input row becomes a wait for this row's stores as well (vmcnt retires in order).
-        unsigned ooff = px < nc ? (unsigned)(((((size_t)img * p.H + y0) * p.W + x0 + px) * COUT + 8 * g) * sizeof(T)) : 0xfffffff0u;
+        unsigned ooff = px < nc ? (unsigned)(((((size_t)img * p.H + y0) * p.W + x0 + px) * COUT + 8 * g) * sizeof(T)) : 0xffffff00u;   // (+ 64 q stays below 2^32: the offset sum wraps there)
         const unsigned ostep = px < nc ? (unsigned)((size_t)p.W * COUT * sizeof(T)) : 0u;
         for (int y = y0; y < y1; ++y, ooff += ostep) {
             mask_row(y + 1, nx, r2);
@@ -164,6 +173,8 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
 #pragma unroll
             for (int x = 0; x < NCOL; ++x) {
                 f32x2s a = {0.f, 0.f};
+                if constexpr (STREAM_ABL & 2) a = unpack2<T>(r0[x] ^ r1[x + 1] ^ r2[x + 2]);
+                else
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
                     const unsigned (&r)[NWIN] = dy == 0 ? r0 : (dy == 1 ? r1 : r2);
@@ -185,7 +196,8 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
                     const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((ks * NF + f) * 64 + lane) * 16);
-                    acc[f] = mma16<T>(wf, b, acc[f]);
+                    if constexpr (STREAM_ABL & 4) { acc[f][0] += __uint_as_float(wf.x ^ b.x); acc[f][1] += __uint_as_float(wf.y ^ b.y); }
+                    else acc[f] = mma16<T>(wf, b, acc[f]);
                 }
             }
             // ---- epilogue: lane (pixel px, group g) holds channels 32 q + 8 g .. + 7 of fragment pair q
@@ -205,12 +217,303 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
                 asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
                 asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.z) : "v"(o.z), "v"(lo2));
                 asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.w) : "v"(o.w), "v"(lo2));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), orsrc, (int)ooff + 64 * q, 0, 0);
+                if constexpr (STREAM_ABL & 1) { if (o.x == 0x12345678u && o.y == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), orsrc, (int)ooff + 64 * q, 0, 0); }
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), orsrc, (int)ooff + 64 * q, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < NWIN; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Block tail in one kernel (round 4): out = MaxPool3x3/s2 'same'(BN(sepconv2(y1))) + BN(Conv1x1/s2(x)).
+//
+// The second separable convolution of an entry-flow block is only ever read by the block's max-pool: written and read
+// back it is 2 x 1.42 GB of the 4.8 GB that block 2's sepconv2 + pool/shortcut kernel pair move.  On the streaming structure the pool
+// is incremental and needs no tile-sized staging (the 16x16-tile form of round 3 lost to its serialised phases):
+//  * a strip owns <= 7 POOLED columns = 15 convolution columns (window columns 2xo-pl .. 2xo-pl+2 overlap by one, so
+//    strips overlap by one column: 16 MFMA pixel slots per 14 new columns), a band owns a run of pooled rows;
+//  * a row step produces one convolution row in the accumulator layout (lane = pixel slot px, 8 channels per fragment
+//    pair), folded BN, rounded to the storage type -- the rounding point of the tensor that no longer exists;
+//  * vertical max: a running packed maximum VM of the rows of the current window (16 registers); horizontal max on the
+//    rows that complete a window: the neighbours px-1 / px+1 are the neighbouring LANES of a 16-lane DPP row
+//    (row_shr:1 / row_shl:1), columns outside the image count as -inf;
+//  * the shortcut of the pooled row: x sampled at (2yo, 2xo) straight from global memory in MFMA operand layout (slot
+//    px reads the pixel its own pooled output needs, so the result lands in the lane that holds the pooled maximum),
+//    16 more MFMAs per pooled row, folded BN, rounded (the rounding point of the shortcut tensor of the two-kernel
+//    path), added in fp32, rounded, stored from the odd slots.
+template <typename T>
+struct TailParams {
+    const T* in;           // sepconv2's input [n][H][W][128]
+    const uint4* wp16;     // sepconv2 pointwise weights, 16x16x32 fragment order [4][8][64] x 16 B
+    const float* dw;       // [9][128]
+    const float* scale;    // [128] folded BN of sepconv2
+    const float* bias;
+    const T* x;            // the block's input [n][H][W][CX]
+    const uint4* wr16;     // shortcut weights [CX/32][8][64] x 16 B
+    const float* rscale;   // [128] folded BN of the shortcut
+    const float* rbias;
+    T* out;                // [n][Ho][Wo][128]
+    int n, H, W, Ho, Wo;
+    int nstrips, nbands, items;
+};
+
+template <typename T> __device__ __forceinline__ unsigned pmax2(unsigned a, unsigned b);
+template <> __device__ __forceinline__ unsigned pmax2<f16_t>(unsigned a, unsigned b) {   // one v_pk_max_f16 (exact: a maximum rounds nothing)
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(h16x2s, a), __builtin_bit_cast(h16x2s, b)));
+}
+template <> __device__ __forceinline__ unsigned pmax2<bf16_t>(unsigned a, unsigned b) {
+    const f32x2s x = unpack2<bf16_t>(a), y = unpack2<bf16_t>(b);
+    return H16<bf16_t>::pack2(fmaxf(x.x, y.x), fmaxf(x.y, y.y));
+}
+template <typename T> struct NegInf;
+template <> struct NegInf<f16_t> { static constexpr unsigned v = 0xfc00fc00u; };
+template <> struct NegInf<bf16_t> { static constexpr unsigned v = 0xff80ff80u; };
+
+// pooled rows [p0, p0 + np) of band b when Ho rows are cut into nb bands: the first and the last band end at the image
+// border (one convolution row fewer than 2 np + 1), so the remainder goes to them first
+__device__ __forceinline__ void band_span(int b, int Ho, int nb, int& p0, int& np) {
+    const int base = Ho / nb, rem = Ho - base * nb;
+    const int lo = (rem + 1) / 2, hi = rem / 2;           // bands [0, lo) and [nb - hi, nb) take one more
+    auto extra = [&](int i) { return (i < lo || i >= nb - hi) ? 1 : 0; };
+    p0 = b * base + (b < lo ? b : lo) + (b > nb - hi ? b - (nb - hi) : 0);
+    np = base + extra(b);
+}
+
+template <typename T, int CX, int NW>
+__global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailParams<T> p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
+    constexpr int NT = NW * 64;
+    constexpr int CIN = 128, COUT = 128, KS = CIN / 32, NF = COUT / 16, NQ = COUT / 32, NWIN = 18;
+    constexpr int KR = CX / 32;
+    constexpr int AST = CIN * 2 + 16;
+    constexpr int W_BYTES = KS * NF * 1024, WR_BYTES = KR * NF * 1024;
+    constexpr int WR_OFF = W_BYTES;
+    constexpr int SB_OFF = WR_OFF + WR_BYTES;   // scale | bias | rscale | rbias, fp32 [4][COUT]
+    constexpr int A_OFF = SB_OFF + 4 * COUT * 4;
+    constexpr int A_BYTES = 16 * AST;
+    constexpr unsigned NEG = NegInf<T>::v;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < W_BYTES / 16; i += NT) *reinterpret_cast<uint4*>(smem + i * 16) = p.wp16[i];
+    for (int i = tid; i < WR_BYTES / 16; i += NT) *reinterpret_cast<uint4*>(smem + WR_OFF + i * 16) = p.wr16[i];
+    for (int i = tid; i < COUT; i += NT) {
+        float* sbw = reinterpret_cast<float*>(smem + SB_OFF);
+        sbw[i] = p.scale[i]; sbw[COUT + i] = p.bias[i]; sbw[2 * COUT + i] = p.rscale[i]; sbw[3 * COUT + i] = p.rbias[i];
+    }
+    f32x2s tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tap[t] = *reinterpret_cast<const f32x2s*>(p.dw + t * CIN + 2 * lane);
+    __syncthreads();
+
+    unsigned char* const At = smem + A_OFF + wave * A_BYTES;
+    const int px = lane & 15, g = lane >> 4;
+    const int a_write = lane * 4;
+    const int a_read = px * AST + g * 16;
+    const float* const sb = reinterpret_cast<const float*>(smem + SB_OFF) + 8 * g;
+    const int wgx = xcd_tile(blockIdx.x, gridDim.x);
+    const int pt = p.H & 1, pl = p.W & 1;               // TensorFlow 'same' padding of the pool in front: 1 for odd sizes
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)((size_t)p.n * p.Ho * p.Wo * COUT * sizeof(T)), 0x00020000);
+
+    for (int it = 0;; ++it) {
+        const int item = __builtin_amdgcn_readfirstlane((it * (int)gridDim.x + wgx) * NW + wave);
+        if (item >= p.items) break;
+        const int strip = item % p.nstrips;
+        const int t1 = item / p.nstrips;
+        const int band = t1 % p.nbands;
+        const int img = t1 / p.nbands;
+        int xo_a, npx, p0, npb;
+        strip_span(strip, p.Wo, p.nstrips, xo_a, npx);   // pooled columns [xo_a, xo_a + npx), npx <= 7
+        band_span(band, p.Ho, p.nbands, p0, npb);        // pooled rows [p0, p0 + npb)
+        const int x0 = 2 * xo_a - pl;                    // convolution column of pixel slot 0 (may be -1)
+        int ys = 2 * p0 - pt;                            // first and last convolution row of the band
+        int ye = 2 * (p0 + npb - 1) - pt + 2;
+        ys = ys < 0 ? 0 : ys;
+        ye = ye > p.H - 1 ? p.H - 1 : ye;
+        const int xl = x0 - 1;
+        unsigned cmask = 0;
+#pragma unroll
+        for (int j = 0; j < NWIN; ++j) cmask |= ((unsigned)(xl + j) < (unsigned)p.W) ? (1u << j) : 0u;
+        const T* const img_in = p.in + ((size_t)img * p.H * p.W + (x0 - 1)) * CIN + 2 * lane;
+        const bool col_out = (unsigned)(x0 + px) >= (unsigned)p.W;      // this slot's column lies outside the image: -inf for the pool
+        // shortcut operand: slot px (odd) needs x at column 2 xo = x0 + px - (1 - pl); even slots read their right neighbour's
+        // pixel (same lines, never used); lane = (slot, k-group g)
+        int xs = x0 + (px | 1) - (1 - pl);
+        xs = xs < 0 ? 0 : (xs > p.W - 1 ? p.W - 1 : xs);
+        const T* const xcol = p.x + ((size_t)img * p.H * p.W + xs) * CX + 8 * g;
+        // pooled output of this lane: odd slots with (px >> 1) < npx
+        const bool lane_out = (px & 1) && (px >> 1) < npx;
+        const unsigned obase = (unsigned)((((size_t)img * p.Ho * p.Wo + xo_a + (px >> 1)) * COUT + 8 * g) * sizeof(T));
+
+        unsigned r0[NWIN], r1[NWIN], r2[NWIN], nx[NWIN];
+        auto load_row = [&](int y, unsigned (&dst)[NWIN]) {
+            const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
+            const T* rp = img_in + (size_t)yc * p.W * CIN;
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) dst[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
+        };
+        auto mask_row = [&](int y, const unsigned (&src)[NWIN], unsigned (&dst)[NWIN]) {
+            const unsigned m = (unsigned)y < (unsigned)p.H ? cmask : 0u;
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) dst[j] = ((m >> j) & 1u) ? src[j] : 0u;
+        };
+        load_row(ys - 1, nx); mask_row(ys - 1, nx, r0);
+        load_row(ys, nx);     mask_row(ys, nx, r1);
+        load_row(ys + 1, nx);
+
+        unsigned VM[4 * NQ];
+#pragma unroll
+        for (int i = 0; i < 4 * NQ; ++i) VM[i] = NEG;
+
+        for (int y = ys; y <= ye; ++y) {
+            // the pooled row this convolution row completes (t even) -- or the next one will (t odd)
+            const int t = y + pt;
+            const bool t_even = (t & 1) == 0;
+            int yo = (t - 1) >> 1;
+            yo = yo < 0 ? 0 : (yo > p.Ho - 1 ? p.Ho - 1 : yo);
+            const bool do_emit = ((t_even && t >= 2) || y == p.H - 1) && yo >= p0;
+            mask_row(y + 1, nx, r2);
+            load_row(y + 2 <= ye + 1 ? y + 2 : ye + 1, nx);
+            uint4 xb[KR];                                 // shortcut operand of pooled row yo: x[2 yo][xs][32 ks + 8 g ..]
+            {
+                const T* xr = xcol + (size_t)(2 * yo) * p.W * CX;
+#pragma unroll
+                for (int ks = 0; ks < KR; ++ks) xb[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
+            }
+            // ---- depthwise 3x3
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                f32x2s a = {0.f, 0.f};
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const unsigned (&r)[NWIN] = dy == 0 ? r0 : (dy == 1 ? r1 : r2);
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) a = __builtin_elementwise_fma(tap[dy * 3 + dx], unpack2<T>(r[x + dx]), a);
+                }
+                *reinterpret_cast<unsigned*>(At + a_write + x * AST) = H16<T>::pack2(a.x, a.y);
+            }
+            // ---- pointwise
+            f32x4 acc[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 b = *reinterpret_cast<const uint4*>(At + a_read + ks * 64);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((ks * NF + f) * 64 + lane) * 16);
+                    acc[f] = mma16<T>(wf, b, acc[f]);
+                }
+            }
+            // ---- folded BN (no ReLU: the block's last convolution), rounded; then the running maximum of the window's rows
+            unsigned cur[4 * NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float4 s0 = *reinterpret_cast<const float4*>(sb + 32 * q);
+                const float4 s1 = *reinterpret_cast<const float4*>(sb + 32 * q + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(sb + COUT + 32 * q);
+                const float4 b1 = *reinterpret_cast<const float4*>(sb + COUT + 32 * q + 4);
+                const f32x4 u = acc[2 * q], v = acc[2 * q + 1];
+                cur[4 * q + 0] = H16<T>::pack2(fmaf(u[0], s0.x, b0.x), fmaf(u[1], s0.y, b0.y));
+                cur[4 * q + 1] = H16<T>::pack2(fmaf(u[2], s0.z, b0.z), fmaf(u[3], s0.w, b0.w));
+                cur[4 * q + 2] = H16<T>::pack2(fmaf(v[0], s1.x, b1.x), fmaf(v[1], s1.y, b1.y));
+                cur[4 * q + 3] = H16<T>::pack2(fmaf(v[2], s1.z, b1.z), fmaf(v[3], s1.w, b1.w));
+            }
+#pragma unroll
+            for (int i = 0; i < 4 * NQ; ++i) {
+                cur[i] = col_out ? NEG : cur[i];
+                VM[i] = pmax2<T>(VM[i], cur[i]);
+            }
+            uint4 po[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) po[q] = make_uint4(0, 0, 0, 0);
+            if (do_emit) {                                // wave-uniform; no memory operation of the vmcnt stream inside
+                // shortcut: D[cout][slot] = Wr[cout][k] x[k][slot]
+                f32x4 ar[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) ar[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const uint4 wf = *reinterpret_cast<const uint4*>(smem + WR_OFF + ((ks * NF + f) * 64 + lane) * 16);
+                        ar[f] = mma16<T>(wf, xb[ks], ar[f]);
+                    }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float4 s0 = *reinterpret_cast<const float4*>(sb + 2 * COUT + 32 * q);
+                    const float4 s1 = *reinterpret_cast<const float4*>(sb + 2 * COUT + 32 * q + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(sb + 3 * COUT + 32 * q);
+                    const float4 b1 = *reinterpret_cast<const float4*>(sb + 3 * COUT + 32 * q + 4);
+                    const f32x4 u = ar[2 * q], v = ar[2 * q + 1];
+                    unsigned res[4];
+                    res[0] = H16<T>::pack2(fmaf(u[0], s0.x, b0.x), fmaf(u[1], s0.y, b0.y));
+                    res[1] = H16<T>::pack2(fmaf(u[2], s0.z, b0.z), fmaf(u[3], s0.w, b0.w));
+                    res[2] = H16<T>::pack2(fmaf(v[0], s1.x, b1.x), fmaf(v[1], s1.y, b1.y));
+                    res[3] = H16<T>::pack2(fmaf(v[2], s1.z, b1.z), fmaf(v[3], s1.w, b1.w));
+                    unsigned o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned c = VM[4 * q + i];
+                        // neighbouring pixel slots = neighbouring lanes of the 16-lane DPP row; row ends keep -inf
+                        const unsigned lft = (unsigned)__builtin_amdgcn_update_dpp((int)NEG, (int)c, 0x111, 0xf, 0xf, false);   // row_shr:1
+                        const unsigned rgt = (unsigned)__builtin_amdgcn_update_dpp((int)NEG, (int)c, 0x101, 0xf, 0xf, false);   // row_shl:1
+                        const unsigned m = pmax2<T>(pmax2<T>(lft, c), rgt);
+                        const f32x2s a = unpack2<T>(m), r = unpack2<T>(res[i]);
+                        o[i] = H16<T>::pack2(a.x + r.x, a.y + r.y);
+                    }
+                    po[q] = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            {
+                const unsigned off = (do_emit && lane_out) ? obase + (unsigned)yo * (unsigned)(p.Wo * COUT * sizeof(T)) : 0xffffff00u;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, po[q]), orsrc, (int)off + 64 * q, 0, 0);
+            }
+            if (t_even) {
+#pragma unroll
+                for (int i = 0; i < 4 * NQ; ++i) VM[i] = cur[i];
+            }
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+        }
+    }
+}
+
+#ifndef TAIL_NW
+#define TAIL_NW 11
+#endif
+
+template <typename T, int CX>
+int launch_tail(TailParams<T> p, int num_cus, hipStream_t s) {
+    constexpr int NW = TAIL_NW;
+    constexpr size_t lds = (size_t)4 * 8 * 1024 + (size_t)(CX / 32) * 8 * 1024 + 4 * 128 * 4 + (size_t)NW * 16 * (128 * 2 + 16);
+    static_assert(lds <= 160 * 1024, "tail kernel LDS budget");
+    auto kern = block_tail_stream_kernel<T, CX, NW>;
+    static BqLdsAttr attr;
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
+    p.Ho = (p.H + 1) / 2; p.Wo = (p.W + 1) / 2;
+    p.nstrips = (p.Wo + 6) / 7;
+    const int waves = num_cus * NW;
+    int nb = (p.Ho + 17) / 18;                       // bands of ~18 pooled rows = ~37 convolution rows (one of them shared)
+    const long long base_items = (long long)p.n * p.nstrips;
+    if (base_items * nb < waves) {
+        nb = (int)((waves + base_items - 1) / base_items);
+        if (nb > p.Ho / 2) nb = p.Ho / 2;
+        if (nb < 1) nb = 1;
+    }
+    p.nbands = nb;
+    p.items = (int)(base_items * nb);
+    int grid = (p.items + NW - 1) / NW;
+    if (grid > num_cus) grid = num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, p);
+    return (int)hipGetLastError();
 }
 
 template <typename T, int CIN, int COUT, bool RELU_IN>
@@ -261,7 +564,30 @@ int launch_stream_t(int cin, int cout, bool relu_in, const void* in, const void*
 
 bool stream_supported(int dtype, int cin, int cout, bool relu_in, long long n, int H, int W) {
     return dtype != 0 && !relu_in && cout == 128 && (cin == 64 || cin == 128) && H >= 4 && W >= 1 &&
-           n * H * W * (long long)cout * 2 < 0xfffffff0ll;
+           n * H * W * (long long)cout * 2 <= 0xffffff00ll;
+}
+
+bool tail_supported(int dtype, int cin, int cout, int cx, long long n, int H, int W) {
+    return dtype != 0 && cin == 128 && cout == 128 && cx == 64 && H >= 8 && W >= 8 &&
+           n * H * W * (long long)cin * 2 <= 0xffffff00ll;
+}
+
+// out = maxpool3x3/s2(BN(sepconv2(y1))) + BN(conv1x1/s2(x)); wp16 / wr16: "<sepconv2>/wp16", "<res>/wp16"
+int launch_block_tail(int dtype, int cin, int cout, int cx, const void* y1, const void* wp16, const float* dw,
+                      const float* scale, const float* bias, const void* x, const void* wr16, const float* rscale,
+                      const float* rbias, void* out, int n, int H, int W, int num_cus, hipStream_t s) {
+    if (!tail_supported(dtype, cin, cout, cx, n, H, W)) return (int)hipErrorInvalidValue;
+    auto go = [&](auto tag) {
+        typedef decltype(tag) T;
+        TailParams<T> p;
+        p.in = reinterpret_cast<const T*>(y1); p.wp16 = reinterpret_cast<const uint4*>(wp16); p.dw = dw;
+        p.scale = scale; p.bias = bias;
+        p.x = reinterpret_cast<const T*>(x); p.wr16 = reinterpret_cast<const uint4*>(wr16); p.rscale = rscale; p.rbias = rbias;
+        p.out = reinterpret_cast<T*>(out);
+        p.n = n; p.H = H; p.W = W; p.Ho = p.Wo = p.nstrips = p.nbands = p.items = 0;
+        return launch_tail<T, 64>(p, num_cus, s);
+    };
+    return dtype == 2 ? go(f16_t{}) : go(bf16_t{});
 }
 
 int launch_sepconv_stream(int dtype, int cin, int cout, bool relu_in, const void* in, const void* wp16, const float* dw,

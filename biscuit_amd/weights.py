@@ -288,6 +288,7 @@ def wide_layers():
 
 # kernels_stream.hip (round 4): the 147x147 separable convolutions of block 2 take the same 16x16x32 fragment order
 STREAM_LAYERS = ('block2_sepconv1', 'block2_sepconv2')
+TAIL_RES_LAYERS = ('block2_res',)
 
 
 def fold_bn(w, name):
@@ -336,6 +337,8 @@ def pack_blob(w, dtype='bf16'):
             # in one kernel (blocks 2 and 3; the wider shortcuts measured faster as two kernels)
             add(name + '/wp32', to_bits(pack_fragments32(w[name + '_conv/kernel'].reshape(cin, cout),
                                                                   pad_channels(cin), npad)))
+        if half and name in TAIL_RES_LAYERS:          # kernels_stream.hip: the shortcut inside the fused block tail
+            add(name + '/wp16', to_bits(pack_fragments16(w[name + '_conv/kernel'].reshape(cin, cout), pad_channels(cin), npad)))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)
     wide = set(wide_layers())

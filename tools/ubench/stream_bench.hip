@@ -1,0 +1,71 @@
+// Standalone timing harness of csrc/kernels_stream.hip (GPU only): random input, 128 -> 128 and 64 -> 128 @147x147 at batch
+// 256, HIP events over 20 launches, a checksum of the output (variants that only change the schedule must agree), and a
+// plain 16-byte copy of the same bytes as the box's calibration.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSTREAM_NW=16 -DSTREAM_ABL=1 ...] -o stream_bench stream_bench.hip
+#include "../../biscuit_amd/csrc/kernels_stream.hip"
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void copy16(const uint4* __restrict__ a, uint4* __restrict__ b, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+__global__ void fill_rand(unsigned short* p, size_t n, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const float v = ((h & 0xffff) / 65536.0f - 0.5f) * 4.0f;
+        p[i] = __builtin_bit_cast(unsigned short, (_Float16)v);
+    }
+}
+__global__ void checksum(const unsigned* p, size_t n, unsigned long long* out) {
+    unsigned long long s = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += p[i] * (unsigned long long)(i % 1000003 + 1);
+    atomicAdd(out, s);
+}
+
+int main(int argc, char** argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 256, H = 147, W = 147;
+    const char* tag = argc > 2 ? argv[2] : "";
+    const size_t px = (size_t)n * H * W;
+    unsigned short *in, *out; uint4* wp; float *dw, *sc, *bi; unsigned long long* cs;
+    CK(hipMalloc(&in, px * 128 * 2 + 8192)); CK(hipMalloc(&out, px * 128 * 2)); CK(hipMalloc(&wp, 32768)); CK(hipMalloc(&dw, 9 * 128 * 4));
+    CK(hipMalloc(&sc, 512)); CK(hipMalloc(&bi, 512)); CK(hipMalloc(&cs, 8));
+    in += 2048;   // front pad
+    fill_rand<<<2048, 256>>>(in, px * 128, 1);
+    fill_rand<<<64, 256>>>((unsigned short*)wp, 16384, 2);
+    {
+        std::vector<float> h(9 * 128), s(128), b(128);
+        for (int i = 0; i < 9 * 128; ++i) h[i] = ((i * 37 % 101) / 101.0f - 0.5f) * 0.6f;
+        for (int i = 0; i < 128; ++i) { s[i] = 0.2f + (i % 7) * 0.01f; b[i] = (i % 5) * 0.1f - 0.2f; }
+        CK(hipMemcpy(dw, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(sc, s.data(), 512, hipMemcpyHostToDevice)); CK(hipMemcpy(bi, b.data(), 512, hipMemcpyHostToDevice));
+    }
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int cin : {128, 64}) {
+        const double gb = (double)px * (cin + 128) * 2 / 1e9;
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int i = 0; i < 3; ++i) if (launch_sepconv_stream(2, cin, 128, false, in, wp, dw, sc, bi, out, n, H, W, 1, 256, 0)) { printf("launch failed\n"); return 1; }
+            CK(hipEventRecord(a));
+            for (int i = 0; i < 20; ++i) launch_sepconv_stream(2, cin, 128, false, in, wp, dw, sc, bi, out, n, H, W, 1, 256, 0);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
+            CK(hipMemset(cs, 0, 8));
+            checksum<<<1024, 256>>>((const unsigned*)out, px * 64, cs);
+            unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
+            printf("%-28s cin %3d: %.4f ms  %.0f GB/s  checksum %016llx\n", tag, cin, ms, gb / ms * 1e3, h);
+        }
+    }
+    {   // calibration: copy of 1.42 GB (read + write 2.83 GB)
+        const size_t n16 = px * 128 * 2 / 16;
+        for (int i = 0; i < 3; ++i) copy16<<<256 * 8, 256>>>((const uint4*)in, (uint4*)out, n16);
+        CK(hipEventRecord(a));
+        for (int i = 0; i < 20; ++i) copy16<<<256 * 8, 256>>>((const uint4*)in, (uint4*)out, n16);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
+        printf("%-28s copy16 of the same bytes: %.4f ms  %.0f GB/s\n", tag, ms, (double)n16 * 32 / 1e9 / ms * 1e3);
+    }
+    return 0;
+}
