@@ -1,37 +1,162 @@
-// Streaming separable-convolution kernel for the big, HBM-bound entry-flow layers (block 2 at 147x147: 64 -> 128 and
-// 128 -> 128; block 3 at 74x74: 128 -> 256), 16-bit storage, round 4.
+// Streaming separable-convolution kernels for the big, HBM-bound entry-flow layers (block 2 at 147x147: 64 -> 128,
+// 128 -> 128 and the block's fused tail), 16-bit storage, round 4.
 //
 // The tile kernels these layers ran on (kernels_tile.hip) are one fat workgroup per CU that walks barrier-separated
 // phases -- halo registers -> LDS, barrier, depthwise, matrix stage, staged epilogue -- so all 256 CUs load, compute and
 // store in lock step and nothing overlaps (3.4-4.2 TB/s).  Here every WAVE is an independent worker and there is no
 // workgroup barrier after the weights have been copied to LDS:
-//  * a work item is a vertical strip of an image: <= 16 output columns x a band of ~25 rows.  The wave walks DOWN the
-//    strip one output row per step.
-//  * lane = channel pair.  The 3-row window of the depthwise convolution lives in REGISTERS as packed 16-bit pairs
-//    (3 x 18 dwords): a step fetches ONE new input row of 18 pixels with coalesced `global_load_dword`s (64 lanes x 4 B =
-//    the 256 contiguous bytes of a 128-channel pixel), one step ahead of its use.  No halo image in LDS, no staging pass,
-//    every input row of a strip is read once (17/15 columns per output column; rows 27/25).
-//  * the 16 depthwise results of a step (fp32 taps and accumulation, the tap order of the tile kernels, rounded to the
-//    storage type) go to a 4 KB wave-private A tile in LDS -- the transposition from (lane = channel pair) to the MFMA
-//    operand (lane = pixel, 8 consecutive channels) -- and come back as the B operand of v_mfma_f32_16x16x32
-//    (D[cout][pixel]); the weights (A operand, 16x16x32 fragment order with interleaved fragment pairs: "<layer>/wp16")
-//    sit in LDS once per workgroup.
+//  * a work item is a vertical strip of an image: <= 16 output columns x a band of rows.  The wave walks DOWN the strip
+//    one output row per step.
+//  * lane = channel pair.  A step fetches ONE new input row of 18 pixels with coalesced `global_load_dword`s (64 lanes x
+//    4 B = the 256 contiguous bytes of a 128-channel pixel), one step ahead of its use.  No halo image in LDS, no staging
+//    pass, every input row of a strip is read once (18 columns per <= 16 output columns).
+//  * depthwise 3x3 as RUNNING PARTIAL SUMS in registers: for every column of the strip a lane keeps sa = the taps of
+//    rows y-1 and y already applied, sb = the taps of row y applied for the NEXT output row.  The new row is converted to
+//    fp32 once (not once per output row it takes part in) and pushed: out(y) = sa + taps2 . row, sa' = sb + taps1 . row,
+//    sb' = taps0 . row -- nine fp32 fmas per output in exactly the order of the tile kernels' tap loop (dy-major, from
+//    0.0f), so the results are bit-identical to them; no 3-row window to rotate.
+//  * the 16 results of a step, rounded to the storage type, go to a 4 KB wave-private A tile in LDS -- the transposition
+//    from (lane = channel pair) to the MFMA operand (lane = pixel, 8 consecutive channels) -- and come back as the B
+//    operand of v_mfma_f32_16x16x32 (D[cout][pixel]); the weights (A operand, 16x16x32 fragment order with interleaved
+//    fragment pairs: "<layer>/wp16") sit in LDS once per workgroup.
 //  * epilogue straight from the accumulators: with the pair interleave a lane holds 8 consecutive channels of its pixel
 //    per fragment pair -> folded BN, ReLU, one 16-byte store; a pair's store covers 64 contiguous bytes of 16 pixels.
-//  * 12 waves per CU (3 per SIMD, <= 168 registers) drift apart by themselves: one wave's loads and stores run under
+//  * 12 waves per CU (3 per SIMD, <= 168 registers; the fused tail: 8, its 240 registers spill at 168 and spills in the vmcnt
+//    stream cost 2x) drift apart by themselves: one wave's loads and stores run under
 //    the others' depthwise and matrix work.
 #include "gemm_common.h"
 
 // ablation switches of tools/ubench/stream_bench.hip (timing only, wrong results): 1 no stores, 2 no depthwise arithmetic,
-// 4 no MFMAs, 8 no input loads.  The product build has none of them.
+// 4 no MFMAs, 8 no input loads, 16 no pooling / shortcut.  The product build has none of them.
 #ifndef STREAM_ABL
 #define STREAM_ABL 0
+#endif
+#ifndef STREAM_NW
+#define STREAM_NW 12
+#endif
+#ifndef TAIL_NW
+#define TAIL_NW 8
 #endif
 
 namespace {
 using namespace bqk;
 
 typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2s __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c);
+template <> __device__ __forceinline__ f32x4 mma16<f16_t>(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma16<bf16_t>(const uint4& a, const uint4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// halves of a packed dword as an fp32 pair, by plain conversions (the asm forms of H16<> cost an s_nop each here: hipcc pads
+// every asm result it cannot see the latency of)
+template <typename T> __device__ __forceinline__ f32x2s unpack2(unsigned u);
+template <> __device__ __forceinline__ f32x2s unpack2<f16_t>(unsigned u) {
+    return __builtin_convertvector(__builtin_bit_cast(h16x2s, u), f32x2s);
+}
+template <> __device__ __forceinline__ f32x2s unpack2<bf16_t>(unsigned u) {
+    return (f32x2s){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+
+// maximum of two packed pairs (exact: a maximum rounds nothing).  f16: ONE v_pk_max_f16 -- through
+// __builtin_elementwise_max hipcc canonicalises both operands first, three instructions
+template <typename T> __device__ __forceinline__ unsigned pmax2(unsigned a, unsigned b);
+template <> __device__ __forceinline__ unsigned pmax2<f16_t>(unsigned a, unsigned b) {
+    unsigned d;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+template <> __device__ __forceinline__ unsigned pmax2<bf16_t>(unsigned a, unsigned b) {
+    const f32x2s x = unpack2<bf16_t>(a), y = unpack2<bf16_t>(b);
+    return H16<bf16_t>::pack2(fmaxf(x.x, y.x), fmaxf(x.y, y.y));
+}
+template <typename T> struct NegInf;
+template <> struct NegInf<f16_t> { static constexpr unsigned v = 0xfc00fc00u; };
+template <> struct NegInf<bf16_t> { static constexpr unsigned v = 0xff80ff80u; };
+
+// first element and length of part s when n elements are cut into ns parts of nearly equal length
+__device__ __forceinline__ void strip_span(int s, int n, int ns, int& x0, int& nc) {
+    const int base = n / ns, rem = n - base * ns;
+    x0 = s * base + (s < rem ? s : rem);
+    nc = base + (s < rem ? 1 : 0);
+}
+
+// ---- depthwise 3x3 of one strip as running partial sums --------------------------------------------------------------
+// NCOL output columns per lane, window columns j = 0 .. NCOL + 1 (column j is output column j - 1's left neighbour).
+// push(row): row = the packed input row y + 1, already masked to zero where it lies outside the image.
+//   OUT:  out(y)[x] = sa[x] + taps(2, .) . row[x ..]  -> rounded, written to the A tile (one ds_write_b32 per column)
+//   then  sa[x] = sb[x] + taps(1, .) . row[x ..],  sb[x] = 0 + taps(0, .) . row[x ..]
+// Tap order per output: (0,0) (0,1) (0,2) (1,0) ... (2,2), each `a = fma(tap, v, a)` from 0.0f: the tile kernels' order.
+template <typename T, int NCOL>
+struct DwSums {
+    f32x2s sa[NCOL], sb[NCOL];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int x = 0; x < NCOL; ++x) { sa[x] = (f32x2s){0.f, 0.f}; sb[x] = (f32x2s){0.f, 0.f}; }
+    }
+    template <bool OUT>
+    __device__ __forceinline__ void push(const f32x2s (&tap)[9], const unsigned (&row)[NCOL + 2], unsigned char* a_lane, int ast) {
+        f32x2s v[NCOL + 2];
+#pragma unroll
+        for (int j = 0; j < NCOL + 2; ++j) v[j] = unpack2<T>(row[j]);
+#pragma unroll
+        for (int x = 0; x < NCOL; ++x) {
+            if constexpr (OUT) {
+                f32x2s o = sa[x];
+                if constexpr (STREAM_ABL & 2) o = v[x + 1];
+                else
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) o = __builtin_elementwise_fma(tap[6 + dx], v[x + dx], o);
+                *reinterpret_cast<unsigned*>(a_lane + x * ast) = H16<T>::pack2(o.x, o.y);
+            }
+            if constexpr (!(STREAM_ABL & 2)) {
+                f32x2s a = sb[x];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) a = __builtin_elementwise_fma(tap[3 + dx], v[x + dx], a);
+                sa[x] = a;
+                f32x2s b = {0.f, 0.f};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) b = __builtin_elementwise_fma(tap[dx], v[x + dx], b);
+                sb[x] = b;
+            }
+        }
+    }
+};
+
+// ---- pointwise: D[cout][pixel] = W[cout][k] * A[pixel][k] from the wave's A tile (LDS operations of a wave complete in order)
+template <typename T, int KS, int NF>
+__device__ __forceinline__ void pointwise(const unsigned char* smem_w, const unsigned char* a_read, int lane, f32x4 (&acc)[NF]) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const uint4 b = *reinterpret_cast<const uint4*>(a_read + ks * 64);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const uint4 wf = *reinterpret_cast<const uint4*>(smem_w + ((ks * NF + f) * 64 + lane) * 16);
+            if constexpr (STREAM_ABL & 4) { acc[f][0] += __uint_as_float(wf.x ^ b.x); acc[f][1] += __uint_as_float(wf.y ^ b.y); }
+            else acc[f] = mma16<T>(wf, b, acc[f]);
+        }
+    }
+}
+
+// folded BN of fragment pair q: lane (pixel px, group g) holds channels 32 q + 8 g .. + 7; sbq = scale + 8 g (bias at + nb)
+template <typename T>
+__device__ __forceinline__ void bn_pair(const f32x4& u, const f32x4& v, const float* sbq, int nb, unsigned (&o)[4]) {
+    const float4 s0 = *reinterpret_cast<const float4*>(sbq);
+    const float4 s1 = *reinterpret_cast<const float4*>(sbq + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(sbq + nb);
+    const float4 b1 = *reinterpret_cast<const float4*>(sbq + nb + 4);
+    o[0] = H16<T>::pack2(fmaf(u[0], s0.x, b0.x), fmaf(u[1], s0.y, b0.y));
+    o[1] = H16<T>::pack2(fmaf(u[2], s0.z, b0.z), fmaf(u[3], s0.w, b0.w));
+    o[2] = H16<T>::pack2(fmaf(v[0], s1.x, b1.x), fmaf(v[1], s1.y, b1.y));
+    o[3] = H16<T>::pack2(fmaf(v[2], s1.z, b1.z), fmaf(v[3], s1.w, b1.w));
+}
 
 template <typename T>
 struct StreamParams {
@@ -46,33 +171,6 @@ struct StreamParams {
     int items;             // n * nbands * nstrips
     int relu;
 };
-
-template <typename T> __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, const f32x4& c);
-template <> __device__ __forceinline__ f32x4 mma16<f16_t>(const uint4& a, const uint4& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x4 mma16<bf16_t>(const uint4& a, const uint4& b, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// halves of a packed dword as an fp32 pair, by plain conversions (the asm forms of H16<> cost an s_nop each here: hipcc pads
-// every asm result it cannot see the latency of)
-typedef _Float16 h16x2s __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-template <typename T> __device__ __forceinline__ f32x2s unpack2(unsigned u);
-template <> __device__ __forceinline__ f32x2s unpack2<f16_t>(unsigned u) {
-    return __builtin_convertvector(__builtin_bit_cast(h16x2s, u), f32x2s);
-}
-template <> __device__ __forceinline__ f32x2s unpack2<bf16_t>(unsigned u) {
-    return (f32x2s){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-}
-
-// first column and width of strip s when W columns are cut into ns strips of nearly equal width (<= 16)
-__device__ __forceinline__ void strip_span(int s, int W, int ns, int& x0, int& nc) {
-    const int base = W / ns, rem = W - base * ns;
-    x0 = s * base + (s < rem ? s : rem);
-    nc = base + (s < rem ? 1 : 0);
-}
 
 template <typename T, int CIN, int COUT, bool RELU_IN, int NW>
 __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamParams<T> p) {
@@ -107,8 +205,8 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
 
     unsigned char* const At = smem + A_OFF + wave * A_BYTES;
     const int px = lane & 15, g = lane >> 4;
-    const int a_write = (chalf * NCOL) * AST + cpair * 4;
-    const int a_read = px * AST + g * 16;
+    unsigned char* const a_lane = At + (chalf * NCOL) * AST + cpair * 4;
+    const unsigned char* const a_read = At + px * AST + g * 16;
     const float* const sb = reinterpret_cast<const float*>(smem + SB_OFF) + 8 * g;
     const unsigned lo2 = p.relu ? 0u : 0x80008000u;     // ReLU = packed signed 16-bit max with 0 (0x8000: no-op)
     const int wgx = xcd_tile(blockIdx.x, gridDim.x);
@@ -129,110 +227,76 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
         strip_span(band, p.H, p.nbands, y0, nr);
         const int y1 = y0 + nr;
         // window column j of this lane is image column xl + j; outside [0, W) it reads as zero ('same' padding); columns
-        // past the strip's own 16 + 1 are never used for a stored pixel
+        // past the strip's own 16 + 1 are never used for a stored pixel.  Column -1 of an image's first row and the columns
+        // behind its last row's end are read (and masked) from the bytes next to the tensor: the workspace is padded.
         const int xl = x0 - 1 + chalf * NCOL;
         unsigned cmask = 0;
 #pragma unroll
         for (int j = 0; j < NWIN; ++j) cmask |= ((unsigned)(xl + j) < (unsigned)p.W) ? (1u << j) : 0u;
         const T* const img_in = p.in + ((size_t)img * p.H * p.W + (x0 - 1)) * CIN + lane_el;
 
-        unsigned r0[NWIN], r1[NWIN], r2[NWIN], nx[NWIN];
-        auto load_row = [&](int y, unsigned (&dst)[NWIN]) {        // row clamped into the image: always valid memory
+        unsigned nx[NWIN], row[NWIN];
+        auto load_row = [&](int y) {                       // row clamped into the image: always valid memory
             const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
             const T* rp = img_in + (size_t)yc * p.W * CIN;
 #pragma unroll
             for (int j = 0; j < NWIN; ++j) {
-                if constexpr (STREAM_ABL & 8) dst[j] = (unsigned)(size_t)rp + j;
-                else dst[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
+                if constexpr (STREAM_ABL & 8) nx[j] = (unsigned)(size_t)rp + j;
+                else nx[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
             }
         };
-        auto mask_row = [&](int y, const unsigned (&src)[NWIN], unsigned (&dst)[NWIN]) {
+        auto take_row = [&](int y) {                       // nx (row y) -> row, zero outside the image, ReLU of the layer in front
             const unsigned m = (unsigned)y < (unsigned)p.H ? cmask : 0u;
 #pragma unroll
             for (int j = 0; j < NWIN; ++j) {
-                unsigned v = ((m >> j) & 1u) ? src[j] : 0u;
+                unsigned v = ((m >> j) & 1u) ? nx[j] : 0u;
                 if (RELU_IN) v = relu_pk16(v);
-                dst[j] = v;
+                row[j] = v;
             }
         };
-        load_row(y0 - 1, nx); mask_row(y0 - 1, nx, r0);
-        load_row(y0, nx);     mask_row(y0, nx, r1);
-        load_row(y0 + 1, nx);
+        DwSums<T, NCOL> dws;
+        dws.clear();
+        load_row(y0 - 1); take_row(y0 - 1);
+        load_row(y0);
+        dws.template push<false>(tap, row, a_lane, AST);   // (only sb of this push is used)
+        take_row(y0);
+        load_row(y0 + 1);
+        dws.template push<false>(tap, row, a_lane, AST);
 
         // Stores are raw buffer stores: a lane whose pixel lies outside the strip gets an offset beyond the buffer and the
         // hardware drops its store.  Under `if (px < nc)` hipcc cannot count the stores in vmcnt any more and the wait for
-        // the next input row becomes a wait for this row's stores as well (vmcnt retires in order).
-        unsigned ooff = px < nc ? (unsigned)(((((size_t)img * p.H + y0) * p.W + x0 + px) * COUT + 8 * g) * sizeof(T)) : 0xffffff00u;   // (+ 64 q stays below 2^32: the offset sum wraps there)
+        // the next input row becomes a wait for this row's stores as well (vmcnt retires in order).  (+ 64 q must stay
+        // below 2^32: the offset sum wraps there.)
+        unsigned ooff = px < nc ? (unsigned)(((((size_t)img * p.H + y0) * p.W + x0 + px) * COUT + 8 * g) * sizeof(T)) : 0xffffff00u;
         const unsigned ostep = px < nc ? (unsigned)((size_t)p.W * COUT * sizeof(T)) : 0u;
         for (int y = y0; y < y1; ++y, ooff += ostep) {
-            mask_row(y + 1, nx, r2);
-            // the row after next, one whole step ahead of its use (the last step re-reads row y1: an L2 hit, branch-free)
-            load_row(y + 2 < y1 ? y + 2 : y1, nx);
-
-            // ---- depthwise 3x3: nine tap pairs in registers, window in registers
-#pragma unroll
-            for (int x = 0; x < NCOL; ++x) {
-                f32x2s a = {0.f, 0.f};
-                if constexpr (STREAM_ABL & 2) a = unpack2<T>(r0[x] ^ r1[x + 1] ^ r2[x + 2]);
-                else
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const unsigned (&r)[NWIN] = dy == 0 ? r0 : (dy == 1 ? r1 : r2);
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const unsigned u = r[x + dx];
-                        a = __builtin_elementwise_fma(tap[dy * 3 + dx], unpack2<T>(u), a);
-                    }
-                }
-                *reinterpret_cast<unsigned*>(At + a_write + x * AST) = H16<T>::pack2(a.x, a.y);
-            }
-            // ---- pointwise: D[cout][pixel] += W[cout][k] * A[pixel][k] (LDS operations of a wave complete in order)
+            take_row(y + 1);
+            // the row after next, one step ahead of its use (the last step re-reads row y1: an L2 hit, branch-free)
+            load_row(y + 2 < y1 ? y + 2 : y1);
+            dws.template push<true>(tap, row, a_lane, AST);
             f32x4 acc[NF];
-#pragma unroll
-            for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const uint4 b = *reinterpret_cast<const uint4*>(At + a_read + ks * 64);
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((ks * NF + f) * 64 + lane) * 16);
-                    if constexpr (STREAM_ABL & 4) { acc[f][0] += __uint_as_float(wf.x ^ b.x); acc[f][1] += __uint_as_float(wf.y ^ b.y); }
-                    else acc[f] = mma16<T>(wf, b, acc[f]);
-                }
-            }
-            // ---- epilogue: lane (pixel px, group g) holds channels 32 q + 8 g .. + 7 of fragment pair q
+            pointwise<T, KS, NF>(smem, a_read, lane, acc);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const float4 s0 = *reinterpret_cast<const float4*>(sb + 32 * q);
-                const float4 s1 = *reinterpret_cast<const float4*>(sb + 32 * q + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(sb + COUT + 32 * q);
-                const float4 b1 = *reinterpret_cast<const float4*>(sb + COUT + 32 * q + 4);
-                const f32x4 u = acc[2 * q], v = acc[2 * q + 1];
-                uint4 o;
-                o.x = H16<T>::pack2(fmaf(u[0], s0.x, b0.x), fmaf(u[1], s0.y, b0.y));
-                o.y = H16<T>::pack2(fmaf(u[2], s0.z, b0.z), fmaf(u[3], s0.w, b0.w));
-                o.z = H16<T>::pack2(fmaf(v[0], s1.x, b1.x), fmaf(v[1], s1.y, b1.y));
-                o.w = H16<T>::pack2(fmaf(v[2], s1.z, b1.z), fmaf(v[3], s1.w, b1.w));
-                asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.x) : "v"(o.x), "v"(lo2));
-                asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.y) : "v"(o.y), "v"(lo2));
-                asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.z) : "v"(o.z), "v"(lo2));
-                asm("v_pk_max_i16 %0, %1, %2" : "=v"(o.w) : "v"(o.w), "v"(lo2));
-                if constexpr (STREAM_ABL & 1) { if (o.x == 0x12345678u && o.y == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), orsrc, (int)ooff + 64 * q, 0, 0); }
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), orsrc, (int)ooff + 64 * q, 0, 0);
-            }
+                unsigned o[4];
+                bn_pair<T>(acc[2 * q], acc[2 * q + 1], sb + 32 * q, COUT, o);
 #pragma unroll
-            for (int j = 0; j < NWIN; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
+                for (int i = 0; i < 4; ++i) asm("v_pk_max_i16 %0, %1, %2" : "=v"(o[i]) : "v"(o[i]), "v"(lo2));
+                const u32x4s ov = {o[0], o[1], o[2], o[3]};
+                if constexpr (STREAM_ABL & 1) { if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u) __builtin_amdgcn_raw_buffer_store_b128(ov, orsrc, (int)ooff + 64 * q, 0, 0); }
+                else __builtin_amdgcn_raw_buffer_store_b128(ov, orsrc, (int)ooff + 64 * q, 0, 0);
+            }
         }
     }
 }
 
-
 // ------------------------------------------------------------------------------------------------------------------------
-// Block tail in one kernel (round 4): out = MaxPool3x3/s2 'same'(BN(sepconv2(y1))) + BN(Conv1x1/s2(x)).
+// Block tail in one kernel: out = MaxPool3x3/s2 'same'(BN(sepconv2(y1))) + BN(Conv1x1/s2(x)).
 //
 // The second separable convolution of an entry-flow block is only ever read by the block's max-pool: written and read
-// back it is 2 x 1.42 GB of the 4.8 GB that block 2's sepconv2 + pool/shortcut kernel pair move.  On the streaming structure the pool
-// is incremental and needs no tile-sized staging (the 16x16-tile form of round 3 lost to its serialised phases):
+// back it is 2 x 1.42 GB of the 4.8 GB that block 2's sepconv2 + pool/shortcut kernel pair move.  On the streaming
+// structure the pool is incremental and needs no tile-sized staging (the 16x16-tile form of round 3 lost to its
+// serialised phases):
 //  * a strip owns <= 7 POOLED columns = 15 convolution columns (window columns 2xo-pl .. 2xo-pl+2 overlap by one, so
 //    strips overlap by one column: 16 MFMA pixel slots per 14 new columns), a band owns a run of pooled rows;
 //  * a row step produces one convolution row in the accumulator layout (lane = pixel slot px, 8 channels per fragment
@@ -260,33 +324,20 @@ struct TailParams {
     int nstrips, nbands, items;
 };
 
-template <typename T> __device__ __forceinline__ unsigned pmax2(unsigned a, unsigned b);
-template <> __device__ __forceinline__ unsigned pmax2<f16_t>(unsigned a, unsigned b) {   // one v_pk_max_f16 (exact: a maximum rounds nothing)
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(h16x2s, a), __builtin_bit_cast(h16x2s, b)));
-}
-template <> __device__ __forceinline__ unsigned pmax2<bf16_t>(unsigned a, unsigned b) {
-    const f32x2s x = unpack2<bf16_t>(a), y = unpack2<bf16_t>(b);
-    return H16<bf16_t>::pack2(fmaxf(x.x, y.x), fmaxf(x.y, y.y));
-}
-template <typename T> struct NegInf;
-template <> struct NegInf<f16_t> { static constexpr unsigned v = 0xfc00fc00u; };
-template <> struct NegInf<bf16_t> { static constexpr unsigned v = 0xff80ff80u; };
-
 // pooled rows [p0, p0 + np) of band b when Ho rows are cut into nb bands: the first and the last band end at the image
 // border (one convolution row fewer than 2 np + 1), so the remainder goes to them first
 __device__ __forceinline__ void band_span(int b, int Ho, int nb, int& p0, int& np) {
     const int base = Ho / nb, rem = Ho - base * nb;
     const int lo = (rem + 1) / 2, hi = rem / 2;           // bands [0, lo) and [nb - hi, nb) take one more
-    auto extra = [&](int i) { return (i < lo || i >= nb - hi) ? 1 : 0; };
     p0 = b * base + (b < lo ? b : lo) + (b > nb - hi ? b - (nb - hi) : 0);
-    np = base + extra(b);
+    np = base + ((b < lo || b >= nb - hi) ? 1 : 0);
 }
 
 template <typename T, int CX, int NW>
 __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailParams<T> p) {
     if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int NT = NW * 64;
-    constexpr int CIN = 128, COUT = 128, KS = CIN / 32, NF = COUT / 16, NQ = COUT / 32, NWIN = 18;
+    constexpr int CIN = 128, COUT = 128, KS = CIN / 32, NF = COUT / 16, NQ = COUT / 32, NCOL = 16, NWIN = NCOL + 2;
     constexpr int KR = CX / 32;
     constexpr int AST = CIN * 2 + 16;
     constexpr int W_BYTES = KS * NF * 1024, WR_BYTES = KR * NF * 1024;
@@ -312,8 +363,8 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
 
     unsigned char* const At = smem + A_OFF + wave * A_BYTES;
     const int px = lane & 15, g = lane >> 4;
-    const int a_write = lane * 4;
-    const int a_read = px * AST + g * 16;
+    unsigned char* const a_lane = At + lane * 4;
+    const unsigned char* const a_read = At + px * AST + g * 16;
     const float* const sb = reinterpret_cast<const float*>(smem + SB_OFF) + 8 * g;
     const int wgx = xcd_tile(blockIdx.x, gridDim.x);
     const int pt = p.H & 1, pl = p.W & 1;               // TensorFlow 'same' padding of the pool in front: 1 for odd sizes
@@ -341,6 +392,7 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
         for (int j = 0; j < NWIN; ++j) cmask |= ((unsigned)(xl + j) < (unsigned)p.W) ? (1u << j) : 0u;
         const T* const img_in = p.in + ((size_t)img * p.H * p.W + (x0 - 1)) * CIN + 2 * lane;
         const bool col_out = (unsigned)(x0 + px) >= (unsigned)p.W;      // this slot's column lies outside the image: -inf for the pool
+        const bool any_col_out = x0 < 0 || x0 + 15 >= p.W;              // (wave-uniform)
         // shortcut operand: slot px (odd) needs x at column 2 xo = x0 + px - (1 - pl); even slots read their right neighbour's
         // pixel (same lines, never used); lane = (slot, k-group g)
         int xs = x0 + (px | 1) - (1 - pl);
@@ -350,21 +402,29 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
         const bool lane_out = (px & 1) && (px >> 1) < npx;
         const unsigned obase = (unsigned)((((size_t)img * p.Ho * p.Wo + xo_a + (px >> 1)) * COUT + 8 * g) * sizeof(T));
 
-        unsigned r0[NWIN], r1[NWIN], r2[NWIN], nx[NWIN];
-        auto load_row = [&](int y, unsigned (&dst)[NWIN]) {
+        unsigned nx[NWIN], row[NWIN];
+        auto load_row = [&](int y) {
             const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
             const T* rp = img_in + (size_t)yc * p.W * CIN;
 #pragma unroll
-            for (int j = 0; j < NWIN; ++j) dst[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
+            for (int j = 0; j < NWIN; ++j) {
+                if constexpr (STREAM_ABL & 8) nx[j] = (unsigned)(size_t)rp + j;
+                else nx[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
+            }
         };
-        auto mask_row = [&](int y, const unsigned (&src)[NWIN], unsigned (&dst)[NWIN]) {
+        auto take_row = [&](int y) {
             const unsigned m = (unsigned)y < (unsigned)p.H ? cmask : 0u;
 #pragma unroll
-            for (int j = 0; j < NWIN; ++j) dst[j] = ((m >> j) & 1u) ? src[j] : 0u;
+            for (int j = 0; j < NWIN; ++j) row[j] = ((m >> j) & 1u) ? nx[j] : 0u;
         };
-        load_row(ys - 1, nx); mask_row(ys - 1, nx, r0);
-        load_row(ys, nx);     mask_row(ys, nx, r1);
-        load_row(ys + 1, nx);
+        DwSums<T, NCOL> dws;
+        dws.clear();
+        load_row(ys - 1); take_row(ys - 1);
+        load_row(ys);
+        dws.template push<false>(tap, row, a_lane, AST);
+        take_row(ys);
+        load_row(ys + 1);
+        dws.template push<false>(tap, row, a_lane, AST);
 
         unsigned VM[4 * NQ];
 #pragma unroll
@@ -377,62 +437,37 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
             int yo = (t - 1) >> 1;
             yo = yo < 0 ? 0 : (yo > p.Ho - 1 ? p.Ho - 1 : yo);
             const bool do_emit = ((t_even && t >= 2) || y == p.H - 1) && yo >= p0;
-            mask_row(y + 1, nx, r2);
-            load_row(y + 2 <= ye + 1 ? y + 2 : ye + 1, nx);
+            take_row(y + 1);
+            load_row(y + 2 <= ye + 1 ? y + 2 : ye + 1);
             uint4 xb[KR];                                 // shortcut operand of pooled row yo: x[2 yo][xs][32 ks + 8 g ..]
             {
                 const T* xr = xcol + (size_t)(2 * yo) * p.W * CX;
 #pragma unroll
                 for (int ks = 0; ks < KR; ++ks) xb[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
             }
-            // ---- depthwise 3x3
-#pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                f32x2s a = {0.f, 0.f};
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const unsigned (&r)[NWIN] = dy == 0 ? r0 : (dy == 1 ? r1 : r2);
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) a = __builtin_elementwise_fma(tap[dy * 3 + dx], unpack2<T>(r[x + dx]), a);
-                }
-                *reinterpret_cast<unsigned*>(At + a_write + x * AST) = H16<T>::pack2(a.x, a.y);
-            }
-            // ---- pointwise
+            dws.template push<true>(tap, row, a_lane, AST);
             f32x4 acc[NF];
-#pragma unroll
-            for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const uint4 b = *reinterpret_cast<const uint4*>(At + a_read + ks * 64);
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const uint4 wf = *reinterpret_cast<const uint4*>(smem + ((ks * NF + f) * 64 + lane) * 16);
-                    acc[f] = mma16<T>(wf, b, acc[f]);
-                }
-            }
+            pointwise<T, KS, NF>(smem, a_read, lane, acc);
             // ---- folded BN (no ReLU: the block's last convolution), rounded; then the running maximum of the window's rows
             unsigned cur[4 * NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const float4 s0 = *reinterpret_cast<const float4*>(sb + 32 * q);
-                const float4 s1 = *reinterpret_cast<const float4*>(sb + 32 * q + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(sb + COUT + 32 * q);
-                const float4 b1 = *reinterpret_cast<const float4*>(sb + COUT + 32 * q + 4);
-                const f32x4 u = acc[2 * q], v = acc[2 * q + 1];
-                cur[4 * q + 0] = H16<T>::pack2(fmaf(u[0], s0.x, b0.x), fmaf(u[1], s0.y, b0.y));
-                cur[4 * q + 1] = H16<T>::pack2(fmaf(u[2], s0.z, b0.z), fmaf(u[3], s0.w, b0.w));
-                cur[4 * q + 2] = H16<T>::pack2(fmaf(v[0], s1.x, b1.x), fmaf(v[1], s1.y, b1.y));
-                cur[4 * q + 3] = H16<T>::pack2(fmaf(v[2], s1.z, b1.z), fmaf(v[3], s1.w, b1.w));
+                unsigned o[4];
+                bn_pair<T>(acc[2 * q], acc[2 * q + 1], sb + 32 * q, COUT, o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur[4 * q + i] = o[i];
+            }
+            if (any_col_out) {
+#pragma unroll
+                for (int i = 0; i < 4 * NQ; ++i) cur[i] = col_out ? NEG : cur[i];
             }
 #pragma unroll
-            for (int i = 0; i < 4 * NQ; ++i) {
-                cur[i] = col_out ? NEG : cur[i];
-                VM[i] = pmax2<T>(VM[i], cur[i]);
-            }
-            uint4 po[NQ];
+            for (int i = 0; i < 4 * NQ; ++i) VM[i] = pmax2<T>(VM[i], cur[i]);
+            u32x4s po[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) po[q] = make_uint4(0, 0, 0, 0);
-            if (do_emit) {                                // wave-uniform; no memory operation of the vmcnt stream inside
+            for (int q = 0; q < NQ; ++q) po[q] = (u32x4s){0u, 0u, 0u, 0u};
+            if (do_emit && !(STREAM_ABL & 16)) {          // wave-uniform; no memory operation of the vmcnt stream inside
+                asm volatile("" ::: "memory");            // a real branch: left alone hipcc runs all of this on every row and selects
                 // shortcut: D[cout][slot] = Wr[cout][k] x[k][slot]
                 f32x4 ar[NF];
 #pragma unroll
@@ -446,17 +481,8 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
                     }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const float4 s0 = *reinterpret_cast<const float4*>(sb + 2 * COUT + 32 * q);
-                    const float4 s1 = *reinterpret_cast<const float4*>(sb + 2 * COUT + 32 * q + 4);
-                    const float4 b0 = *reinterpret_cast<const float4*>(sb + 3 * COUT + 32 * q);
-                    const float4 b1 = *reinterpret_cast<const float4*>(sb + 3 * COUT + 32 * q + 4);
-                    const f32x4 u = ar[2 * q], v = ar[2 * q + 1];
-                    unsigned res[4];
-                    res[0] = H16<T>::pack2(fmaf(u[0], s0.x, b0.x), fmaf(u[1], s0.y, b0.y));
-                    res[1] = H16<T>::pack2(fmaf(u[2], s0.z, b0.z), fmaf(u[3], s0.w, b0.w));
-                    res[2] = H16<T>::pack2(fmaf(v[0], s1.x, b1.x), fmaf(v[1], s1.y, b1.y));
-                    res[3] = H16<T>::pack2(fmaf(v[2], s1.z, b1.z), fmaf(v[3], s1.w, b1.w));
-                    unsigned o[4];
+                    unsigned res[4], o[4];
+                    bn_pair<T>(ar[2 * q], ar[2 * q + 1], sb + 2 * COUT + 32 * q, COUT, res);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const unsigned c = VM[4 * q + i];
@@ -467,28 +493,57 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
                         const f32x2s a = unpack2<T>(m), r = unpack2<T>(res[i]);
                         o[i] = H16<T>::pack2(a.x + r.x, a.y + r.y);
                     }
-                    po[q] = make_uint4(o[0], o[1], o[2], o[3]);
+                    po[q] = (u32x4s){o[0], o[1], o[2], o[3]};
                 }
             }
             {
                 const unsigned off = (do_emit && lane_out) ? obase + (unsigned)yo * (unsigned)(p.Wo * COUT * sizeof(T)) : 0xffffff00u;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, po[q]), orsrc, (int)off + 64 * q, 0, 0);
+                    if (!(STREAM_ABL & 1) || po[q][0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(po[q], orsrc, (int)off + 64 * q, 0, 0);
+                if constexpr (STREAM_ABL & 16) {
+                    unsigned h = xb[0].x ^ xb[KR - 1].w;
+#pragma unroll
+                    for (int i = 0; i < 4 * NQ; ++i) h ^= VM[i];
+                    if (h == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(po[0], orsrc, (int)h, 0, 0);
+                }
             }
             if (t_even) {
 #pragma unroll
                 for (int i = 0; i < 4 * NQ; ++i) VM[i] = cur[i];
             }
-#pragma unroll
-            for (int j = 0; j < NWIN; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
         }
     }
 }
 
-#ifndef TAIL_NW
-#define TAIL_NW 11
-#endif
+// bands of ~rows_per_band rows; small batches get shorter bands so that every CU still has work
+inline int pick_bands(long long base_items, int rows, int rows_per_band, int min_rows, int waves) {
+    int nb = (rows + rows_per_band - 1) / rows_per_band;
+    if (base_items * nb < waves) {
+        nb = (int)((waves + base_items - 1) / base_items);
+        if (nb > rows / min_rows) nb = rows / min_rows;
+        if (nb < 1) nb = 1;
+    }
+    return nb;
+}
+
+template <typename T, int CIN, int COUT, bool RELU_IN>
+int launch_stream(StreamParams<T> p, int num_cus, hipStream_t s) {
+    constexpr int NW = STREAM_NW;
+    constexpr size_t lds = (size_t)(CIN / 32) * (COUT / 16) * 1024 + 2 * COUT * 4 + (size_t)NW * 16 * (CIN * 2 + 16);
+    static_assert(lds <= 160 * 1024, "stream kernel LDS budget");
+    auto kern = sepconv_stream_kernel<T, CIN, COUT, RELU_IN, NW>;
+    static BqLdsAttr attr;
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
+    p.nstrips = (p.W + 15) / 16;
+    const long long base_items = (long long)p.n * p.nstrips;
+    p.nbands = pick_bands(base_items, p.H, 25, 4, num_cus * NW);     // bands of ~25 rows (2 halo rows per band)
+    p.items = (int)(base_items * p.nbands);
+    int grid = (p.items + NW - 1) / NW;
+    if (grid > num_cus) grid = num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, p);
+    return (int)hipGetLastError();
+}
 
 template <typename T, int CX>
 int launch_tail(TailParams<T> p, int num_cus, hipStream_t s) {
@@ -500,45 +555,9 @@ int launch_tail(TailParams<T> p, int num_cus, hipStream_t s) {
     if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     p.Ho = (p.H + 1) / 2; p.Wo = (p.W + 1) / 2;
     p.nstrips = (p.Wo + 6) / 7;
-    const int waves = num_cus * NW;
-    int nb = (p.Ho + 17) / 18;                       // bands of ~18 pooled rows = ~37 convolution rows (one of them shared)
     const long long base_items = (long long)p.n * p.nstrips;
-    if (base_items * nb < waves) {
-        nb = (int)((waves + base_items - 1) / base_items);
-        if (nb > p.Ho / 2) nb = p.Ho / 2;
-        if (nb < 1) nb = 1;
-    }
-    p.nbands = nb;
-    p.items = (int)(base_items * nb);
-    int grid = (p.items + NW - 1) / NW;
-    if (grid > num_cus) grid = num_cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, p);
-    return (int)hipGetLastError();
-}
-
-template <typename T, int CIN, int COUT, bool RELU_IN>
-int launch_stream(StreamParams<T> p, int num_cus, hipStream_t s) {
-#ifndef STREAM_NW
-#define STREAM_NW 12
-#endif
-    constexpr int NW = STREAM_NW;
-    constexpr size_t lds = (size_t)(CIN / 32) * (COUT / 16) * 1024 + 2 * COUT * 4 + (size_t)NW * 16 * (CIN * 2 + 16);
-    static_assert(lds <= 160 * 1024, "stream kernel LDS budget");
-    auto kern = sepconv_stream_kernel<T, CIN, COUT, RELU_IN, NW>;
-    static BqLdsAttr attr;
-    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
-    p.nstrips = (p.W + 15) / 16;
-    // bands of ~25 rows (2 halo rows per band); small batches get shorter bands so that every CU still has work
-    const int waves = num_cus * NW;
-    int nb = (p.H + 24) / 25;
-    const long long base_items = (long long)p.n * p.nstrips;
-    if (base_items * nb < waves) {
-        nb = (int)((waves + base_items - 1) / base_items);
-        if (nb > p.H / 4) nb = p.H / 4;
-        if (nb < 1) nb = 1;
-    }
-    p.nbands = nb;
-    p.items = (int)(base_items * nb);
+    p.nbands = pick_bands(base_items, p.Ho, 18, 2, num_cus * NW);    // ~18 pooled rows = ~37 convolution rows (one shared)
+    p.items = (int)(base_items * p.nbands);
     int grid = (p.items + NW - 1) / NW;
     if (grid > num_cus) grid = num_cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, p);

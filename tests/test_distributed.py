@@ -82,9 +82,9 @@ class StandInPool:
         pass
 
 
-def make_slides():
+def make_slides(counts=None):
     rng = np.random.default_rng(0)
-    counts = [7, 0, 13, 5, 21, 1, 9, 4]
+    counts = [7, 0, 13, 5, 21, 1, 9, 4] if counts is None else list(counts)
     return [Slide(f's{i}', rng.integers(0, 256, (c, 4, 4, 3), dtype=np.uint8), c, y_true=i % 2)
             for i, c in enumerate(counts)]
 
@@ -178,3 +178,83 @@ def test_two_rank_gloo_gather():
         assert ntile == sum(cnt[i] for i in loc)                              # tile rows stay rank-local
         locals_ += loc
     assert sorted(locals_) == list(range(len(slides)))                        # disjoint cover
+
+
+# ---- eight ranks (BASELINE config 3's world size), ragged tile counts, fewer slides than ranks --------------------------
+def _worker_n(rank, world, port, q, counts, batch):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = D.init_from_env(device_type='cpu')
+    slides = make_slides(counts)
+    eng = StandInEngine()
+    res = evaluate(eng, slides, mc_n=30, seed=1, batch=batch, rank=r, world=w)
+    q.put((rank, res.slide_pred, res.slide_unc, res.slide_count, res.local_slides, len(res.tile_df), eng.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world(world, counts, batch):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, q, counts, batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return sorted(out, key=lambda t: t[0])
+
+
+@pytest.mark.parametrize('counts,batch', [
+    ([40] * 64, 16),                                    # config 3 in small: equal slides -> contiguous blocks of 8 per rank
+    ([17, 3, 0, 41, 8, 8, 8, 29, 1, 0, 12, 5, 33, 2, 19, 7, 7, 40, 11, 6, 0, 23, 9], 16),   # ragged, with empty slides
+    ([5, 9, 2], 4),                                     # fewer slides than ranks: five ranks hold nothing
+])
+def test_eight_rank_gloo_gather(counts, batch):
+    world = 8
+    out = _run_world(world, counts, batch)
+    slides = make_slides(counts)
+    pred, unc, cnt = reference_result(slides)
+    parts = D.partition_slides(counts, world)
+    covered = []
+    for rank, gp, gu, gc, loc, ntile, calls in out:
+        np.testing.assert_allclose(gp, pred, atol=1e-12, equal_nan=True)      # every rank holds every slide's result
+        np.testing.assert_allclose(gu, unc, atol=1e-12, equal_nan=True)
+        assert list(gc) == list(cnt)
+        assert loc == parts[rank] and ntile == sum(cnt[i] for i in loc)       # the partition every rank derived by itself
+        covered += loc
+        # every call covered a run of consecutive GLOBAL tile indices; all of the rank's tiles exactly once
+        off = D.global_tile_offsets(counts)
+        want = sorted(sum([list(range(int(off[i]), int(off[i]) + counts[i])) for i in loc], []))
+        assert sorted(sum([list(range(a, a + n)) for a, n in calls], [])) == want
+    assert sorted(covered) == list(range(len(counts)))
+    if len(set(counts)) == 1:
+        # equal slides: contiguous blocks, so a batch that spans slides is ONE run of indices --
+        # one head call per batch, never one per slide
+        per = len(counts) // world
+        assert [p for p in parts] == [list(range(r * per, (r + 1) * per)) for r in range(world)]
+        for rank, *_, calls in out:
+            assert len(calls) == -(-per * counts[0] // batch)
+
+
+def test_partition_keeps_lpt_loads_and_hands_out_ties_in_order():
+    rng = np.random.default_rng(3)
+    for world in (2, 3, 8):
+        for _ in range(20):
+            counts = rng.integers(0, 50, rng.integers(1, 60)).tolist()
+            parts = D.partition_slides(counts, world)
+            assert sorted(sum(parts, [])) == list(range(len(counts)))
+            # the loads of plain greedy LPT
+            load = [0] * world
+            for c in sorted(counts, reverse=True):
+                load[load.index(min(load))] += c
+            assert sorted(sum(counts[i] for i in p) for p in parts) == sorted(load)
+            # slides of equal count are handed out in index order: rank r's are all below rank r+1's
+            for c in set(counts):
+                owners = [r for r in range(world) for i in parts[r] if counts[i] == c]
+                ids = [i for r in range(world) for i in parts[r] if counts[i] == c]
+                assert ids == sorted(ids) and owners == sorted(owners)

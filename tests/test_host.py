@@ -152,14 +152,16 @@ def test_blob_directory_roundtrip():
         nm, off, ln = struct.unpack_from('<48sQQ', blob, 16 + 64 * i)
         names[nm.rstrip(b'\0').decode()] = (off, ln)
         assert off % 256 == 0 and off + ln <= len(blob)
-    # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 30 wide layers and the 32x32x16
-    # copy of the two fused shortcuts (16-bit blobs only)
-    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 30 + 2
+    # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 30 wide layers, of the two streaming
+    # layers of block 2 and of the block-2 shortcut inside the fused tail (round 4), and the 32x32x16 copy of the two fused
+    # shortcuts (16-bit blobs only)
+    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 30 + 2 + 1 + 2
+    assert {'block2_sepconv1/wp16', 'block2_sepconv2/wp16', 'block2_res/wp16'} <= set(names)
     assert names['block3_res/wp32'][1] == 8 * 8 * 64 * 8 * 2 and names['block2_res/wp32'][1] == 4 * 4 * 64 * 8 * 2
     assert 'block4_res/wp32' not in names and 'block13_res/wp32' not in names
     assert names['block5_sepconv1/wp16'][1] == 23 * 48 * 64 * 8 * 2 and 'block4_sepconv2/wp16' in names
     assert names['block3_sepconv2/wp16'][1] == 8 * 16 * 64 * 8 * 2 and names['block3_sepconv1/wp16'][1] == 4 * 16 * 64 * 8 * 2
-    assert 'block2_sepconv2/wp16' not in names
+    assert names['block2_sepconv2/wp16'][1] == 4 * 8 * 64 * 8 * 2 and names['block2_res/wp16'][1] == 2 * 8 * 64 * 8 * 2
     assert names['block4_sepconv1/wp16'][1] == 8 * 48 * 64 * 8 * 2
     off, ln = names['block5_sepconv2/scale']
     s, b = W.fold_bn(w, 'block5_sepconv2_bn')
@@ -303,3 +305,40 @@ def test_heatmap_region_smaller_than_a_tile():
         Heatmap.from_region(None, small)
     tiles, grid = tile_grid(np.zeros((299, 598, 3), np.uint8), stride_div=13)      # one row of cells at stride 23
     assert grid[:, 1].max() == 0 and grid[:, 0].max() == (598 - 299) // 23
+
+
+def test_tf_fixture_checker_accepts_a_well_formed_file_and_names_what_is_wrong_with_a_bad_one(tmp_path):
+    """``tools/make_tf_fixture.py --check`` needs no TensorFlow: the first box that has it must not be able to leave a
+    silently unusable fixture (round-3 review, item 8).  A fabricated, well-formed ``io.npz`` passes; every kind of damage
+    is named."""
+    import importlib.util
+    import os
+    import numpy as np
+    spec = importlib.util.spec_from_file_location(
+        'make_tf_fixture', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'make_tf_fixture.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(0)
+    n = 2
+    tiles = rng.integers(0, 256, (n, 299, 299, 3), dtype=np.uint8)
+    x = tiles.reshape(n, -1).astype(np.float64)
+    std = ((x - x.mean(1, keepdims=True)) / x.std(1, keepdims=True)).reshape(tiles.shape).astype(np.float32)
+    io = {'tiles': tiles, 'standardized': std, 'features': rng.random((n, 2048), dtype=np.float32),
+          'probs_nodrop': np.array([[0.3, 0.7], [0.6, 0.4]], np.float32)}
+    for name in mod.NAMES:
+        io[f'tap_{name}'] = rng.random((n,) + mod.TAP_SHAPES[name], dtype=np.float32)
+    assert mod.check_io(io) == []
+    bad = dict(io); del bad['features']
+    assert any('features' in b for b in mod.check_io(bad))
+    bad = dict(io); bad['tap_block4_out'] = io['tap_block4_out'][:, :18]
+    assert any('tap_block4_out' in b and 'shape' in b for b in mod.check_io(bad))
+    bad = dict(io); bad['standardized'] = std.astype(np.float64)
+    assert any('dtype' in b for b in mod.check_io(bad))
+    bad = dict(io); bad['standardized'] = std[::-1].copy()
+    assert any('does not belong' in b for b in mod.check_io(bad))
+    bad = dict(io); bad['probs_nodrop'] = np.array([[0.3, 0.9], [0.6, 0.4]], np.float32)
+    assert any('probability' in b for b in mod.check_io(bad))
+    bad = dict(io); bad['tap_block1_conv2'] = io['tap_block1_conv2'] - 0.5
+    assert any('activation' in b for b in mod.check_io(bad))
+    # a directory with nothing in it: every file is named
+    assert len([b for b in mod.check(str(tmp_path)) if b.startswith('missing file')]) == 4

@@ -58,6 +58,24 @@ int main(int argc, char** argv) {
             printf("%-28s cin %3d: %.4f ms  %.0f GB/s  checksum %016llx\n", tag, cin, ms, gb / ms * 1e3, h);
         }
     }
+    {   // fused block tail: y1 = in (128 ch), x = second tensor (64 ch), out 74 x 74 x 128
+        unsigned short* x; uint4* wr; unsigned short* out2;
+        CK(hipMalloc(&x, px * 64 * 2)); CK(hipMalloc(&wr, 16384)); CK(hipMalloc(&out2, (size_t)n * 74 * 74 * 128 * 2));
+        fill_rand<<<2048, 256>>>(x, px * 64, 7);
+        fill_rand<<<64, 256>>>((unsigned short*)wr, 8192, 9);
+        const double gb = ((double)px * 128 + (double)n * 74 * 74 * (64 + 128)) * 2 / 1e9;
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int i = 0; i < 3; ++i) if (launch_block_tail(2, 128, 128, 64, in, wp, dw, sc, bi, x, wr, sc, bi, out2, n, H, W, 256, 0)) { printf("tail launch failed\n"); return 1; }
+            CK(hipEventRecord(a));
+            for (int i = 0; i < 20; ++i) launch_block_tail(2, 128, 128, 64, in, wp, dw, sc, bi, x, wr, sc, bi, out2, n, H, W, 256, 0);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
+            CK(hipMemset(cs, 0, 8));
+            checksum<<<1024, 256>>>((const unsigned*)out2, (size_t)n * 74 * 74 * 64, cs);
+            unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
+            printf("%-28s tail    : %.4f ms  %.0f GB/s  checksum %016llx\n", tag, ms, gb / ms * 1e3, h);
+        }
+    }
     {   // calibration: copy of 1.42 GB (read + write 2.83 GB)
         const size_t n16 = px * 128 * 2 / 16;
         for (int i = 0; i < 3; ++i) copy16<<<256 * 8, 256>>>((const uint4*)in, (uint4*)out, n16);
