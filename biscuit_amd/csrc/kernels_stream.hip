@@ -75,6 +75,19 @@ template <> __device__ __forceinline__ unsigned pmax2<bf16_t>(unsigned a, unsign
     const f32x2s x = unpack2<bf16_t>(a), y = unpack2<bf16_t>(b);
     return H16<bf16_t>::pack2(fmaxf(x.x, y.x), fmaxf(x.y, y.y));
 }
+// T(float(a) + float(b)) per half: fp32 sum of the two exact values, rounded once to the storage type (the pooling kernels'
+// `(T)(mx + (float)re)`).  f16: v_fma_mix_f32 reads both halves in place -- a * 1.0 + b, one rounding: the same sum
+template <typename T> __device__ __forceinline__ unsigned padd2(unsigned a, unsigned b);
+template <> __device__ __forceinline__ unsigned padd2<f16_t>(unsigned a, unsigned b) {
+    float lo, hi;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hi) : "v"(a), "v"(b));
+    return H16<f16_t>::pack2(lo, hi);
+}
+template <> __device__ __forceinline__ unsigned padd2<bf16_t>(unsigned a, unsigned b) {
+    const f32x2s x = unpack2<bf16_t>(a), y = unpack2<bf16_t>(b);
+    return H16<bf16_t>::pack2(x.x + y.x, x.y + y.y);
+}
 template <typename T> struct NegInf;
 template <> struct NegInf<f16_t> { static constexpr unsigned v = 0xfc00fc00u; };
 template <> struct NegInf<bf16_t> { static constexpr unsigned v = 0xff80ff80u; };
@@ -248,11 +261,11 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
         auto take_row = [&](int y) {                       // nx (row y) -> row, zero outside the image, ReLU of the layer in front
             const unsigned m = (unsigned)y < (unsigned)p.H ? cmask : 0u;
 #pragma unroll
-            for (int j = 0; j < NWIN; ++j) {
-                unsigned v = ((m >> j) & 1u) ? nx[j] : 0u;
-                if (RELU_IN) v = relu_pk16(v);
-                row[j] = v;
-            }
+            for (int j = 0; j < NWIN; ++j) row[j] = RELU_IN ? relu_pk16(nx[j]) : nx[j];
+            if (HALVES == 1 && m == (1u << NWIN) - 1u) return;      // (wave-uniform) an inner strip, a row of the image: nothing to mask
+            asm volatile("" ::: "memory");                 // keep the branch: 18 selects on every row otherwise
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) row[j] = ((m >> j) & 1u) ? row[j] : 0u;
         };
         DwSums<T, NCOL> dws;
         dws.clear();
@@ -273,6 +286,9 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
             take_row(y + 1);
             // the row after next, one step ahead of its use (the last step re-reads row y1: an L2 hit, branch-free)
             load_row(y + 2 < y1 ? y + 2 : y1);
+            // the loads really are issued here: left to itself hipcc sinks them behind the MFMAs, half a step later
+            // (64 -> 128: 0.477 -> 0.440 ms)
+            __builtin_amdgcn_sched_barrier(0);
             dws.template push<true>(tap, row, a_lane, AST);
             f32x4 acc[NF];
             pointwise<T, KS, NF>(smem, a_read, lane, acc);
@@ -415,7 +431,11 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
         auto take_row = [&](int y) {
             const unsigned m = (unsigned)y < (unsigned)p.H ? cmask : 0u;
 #pragma unroll
-            for (int j = 0; j < NWIN; ++j) row[j] = ((m >> j) & 1u) ? nx[j] : 0u;
+            for (int j = 0; j < NWIN; ++j) row[j] = nx[j];
+            if (m == (1u << NWIN) - 1u) return;            // (wave-uniform) an inner strip, a row of the image: nothing to mask
+            asm volatile("" ::: "memory");                 // keep the branch: 18 selects on every row otherwise
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) row[j] = ((m >> j) & 1u) ? row[j] : 0u;
         };
         DwSums<T, NCOL> dws;
         dws.clear();
@@ -439,6 +459,7 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
             const bool do_emit = ((t_even && t >= 2) || y == p.H - 1) && yo >= p0;
             take_row(y + 1);
             load_row(y + 2 <= ye + 1 ? y + 2 : ye + 1);
+            __builtin_amdgcn_sched_barrier(0);             // (as in the plain kernel: the loads are issued here)
             uint4 xb[KR];                                 // shortcut operand of pooled row yo: x[2 yo][xs][32 ks + 8 g ..]
             {
                 const T* xr = xcol + (size_t)(2 * yo) * p.W * CX;
@@ -458,6 +479,7 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
                 for (int i = 0; i < 4; ++i) cur[4 * q + i] = o[i];
             }
             if (any_col_out) {
+                asm volatile("" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < 4 * NQ; ++i) cur[i] = col_out ? NEG : cur[i];
             }
@@ -487,11 +509,10 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
                     for (int i = 0; i < 4; ++i) {
                         const unsigned c = VM[4 * q + i];
                         // neighbouring pixel slots = neighbouring lanes of the 16-lane DPP row; row ends keep -inf
-                        const unsigned lft = (unsigned)__builtin_amdgcn_update_dpp((int)NEG, (int)c, 0x111, 0xf, 0xf, false);   // row_shr:1
-                        const unsigned rgt = (unsigned)__builtin_amdgcn_update_dpp((int)NEG, (int)c, 0x101, 0xf, 0xf, false);   // row_shl:1
-                        const unsigned m = pmax2<T>(pmax2<T>(lft, c), rgt);
-                        const f32x2s a = unpack2<T>(m), r = unpack2<T>(res[i]);
-                        o[i] = H16<T>::pack2(a.x + r.x, a.y + r.y);
+                        // (the row's end lanes read 0: slots 0 and 15 are never the centre of a stored pooled pixel)
+                        const unsigned lft = (unsigned)__builtin_amdgcn_mov_dpp((int)c, 0x111, 0xf, 0xf, true);   // row_shr:1
+                        const unsigned rgt = (unsigned)__builtin_amdgcn_mov_dpp((int)c, 0x101, 0xf, 0xf, true);   // row_shl:1
+                        o[i] = padd2<T>(pmax2<T>(pmax2<T>(lft, c), rgt), res[i]);
                     }
                     po[q] = (u32x4s){o[0], o[1], o[2], o[3]};
                 }
