@@ -23,13 +23,17 @@ from .predictions import save_tile_predictions, tile_frame, EVAL_NAME
 @dataclass
 class Slide:
     """One slide = one TFRecord's worth of tiles.  ``tiles`` is either a uint8 array
-    [T,299,299,3] (host or device) or a zero-argument callable returning one."""
+    [T,299,299,3] (host or device) or a zero-argument callable returning one.  ``source`` (optional): an object with
+    ``read(first, count, out)`` that decodes tiles [first, first + count) into a caller-supplied uint8 buffer and a
+    ``rows`` flag (``TFRecordSource``): ``evaluate`` then streams the slide in fixed chunks through a ring of reusable
+    pinned buffers instead of calling ``tiles``."""
     name: str
     tiles: object
     n_tiles: int
     y_true: int = 0
     patient: Optional[str] = None
     loc: Optional[np.ndarray] = None
+    source: Optional[object] = None
 
     def load(self):
         t = self.tiles() if callable(self.tiles) else self.tiles
@@ -41,6 +45,64 @@ class PngRows:
     [T,px,1+3*px] (host, usually pinned).  ``evaluate`` copies them to the device and calls ``Engine.png_unfilter``."""
     def __init__(self, rows):
         self.rows = rows
+
+
+class TFRecordSource:
+    """Chunk-wise decoder of one slide's TFRecord for ``evaluate``'s pinned ring: ``read(first, count, out)`` decodes
+    tiles [first, first + count) into ``out`` (a uint8 numpy view, usually of page-locked memory) on the reader's thread
+    pool.  ``rows``: stop at the inflated PNG scanlines ([count,px,1+3*px]; the GPU reverses the filters).  A slide with
+    a record outside the native decoders' subset is decoded whole with Pillow once and served from memory."""
+    def __init__(self, path, n_tiles, tile_px=299, rows=False):
+        self.path, self.n_tiles, self.tile_px, self.rows = path, int(n_tiles), int(tile_px), bool(rows)
+        self._reader = None
+        self._fallback = None
+
+    def chunk_shape(self, count):
+        px = self.tile_px
+        return (count, px, 1 + 3 * px) if self.rows else (count, px, px, 3)
+
+    def read(self, first, count, out):
+        from . import tfrecord, tfrecord_native as tn
+        if self._fallback is None and tn.available():
+            if self._reader is None:
+                self._reader = tn.NativeReader(self.path)
+            try:
+                self._reader.decode(first, count, self.tile_px, out=out, rows=self.rows)
+                return
+            except tn.UnsupportedImage:
+                pass
+        if self._fallback is None:                      # Pillow (or the pure-Python reader), the whole slide once
+            self._fallback = tfrecord.read_slide(self.path, self.tile_px, rows=self.rows)[1]
+        out[...] = self._fallback[first:first + count]
+
+    def close(self):
+        if self._reader is not None:
+            self._reader.close()
+            self._reader = None
+        self._fallback = None
+
+
+def pick_unfilter_mode(path, tile_px=299, sample=48):
+    """'auto' for ``slides_from_tfrecords``: decode the first ``sample`` tiles of one slide both ways and keep the GPU
+    un-filter only where it pays -- the host alone is slower than the GPU consumes tiles (~28 k/s) AND stopping at the
+    scanlines makes it at least 8 % faster (noise-like synthetic tiles: Sub / Up rows, cheap on the host; photo-like
+    tiles: +20-30 %).  Returns (use_gpu_unfilter, host tiles/s, rows tiles/s)."""
+    import time
+    from . import tfrecord_native as tn
+    if not tn.available():
+        return False, 0.0, 0.0
+    try:
+        with tn.NativeReader(path) as r:
+            n = min(sample, len(r))
+            if n == 0:
+                return False, 0.0, 0.0
+            r.decode(0, n, tile_px)                      # page cache, thread pool warm
+            t0 = time.perf_counter(); r.decode(0, n, tile_px); t_full = time.perf_counter() - t0
+            t0 = time.perf_counter(); r.decode(0, n, tile_px, rows=True); t_rows = time.perf_counter() - t0
+    except (tn.UnsupportedImage, ValueError, IOError):
+        return False, 0.0, 0.0
+    full, rows = n / max(t_full, 1e-9), n / max(t_rows, 1e-9)
+    return (full < 26000.0 and rows > 1.08 * full), full, rows
 
 
 def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None, gpu_unfilter=None):
@@ -56,6 +118,8 @@ def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None
     from . import tfrecord
     if pinned is None:
         pinned = torch.cuda.is_available()
+    if gpu_unfilter == 'auto':                          # a short measurement on the first slide decides
+        gpu_unfilter = bool(paths) and tile_px <= 341 and torch.cuda.is_available() and pick_unfilter_mode(paths[0], tile_px)[0]
     gpu_unfilter = bool(gpu_unfilter)
     out = []
     for path in paths:
@@ -73,7 +137,8 @@ def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None
                 return t
             return tfrecord.read_slide(pth, tile_px)[1]
         out.append(Slide(name, loader, count, y_true=int(labels.get(name, 0)),
-                         patient=(patients or {}).get(name)))
+                         patient=(patients or {}).get(name),
+                         source=TFRecordSource(path, count, tile_px, rows=gpu_unfilter) if pinned else None))
     return out
 
 
@@ -94,6 +159,118 @@ class EvalResult:
         names = [n for n, k in zip(self.slide_names, keep) if k]
         return group_frame(names, self.slide_pred[keep], self.slide_y_true[keep].astype(np.uint8),
                            self.slide_unc[keep], pred_thresh, level)
+
+
+CHUNK_TILES = 512        # tiles per pinned buffer: 137 MB at 299 px (a 10^4-tile slide is twenty chunks, never one allocation)
+RING_SLOTS = 3
+PREFETCH_CHUNKS = 2      # decoded chunks waiting for the GPU (plus the one being decoded)
+
+
+class _PinnedRing:
+    """RING_SLOTS reusable page-locked buffers (allocated once per process and size: page-locking 137 MB costs tens of
+    milliseconds, which round 3 paid per slide).  A slot is free again when the event recorded behind its last
+    host-to-device copy has completed."""
+    _cache = {}
+
+    def __init__(self, nbytes):
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(RING_SLOTS)]
+        self.events = [None] * RING_SLOTS
+        self.next = 0
+
+    @classmethod
+    def get(cls, nbytes):
+        r = cls._cache.get(nbytes)
+        if r is None:
+            cls._cache.clear()                       # one size at a time: a new tile size replaces the old buffers
+            r = cls._cache[nbytes] = cls(nbytes)
+        return r
+
+    def acquire(self):
+        i = self.next
+        self.next = (i + 1) % RING_SLOTS
+        if self.events[i] is not None:
+            self.events[i].synchronize()             # (the feeder thread waits, not the thread that launches kernels)
+            self.events[i] = None
+        return i
+
+
+def _feed_chunks(slides, mine, dev, copy_stream):
+    """Generator over this rank's slides in order: yields (li, si, first, count, tensor, event, is_rows).  Slides with a
+    ``source`` are decoded chunk by chunk on a feeder thread into the pinned ring and copied to the device on
+    ``copy_stream`` (event = the copy's completion; the tensor was allocated on that stream); PREFETCH_CHUNKS chunks may
+    wait decoded and copied while the GPU works -- with 512-tile chunks that is two 1 000-tile slides of lead.  Other
+    slides are loaded whole on the same thread and handed over as they are (event None)."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=PREFETCH_CHUNKS)
+    stop = threading.Event()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def work():
+        try:
+            for li, si in enumerate(mine):
+                s = slides[si]
+                src = getattr(s, 'source', None)
+                if src is None or s.n_tiles == 0 or copy_stream is None:
+                    if copy_stream is None:
+                        item = (li, si, 0, s.n_tiles, s.load(), None, False)
+                    else:
+                        # a loader may launch GPU work of its own (tiles resident on the device): on this thread that must
+                        # not be the legacy default stream -- a barrier across the pool's streams, and unordered against the
+                        # consumer's -- but the copy stream, with an event for the consumer to wait on
+                        with torch.cuda.stream(copy_stream):
+                            loaded = s.load()
+                            ev = None
+                            if torch.is_tensor(loaded) and loaded.is_cuda:
+                                ev = torch.cuda.Event()
+                                ev.record(copy_stream)
+                        item = (li, si, 0, s.n_tiles, loaded, ev, False)
+                    if not put(item):
+                        return
+                    continue
+                per = int(np.prod(src.chunk_shape(1)))
+                ring = _PinnedRing.get(CHUNK_TILES * per)
+                try:
+                    for first in range(0, s.n_tiles, CHUNK_TILES):
+                        cnt = min(CHUNK_TILES, s.n_tiles - first)
+                        slot = ring.acquire()
+                        host = ring.bufs[slot][:cnt * per].view(src.chunk_shape(cnt))
+                        src.read(first, cnt, host.numpy())
+                        with torch.cuda.stream(copy_stream):
+                            d = torch.empty(src.chunk_shape(cnt), dtype=torch.uint8, device=dev)
+                            d.copy_(host, non_blocking=True)
+                            ev = torch.cuda.Event()
+                            ev.record(copy_stream)
+                        ring.events[slot] = ev
+                        if not put((li, si, first, cnt, d, ev, src.rows)):
+                            return
+                finally:
+                    src.close()
+            put(None)
+        except BaseException as e:                   # noqa: BLE001 -- re-raised in the consumer
+            put(e)
+
+    th = threading.Thread(target=work, name='bq-tile-feeder', daemon=True)
+    th.start()
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        th.join(timeout=30)
 
 
 def _to_device(t, device):
@@ -200,48 +377,43 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             with torch.cuda.stream(prep):
                 return fn()
         return call
-    # slides whose tiles come from a loader (TFRecords) are decoded one slide ahead on a host thread:
-    # the native decoder releases the GIL, so decode, H2D copy and the GPU work of the previous slide overlap
-    from concurrent.futures import ThreadPoolExecutor
-    lazy = any(callable(slides[si].tiles) for si in mine)
-    prefetch = ThreadPoolExecutor(1) if lazy else None
+    # Tiles arrive through a feeder thread: slides with a chunk source (TFRecords) are decoded 512 tiles at a time into a
+    # ring of three reusable pinned buffers and copied to the device on a stream of their own, two chunks ahead of the
+    # GPU; the native decoder releases the GIL, so decode, H2D copy and kernels overlap.  (Round 3 allocated a fresh
+    # page-locked tensor per slide and prefetched one slide.)
     import contextlib
+    copy_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == 'cuda' else None
 
     def stream_slides():
         nonlocal pend_n, rows_slide, rows_true
-        pending = prefetch.submit(on_prep(slides[mine[0]].load)) if prefetch and mine else None
-        for li, si in enumerate(mine):
+        cur_stream = (lambda: torch.cuda.current_stream(dev)) if copy_stream is not None else None
+        for li, si, first, count, loaded, ev, is_rows in _feed_chunks(slides, mine, dev, copy_stream):
             s = slides[si]
-            if prefetch:
-                loaded = pending.result()
-                pending = prefetch.submit(on_prep(slides[mine[li + 1]].load)) if li + 1 < len(mine) else None
-            else:
-                loaded = s.load()
-            if isinstance(loaded, PngRows):      # filtered PNG scanlines: H2D, then the filters are reversed on the device
+            if ev is not None:                       # made on the copy stream: order it before this stream's work
+                cur_stream().wait_event(ev)
+                loaded.record_stream(cur_stream())
+                t = engines[0].png_unfilter(loaded) if is_rows else loaded.contiguous()
+            elif isinstance(loaded, PngRows):        # filtered PNG scanlines: H2D, then the filters are reversed on the device
                 t = engines[0].png_unfilter(_to_device(loaded.rows, dev))
             else:
                 t = _to_device(loaded, dev)
-            assert t.shape[0] == s.n_tiles, (s.name, t.shape, s.n_tiles)
-            if s.n_tiles == 0:
+            assert t.shape[0] == count, (s.name, t.shape, count)
+            if count == 0:
                 continue
             pend_tiles.append(t)
-            pend_sidx.append(torch.full((s.n_tiles,), li, dtype=torch.int32, device=dev))
-            pend_gidx.append(offsets[si] + np.arange(s.n_tiles, dtype=np.int64))
-            pend_n += s.n_tiles
+            pend_sidx.append(torch.full((count,), li, dtype=torch.int32, device=dev))
+            pend_gidx.append(offsets[si] + first + np.arange(count, dtype=np.int64))
+            pend_n += count
             if keep_tiles:
-                rows_slide += [s.name] * s.n_tiles
-                rows_true += [s.y_true] * s.n_tiles
+                rows_slide += [s.name] * count
+                rows_true += [s.y_true] * count
                 if s.loc is not None:
-                    rows_loc.append(np.asarray(s.loc))
+                    rows_loc.append(np.asarray(s.loc)[first:first + count])
             flush()
         flush(final=True)
 
-    try:
-        with (torch.cuda.stream(prep) if prep is not None else contextlib.nullcontext()):
-            stream_slides()
-    finally:
-        if prefetch:
-            prefetch.shutdown()
+    with (torch.cuda.stream(prep) if prep is not None else contextlib.nullcontext()):
+        stream_slides()
     if prep is not None:
         torch.cuda.current_stream(dev).wait_stream(prep)
 
