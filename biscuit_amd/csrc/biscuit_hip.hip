@@ -191,6 +191,8 @@ struct ConvArgs {
     int ldi, ldo;          // row strides (elements)
     int relu;
     void* dwtmp = nullptr; // scratch for the two-kernel (depthwise + GEMM) form, >= n*H*W*ldi elements
+    float* gap_out = nullptr;   // round 4: global average pool as the GEMM's epilogue -> fp32 [n][ldo]; `out` is not written.
+    bool* gap_done = nullptr;   // set when that form ran (it needs the two-kernel path and H * W <= 128)
 };
 
 int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
@@ -271,11 +273,14 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
             const int e = launch_dw3x3(dtype, a.in, L.dw, a.dwtmp, a.n, a.H, a.W, a.ldi, a.prod == PROD_DW_RELU, s);
             if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(dw3x3) ") + a.layer);
         }
-        ProfScope pg(c, s, std::string("gemm_") + cls, 2.0 * M * L.cin * L.cout,
-                     es * (M * L.cin + M * L.cout * (a.residual ? 2.0 : 1.0)));
+        const bool gap = a.gap_out && a.gap_done && !a.residual && a.H * a.W <= 128 && a.ldo == L.cout;
+        ProfScope pg(c, s, std::string(gap ? "gemm_gap_" : "gemm_") + cls, 2.0 * M * L.cin * L.cout + (gap ? M * L.cout : 0.0),
+                     gap ? es * M * L.cin + 4.0 * a.n * L.cout
+                         : es * (M * L.cin + M * L.cout * (a.residual ? 2.0 : 1.0)));
         p.in = a.dwtmp; p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
-        p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = a.out;
-        const int e = launch_gemm_tile(dtype, p, false, s);
+        p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = gap ? (void*)a.gap_out : a.out;
+        if (gap) *a.gap_done = true;
+        const int e = launch_gemm_tile(dtype, p, false, s, gap ? 1 : 0);
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(gemm_tile) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));
         return BQ_OK;
@@ -366,6 +371,26 @@ int block_end(bq_ctx* c, const char* res_name, const char* pool_name, const void
     // measured per batch of 256 (one stream): block 2 0.62 -> 0.46 ms, block 3 0.34 -> 0.27 ms; block 4 (K = 256, six
     // 128-channel workgroups per pixel tile) 0.26 -> 0.34 ms and block 13 0.19 -> 0.20 ms stay on the two-kernel path
     static const bool fuse_all = bq_exp_env("BQ_RESPOOL_ALL") != nullptr;
+    // round 4: the shortcuts of blocks 3, 4 and 13 (K = 128 / 256 / 736) as the tiled GEMM with the pooling pass as its store pass
+    // (kernels_split.hip, EPI_POOL): the shortcut tensor never goes to HBM, one launch instead of two
+    static const bool no_poolgemm = bq_exp_env("BQ_NO_POOLGEMM") != nullptr;
+#ifndef POOLGEMM_MINK
+#define POOLGEMM_MINK 128     // block 3 (K = 128) too: 0.273 -> 0.242 ms against kernels_respool.hip; block 2 (K = 64) lives in the fused tail
+#endif
+    if (is16(c->cfg.dtype) && !want_res && !no_poolgemm && L.kpad >= POOLGEMM_MINK && L.nfp % 4 == 0) {
+        const double px = (double)n * Ho * Ho;
+        GemmParams p{};
+        p.in = x; p.wp = L.wp; p.scale = L.scale; p.bias = L.bias; p.residual = y; p.out = out;
+        p.M = n * Ho * Ho; p.K = L.kpad; p.KBtot = L.kpad / 16; p.kb0 = 0; p.k_off = 0;
+        p.NFp = L.nfp; p.Nstore = co; p.ldo = co; p.ldi = ci;
+        p.H = Ho; p.W = Ho; p.Hi = Hi; p.Wi = Hi; p.relu = 0;
+        ProfScope ps(c, s, std::string("respool_") + std::to_string(Hi) + "_c" + std::to_string(cout),
+                     2.0 * px * L.cin * L.cout + 9.0 * px * co,
+                     es * ((double)n * Hi * Hi * co + px * co + px * ci) + es * (double)L.cin * L.cout);
+        const int e = launch_gemm_tile(c->cfg.dtype, p, true, s, 2);
+        if (e) return fail(c, BQ_ERR_HIP, std::string("launch(gemm_tile pool) ") + res_name + ": " + hipGetErrorString((hipError_t)e));
+        return BQ_OK;
+    }
     if (is16(c->cfg.dtype) && L.wp32 && !want_res && !no_fuse && (L.kpad <= 128 || fuse_all)) {
         const double px = (double)n * Ho * Ho;
         ProfScope ps(c, s, std::string("respool_") + std::to_string(Hi) + "_c" + std::to_string(cout),
@@ -518,11 +543,19 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     TAP("block13_out", S, 10, 10, 1024, 1024);
     RUN(run_conv(c, {"block14_sepconv1", PROD_DW, S, Y, nullptr, C, n, 10, 10, 10, 10, 1024, 1536, 1, X}, s));
     TAP("block14_sepconv1", Y, 10, 10, 1536, 1536);
-    RUN(run_conv(c, {"block14_sepconv2", PROD_DW, Y, C, nullptr, S, n, 10, 10, 10, 10, 1536, 2048, 1, X}, s));
-    TAP("block14_sepconv2", C, 10, 10, 2048, 2048);
-    {
-        ProfScope ps(c, s, "global_avg_pool", (double)n * 100 * 2048, es * (double)n * 100 * 2048 + 4.0 * n * 2048);
-        if (launch_gap(C, n, 100, 2048, 2048, feat, dt, s)) return fail(c, BQ_ERR_HIP, "gap launch failed");
+    {   // round 4: the global average pool is the epilogue of block14_sepconv2's GEMM (one workgroup owns an image's 100
+        // pixels) unless the convolution's own output was asked for
+        const bool want14 = tap && tap->want && strcmp(tap->want, "block14_sepconv2") == 0;
+        static const bool no_gapfuse = bq_exp_env("BQ_NO_GAPFUSE") != nullptr;
+        bool gap_done = false;
+        ConvArgs a14{"block14_sepconv2", PROD_DW, Y, C, nullptr, S, n, 10, 10, 10, 10, 1536, 2048, 1, X};
+        if (!want14 && !no_gapfuse) { a14.gap_out = feat; a14.gap_done = &gap_done; }
+        RUN(run_conv(c, a14, s));
+        if (!gap_done) {
+            TAP("block14_sepconv2", C, 10, 10, 2048, 2048);
+            ProfScope ps(c, s, "global_avg_pool", (double)n * 100 * 2048, es * (double)n * 100 * 2048 + 4.0 * n * 2048);
+            if (launch_gap(C, n, 100, 2048, 2048, feat, dt, s)) return fail(c, BQ_ERR_HIP, "gap launch failed");
+        }
     }
     if (tap && tap->want) return fail(c, BQ_ERR_ARG, std::string("unknown activation: ") + tap->want);
     return BQ_OK;

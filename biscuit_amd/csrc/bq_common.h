@@ -102,7 +102,7 @@ int launch_block_tail(int dtype, int cin, int cout, int cx, const void* y1, cons
                       const float* scale, const float* bias, const void* x, const void* wr16, const float* rscale,
                       const float* rbias, void* out, int n, int H, int W, int num_cus, hipStream_t s);
 int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
-int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s);
+int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s, int epi = 0);   // epi: 1 = + global average pool, 2 = + max-pool + add
 int launch_tile_conv(int dtype, int kind, const void* in, const void* wp, const float* dw, const float* scale,
                      const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
                      hipStream_t s);

@@ -102,7 +102,18 @@ constexpr int ST_ROW = BN * 2 + 16;       // staging row of the output tile
 
 // S2: the rows of A are the even pixels of a larger map (1x1 / stride 2 / 'same' shortcut convolutions): row m = output
 // pixel (img, y, x) of an H x W map reads input pixel (img, 2y, 2x) of the Hi x Wi map.
-template <typename T, int PF, bool S2>
+// EPI (round 4: the fusions BASELINE.json's north_star names, so that neither tensor goes through HBM on its own):
+//   EPI_GAP   the tile's rows are ONE image's H x W pixels (<= 128; the rest of the 128 MFMA rows is computed and dropped):
+//             folded BN + ReLU, rounded to the storage type -- the rounding point of the tensor GlobalAveragePooling2D
+//             used to read --, then the column means in the pixel order of the old pooling kernel (bit-identical to it),
+//             fp32 [n][ldo] to p.out.  No atomics: one workgroup owns an image's pixels.
+//   EPI_POOL  (with S2) out = MaxPool3x3/s2 'same' (y) + BN(conv1x1/s2(x)): the shortcut tile, rounded, waits in LDS and
+//             the store pass becomes the pooling pass of kernels_misc.hip (thread = 8 channels of a pooled pixel, nine
+//             coalesced 16-byte loads of y = p.residual [n][Hi][Wi][ldo], fp32 max, + shortcut, rounded).  Three workgroups
+//             per CU: one's pooling pass runs under the others' MFMAs.
+enum { EPI_PLAIN = 0, EPI_GAP = 1, EPI_POOL = 2 };
+
+template <typename T, int PF, bool S2, int EPI = EPI_PLAIN>
 __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
     if constexpr (H16<T>::F16) bq_f16_saturate();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -112,7 +123,8 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
     const int ntn = p.NFp / 4;                       // 128-column tiles
     const int tile = xcd_tile(blockIdx.x, gridDim.x);
     const int mt = tile / ntn, nt = tile - mt * ntn;
-    const int m0 = mt * BM;
+    const int rows_per_tile = EPI == EPI_GAP ? p.H * p.W : BM;
+    const int m0 = mt * rows_per_tile;
     const int K = p.K, KB = K / 16, NC = (K + BK - 1) / BK;
     const T* __restrict__ A = reinterpret_cast<const T*>(p.in);
 
@@ -198,7 +210,7 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
     }
 
     // ---- epilogue: folded BN, residual, ReLU in registers -> LDS -> whole 256-byte row segments
-    const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+    const T* __restrict__ res = EPI == EPI_PLAIN ? reinterpret_cast<const T*>(p.residual) : nullptr;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -235,7 +247,76 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
             }
         }
     __syncthreads();
-    {
+    if constexpr (EPI == EPI_GAP) {
+        // column means over the image's pixels, in pixel order (the summation order of gap_kernel)
+        if (tid < BN) {
+            const int ncol = nt * BN + tid;
+            if (ncol < p.Nstore) {
+                float sum = 0.f;
+                for (int r = 0; r < rows_per_tile; ++r)
+                    sum += (float)*reinterpret_cast<const T*>(smem + (size_t)r * ST_ROW + tid * 2);
+                reinterpret_cast<float*>(p.out)[(size_t)mt * p.ldo + ncol] = sum / (float)rows_per_tile;
+            }
+        }
+    } else if constexpr (EPI == EPI_POOL) {
+        const T* __restrict__ y = reinterpret_cast<const T*>(p.residual);
+        T* __restrict__ out = reinterpret_cast<T*>(p.out);
+        const int pc = tid & 15;
+        const int ncol = nt * BN + pc * 8;
+        const int pt = (p.Hi & 1) ? 1 : 0, pl = (p.Wi & 1) ? 1 : 0;   // TensorFlow 'same' padding of the pool: (1,1) odd, (0,1) even
+        if (ncol < p.Nstore) {
+            // Branch-free taps: a tap outside the map is clamped onto the map's edge, which lies inside the same window (a
+            // duplicate changes no maximum), so all nine 16-byte loads of a pixel -- and of the next pixel: two rows per
+            // step -- are in flight together.  (First form, taps under `if`, one row at a time: 0.36 ms for block 4 against
+            // 0.26 ms for the two kernels it replaces.)
+            const int hw = p.H * p.W;
+            constexpr int RU = 2;
+            for (int r0 = tid >> 4; r0 < BM; r0 += 16 * RU) {
+                uint4 u[RU][9];
+                int mrow[RU];
+#pragma unroll
+                for (int k = 0; k < RU; ++k) {
+                    int m = m0 + r0 + 16 * k;
+                    mrow[k] = m;
+                    m = m < p.M ? m : p.M - 1;
+                    const int img = m / hw, rem = m - img * hw;
+                    const int yo = rem / p.W, xo = rem - yo * p.W;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        int yy = 2 * yo + dy - pt;
+                        yy = yy < 0 ? 0 : (yy > p.Hi - 1 ? p.Hi - 1 : yy);
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            int xx = 2 * xo + dx - pl;
+                            xx = xx < 0 ? 0 : (xx > p.Wi - 1 ? p.Wi - 1 : xx);
+                            u[k][dy * 3 + dx] = *reinterpret_cast<const uint4*>(y + ((size_t)(img * p.Hi + yy) * p.Wi + xx) * p.ldo + ncol);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < RU; ++k) {
+                    const int r = r0 + 16 * k;
+                    if (r >= BM || mrow[k] >= p.M) continue;
+                    float mx[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mx[j] = -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const T* e = reinterpret_cast<const T*>(&u[k][t]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], (float)e[j]);
+                    }
+                    const uint4 ru = *reinterpret_cast<const uint4*>(smem + (size_t)r * ST_ROW + pc * 16);
+                    const T* re = reinterpret_cast<const T*>(&ru);
+                    uint4 ou;
+                    T* oe = reinterpret_cast<T*>(&ou);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) oe[j] = (T)(mx[j] + (float)re[j]);
+                    *reinterpret_cast<uint4*>(out + (size_t)mrow[k] * p.ldo + ncol) = ou;
+                }
+            }
+        }
+    } else {
         unsigned char* __restrict__ out = reinterpret_cast<unsigned char*>(p.out);
         const int pc = tid & 15;                                   // 16-byte piece of the 256-byte row segment
         const int ncol = nt * BN + pc * 8;
@@ -272,10 +353,26 @@ int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, i
 }
 
 // p.in = depthwise result [M][ldi] -- or, with s2, the map [n][Hi][Wi][ldi] whose even pixels are the rows;
-// p.NFp multiple of 4; 16-bit types only
-int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s) {
+// p.NFp multiple of 4; 16-bit types only.  epi: 0 plain; 1 = global average pool (p.out = fp32 [M / (H W)][ldo], H W <= 128,
+// M a multiple of H W, no s2); 2 = max-pool + add (s2 only: p.residual = the map to pool, [n][Hi][Wi][ldo])
+int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s, int epi) {
     if (p.NFp % 4 != 0 || p.K % 16 != 0) return (int)hipErrorInvalidValue;
     const size_t lds = 2 * A_BUF > BM * ST_ROW ? 2 * A_BUF : BM * ST_ROW;
+    if (epi == EPI_GAP) {
+        const int hw = p.H * p.W;
+        if (s2 || hw <= 0 || hw > BM || p.M % hw) return (int)hipErrorInvalidValue;
+        const int grid = (p.M / hw) * (p.NFp / 4);
+        if (dtype == 2) hipLaunchKernelGGL((gemm_tile_kernel<f16_t, 4, false, EPI_GAP>), dim3(grid), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((gemm_tile_kernel<bf16_t, 4, false, EPI_GAP>), dim3(grid), dim3(256), lds, s, p);
+        return (int)hipGetLastError();
+    }
+    if (epi == EPI_POOL) {
+        if (!s2 || !p.residual) return (int)hipErrorInvalidValue;
+        const int grid = ((p.M + BM - 1) / BM) * (p.NFp / 4);
+        if (dtype == 2) hipLaunchKernelGGL((gemm_tile_kernel<f16_t, 4, true, EPI_POOL>), dim3(grid), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((gemm_tile_kernel<bf16_t, 4, true, EPI_POOL>), dim3(grid), dim3(256), lds, s, p);
+        return (int)hipGetLastError();
+    }
     const int grid = ((p.M + BM - 1) / BM) * (p.NFp / 4);
     if (dtype == 2) {
         if (s2) hipLaunchKernelGGL((gemm_tile_kernel<f16_t, 4, true>), dim3(grid), dim3(256), lds, s, p);
