@@ -52,6 +52,7 @@ ABI = {
     'bq_profile_enable': (_i, [_vp, _i]),
     'bq_profile_read': (_i, [_vp, C.POINTER(BqProfEntry), _i]),
     'bq_debug_activation': (_i64, [_vp, C.c_char_p, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
+    'bq_debug_activation_u8': (_i64, [_vp, C.c_char_p, _vp, _i, _vp, _sz, _vp, _sz, _vp]),
 }
 
 

@@ -45,6 +45,8 @@ struct bq_ctx {
     std::map<std::string, Blob> entries;
     std::map<std::string, GemmLayer> layers;
     const float* stem_w = nullptr; const float* stem_s = nullptr; const float* stem_b = nullptr;
+    const void* front_ws16 = nullptr;   // "block1_conv1/w16" + "block1_conv2/wp16": the fused front kernel (kernels_front.hip)
+    const void* front_wc16 = nullptr;
     const float* logits_w = nullptr; const float* logits_b = nullptr;
     HeadLayer head[2];             // hidden_0, hidden_1: weights split into two halves (kernels_head.hip)
     bool loaded = false;
@@ -414,10 +416,31 @@ int block_end(bq_ctx* c, const char* res_name, const char* pool_name, const void
 
 // Stem + entry flow (blocks 1-4) of n tiles.  A/B/C/R are scratch for n tiles; the block-4 output
 // (19x19x736 per tile) goes to out4.  Returns 1 if a debug tap matched (caller stops).
+// u8 != nullptr: the uint8 tiles themselves -- staging, block1_conv1 and block1_conv2 run as ONE kernel (kernels_front.hip;
+// `in_nchw` is not read) when its weights are loaded
 int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void* B, void* C, void* R,
-               hipStream_t s, Tap* tap) {
+               hipStream_t s, Tap* tap, const uint8_t* u8 = nullptr) {
     const int dt = c->cfg.dtype;
     const double es = (double)esize(c);
+    if (u8) {
+        auto l2 = c->layers.find("block1_conv2");
+        if (!c->front_ws16 || !c->front_wc16 || l2 == c->layers.end() || !is16(dt))
+            return fail(c, BQ_ERR_ARG, "the fused front kernel needs a 16-bit context with its weights loaded");
+        if (tap && tap->want && (strcmp(tap->want, "staged") == 0 || strcmp(tap->want, "block1_conv1") == 0))
+            return fail(c, BQ_ERR_ARG, "the fused front kernel does not materialise the staged tile or block1_conv1");
+        {
+            ProfScope ps(c, s, "stage_stats", 2.0 * n * kStaged, (double)n * kStaged);
+            if (launch_stage_stats(u8, n, 299, c->d_stage_stats, s)) return fail(c, BQ_ERR_HIP, "stage stats launch failed");
+        }
+        {
+            const double p1 = (double)n * 149 * 149, p2 = (double)n * 147 * 147;
+            ProfScope ps(c, s, "front_stage_stem_conv2", 2.0 * p1 * 27 * 32 + 2.0 * p2 * 288 * 64 + 4.0 * n * kStaged,
+                         (double)n * kStaged + es * p2 * 64);
+            const int e = launch_front(dt, u8, reinterpret_cast<const unsigned long long*>(c->d_stage_stats), c->front_ws16, c->stem_s,
+                                       c->stem_b, c->front_wc16, l2->second.scale, l2->second.bias, B, n, c->num_cus, s);
+            if (e) return fail(c, BQ_ERR_HIP, std::string("launch(front): ") + hipGetErrorString((hipError_t)e));
+        }
+    } else {
     if (tap && tap->want && strcmp(tap->want, "staged") == 0) {
         if ((size_t)n * kStaged > tap->out_elems) return fail(c, BQ_ERR_ARG, "debug output too small");
         if (launch_nchw_to_f32_nhwc(in_nchw, n, 3, 299 * 299, tap->out, dt, s))
@@ -433,6 +456,7 @@ int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void*
     }
     TAP("block1_conv1", A, 149, 149, 32, 32);
     RUN(run_conv(c, {"block1_conv2", PROD_IM2COL, A, B, nullptr, nullptr, n, 147, 147, 149, 149, 32, 64, 1}, s));
+    }
     TAP("block1_conv2", B, 147, 147, 64, 64);
 
     // entry flow: blocks 2-4.  The block's input lives in `cur`, its output goes to `nxt` (block 4: out4)
@@ -488,7 +512,7 @@ int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void*
 }
 
 int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned char* ws, hipStream_t s,
-                  Tap* tap) {
+                  Tap* tap, const uint8_t* u8 = nullptr) {
     const WsLayout L = ws_layout(c, n, 1);
     void* A = ws + L.a; void* B = ws + L.b; void* C = ws + L.c; void* R = ws + L.r;
     const int dt = c->cfg.dtype;
@@ -507,13 +531,13 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     unsigned char* X4 = sub == n ? (unsigned char*)R : (unsigned char*)B + (size_t)(n / 2) * kMaxAct * esize(c);
     void* S = sub == n ? B : R;
     if (sub == n) {
-        RUN(entry_flow(c, in_nchw, n, X4, A, B, C, R, s, tap));
+        RUN(entry_flow(c, in_nchw, n, X4, A, B, C, R, s, tap, u8));
         if (tap && tap->written >= 0) return BQ_OK;
     } else {
         for (int i0 = 0; i0 < n; i0 += sub) {
             const int ns = n - i0 < sub ? n - i0 : sub;
             const unsigned char* in_i = (const unsigned char*)in_nchw + (size_t)i0 * kStaged * esize(c);
-            RUN(entry_flow(c, in_i, ns, X4 + (size_t)i0 * tile4, A, B, C, R, s, nullptr));
+            RUN(entry_flow(c, in_i, ns, X4 + (size_t)i0 * tile4, A, B, C, R, s, nullptr, u8 ? u8 + (size_t)i0 * kStaged : nullptr));
         }
     }
     // middle flow: blocks 5-12 at 19x19x728 (stride 736)
@@ -769,6 +793,16 @@ int bq_load_weights(bq_ctx* c, const void* host_blob, size_t nbytes) {
     c->logits_b = entry_f32(c, "logits/bias");
     if (!c->stem_w || !c->stem_s || !c->stem_b || !c->logits_w || !c->logits_b)
         return fail(c, BQ_ERR_WEIGHTS, "missing stem/logits tensors");
+    c->front_ws16 = c->front_wc16 = nullptr;
+    {
+        auto a = c->entries.find("block1_conv1/w16"), b = c->entries.find("block1_conv2/wp16");
+        if (a != c->entries.end() && b != c->entries.end()) {
+            if (a->second.n != 2 * 2 * 1024 || b->second.n != 9 * 4 * 1024)
+                return fail(c, BQ_ERR_WEIGHTS, "bad size for block1_conv1/w16 or block1_conv2/wp16");
+            c->front_ws16 = a->second.p;
+            c->front_wc16 = b->second.p;
+        }
+    }
     RUN(register_gemm_layer(c, "block1_conv2", 32, 64, 288, false, vec, elt));
     const int res[4][3] = {{2, 64, 128}, {3, 128, 256}, {4, 256, 728}, {13, 728, 1024}};
     for (auto& r : res)
@@ -908,15 +942,26 @@ int bq_mc_infer(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int
     void* staged = ws + L.staged;
     float* feat = (float*)(ws + L.feat);
     float* state = (float*)(ws + L.state);
+    // 16-bit contexts: staging + stem + block1_conv2 as one kernel straight from the uint8 tiles (kernels_front.hip)
+    static const bool no_front = bq_exp_env("BQ_NO_FRONT") != nullptr;
+    const bool front = !no_front && is16(c->cfg.dtype) && c->front_ws16 && c->front_wc16;
     if (mc_mode == BQ_MC_HEAD) {
-        RUN(bq_stage(c, d_tiles, n, staged, stream));
-        RUN(backbone_impl(c, staged, n, feat, ws, s, nullptr));
+        if (front) {
+            RUN(backbone_impl(c, nullptr, n, feat, ws, s, nullptr, d_tiles));
+        } else {
+            RUN(bq_stage(c, d_tiles, n, staged, stream));
+            RUN(backbone_impl(c, staged, n, feat, ws, s, nullptr));
+        }
         return head_impl(c, feat, n, tile_idx0, mc_n, 0, seed, 1, 1, state, d_mean2, d_std2, ws, s);
     }
     // BQ_MC_FULL: the reference's loop structure -- the whole network once per pass.
     for (int p = 0; p < mc_n; ++p) {
-        RUN(bq_stage(c, d_tiles, n, staged, stream));
-        RUN(backbone_impl(c, staged, n, feat, ws, s, nullptr));
+        if (front) {
+            RUN(backbone_impl(c, nullptr, n, feat, ws, s, nullptr, d_tiles));
+        } else {
+            RUN(bq_stage(c, d_tiles, n, staged, stream));
+            RUN(backbone_impl(c, staged, n, feat, ws, s, nullptr));
+        }
         RUN(head_impl(c, feat, n, tile_idx0, 1, p, seed, p == 0, p == mc_n - 1, state, d_mean2, d_std2, ws, s));
     }
     return BQ_OK;
@@ -1003,6 +1048,19 @@ int64_t bq_debug_activation(bq_ctx* c, const char* name, const void* d_in, int n
     Tap t; t.want = name; t.out = d_out; t.out_elems = out_elems;
     unsigned char* ws = (unsigned char*)d_ws;
     const int r = backbone_impl(c, d_in, n, (float*)(ws + L.feat), ws, (hipStream_t)stream, &t);
+    if (r != BQ_OK) return r;
+    return t.written;
+}
+
+int64_t bq_debug_activation_u8(bq_ctx* c, const char* name, const uint8_t* d_tiles, int n, void* d_ws, size_t ws_bytes,
+                               float* d_out, size_t out_elems, bq_stream_t stream) {
+    if (!c || !name || !d_tiles || !d_ws || !d_out || n <= 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_debug_activation_u8: bad argument");
+    if (!c->loaded) return fail(c, BQ_ERR_WEIGHTS, "weights not loaded");
+    const WsLayout L = ws_layout(c, n, 1);
+    if (ws_bytes < L.total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
+    Tap t; t.want = name; t.out = d_out; t.out_elems = out_elems;
+    unsigned char* ws = (unsigned char*)d_ws;
+    const int r = backbone_impl(c, nullptr, n, (float*)(ws + L.feat), ws, (hipStream_t)stream, &t, d_tiles);
     if (r != BQ_OK) return r;
     return t.written;
 }

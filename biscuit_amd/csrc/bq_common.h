@@ -112,6 +112,10 @@ int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, d
                     hipStream_t s);
 int launch_reinhard(const uint8_t* tiles, int n, int px, const float* d_lut, const float* consts27,
                     const float* tgt_mean, const float* tgt_std, uint8_t* dst, float* d_stats, hipStream_t s);
+int launch_stage_stats(const uint8_t* tiles, int n, int px, double* stats_scratch, hipStream_t s);
+int launch_front(int dtype, const uint8_t* tiles, const unsigned long long* stats, const void* ws16, const float* s_scale,
+                 const float* s_bias, const void* wc16, const float* c_scale, const float* c_bias, void* out, int n, int num_cus,
+                 hipStream_t s);
 int launch_stage_f32(const float* tiles, int n, int px, void* out, int dtype, hipStream_t s);
 // kernels_png.hip: PNG scanline un-filtering (rows: [n][px][1 + 3 px] filter byte + filtered RGB bytes -> out uint8 NHWC)
 int launch_png_unfilter(const unsigned char* rows, int n, int px, unsigned char* out, hipStream_t s);

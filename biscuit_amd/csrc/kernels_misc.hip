@@ -452,6 +452,16 @@ int launch_stage_u8(const uint8_t* tiles, int n, int px, void* out, int dtype, d
     return (int)hipGetLastError();
 }
 
+// the per-tile integer sums alone (2 x 64-bit per tile, zeroed here): the pre-pass of the fused front kernel (kernels_front.hip)
+int launch_stage_stats(const uint8_t* tiles, int n, int px, double* stats_scratch, hipStream_t s) {
+    if (n <= 0) return 0;
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(stats_scratch);
+    hipError_t e = hipMemsetAsync(st, 0, (size_t)n * 16, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(stage_stats_kernel, dim3(n * kStageSlices), dim3(256), 0, s, tiles, px, st);
+    return (int)hipGetLastError();
+}
+
 int launch_stage_f32(const float* tiles, int n, int px, void* out, int dtype, hipStream_t s) {
     if (n <= 0) return 0;
     const long long total = (long long)n * px * px;

@@ -144,16 +144,31 @@ struct DwSums {
 // ---- pointwise: D[cout][pixel] = W[cout][k] * A[pixel][k] from the wave's A tile (LDS operations of a wave complete in order)
 template <typename T, int KS, int NF>
 __device__ __forceinline__ void pointwise(const unsigned char* smem_w, const unsigned char* a_read, int lane, f32x4 (&acc)[NF]) {
+    // Written as an explicit pipeline: all B operands first, the weight fragments in groups of four, one group ahead of the
+    // MFMAs that use them (LDS returns in order: the wait in front of a group is lgkmcnt(4), the next group stays in flight).
+    // Left as `read fragment; mfma` the compiler waits lgkmcnt(0) in front of most MFMAs: an LDS round trip each.
+    constexpr int G = 4, NG = KS * NF / G;
+    static_assert(NF % G == 0, "fragments per k-step in groups of four");
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint4 b[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const uint4 b = *reinterpret_cast<const uint4*>(a_read + ks * 64);
+    for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const uint4*>(a_read + ks * 64);
+    uint4 w[2][G];
+    auto fetch = [&](int grp, uint4 (&dst)[G]) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const uint4 wf = *reinterpret_cast<const uint4*>(smem_w + ((ks * NF + f) * 64 + lane) * 16);
-            if constexpr (STREAM_ABL & 4) { acc[f][0] += __uint_as_float(wf.x ^ b.x); acc[f][1] += __uint_as_float(wf.y ^ b.y); }
-            else acc[f] = mma16<T>(wf, b, acc[f]);
+        for (int i = 0; i < G; ++i)
+            dst[i] = *reinterpret_cast<const uint4*>(smem_w + ((grp * G + i) * 64 + lane) * 16);    // (ks * NF + f) = grp * G + i
+    };
+    fetch(0, w[0]);
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+        if (grp + 1 < NG) fetch(grp + 1, w[(grp + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int ks = (grp * G + i) / NF, f = (grp * G + i) % NF;
+            if constexpr (STREAM_ABL & 4) { acc[f][0] += __uint_as_float(w[grp & 1][i].x ^ b[ks].x); acc[f][1] += __uint_as_float(w[grp & 1][i].y ^ b[ks].y); }
+            else acc[f] = mma16<T>(w[grp & 1][i], b[ks], acc[f]);
         }
     }
 }
@@ -282,6 +297,13 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
         // below 2^32: the offset sum wraps there.)
         unsigned ooff = px < nc ? (unsigned)(((((size_t)img * p.H + y0) * p.W + x0 + px) * COUT + 8 * g) * sizeof(T)) : 0xffffff00u;
         const unsigned ostep = px < nc ? (unsigned)((size_t)p.W * COUT * sizeof(T)) : 0u;
+        // NQ stores the hardware drops, so that the vector-memory queue looks the same on entry to the loop as on its back
+        // edge -- the next row's loads, then a row's stores: the compiler then waits for the LOADS at the top of a step
+        // (vmcnt(NQ)); with "loads only" on entry it merged the two into vmcnt(0) and every step waited for the previous
+        // step's stores to be acknowledged.
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)(0xffffff00u + 16 * q), 0, 0);
         for (int y = y0; y < y1; ++y, ooff += ostep) {
             take_row(y + 1);
             // the row after next, one step ahead of its use (the last step re-reads row y1: an L2 hit, branch-free)
@@ -449,6 +471,10 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
         unsigned VM[4 * NQ];
 #pragma unroll
         for (int i = 0; i < 4 * NQ; ++i) VM[i] = NEG;
+        // (dropped stores: the queue on entry looks like the queue on the back edge, see the plain kernel)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)(0xffffff00u + 16 * q), 0, 0);
 
         for (int y = ys; y <= ye; ++y) {
             // the pooled row this convolution row completes (t even) -- or the next one will (t odd)
@@ -458,14 +484,16 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
             yo = yo < 0 ? 0 : (yo > p.Ho - 1 ? p.Ho - 1 : yo);
             const bool do_emit = ((t_even && t >= 2) || y == p.H - 1) && yo >= p0;
             take_row(y + 1);
-            load_row(y + 2 <= ye + 1 ? y + 2 : ye + 1);
-            __builtin_amdgcn_sched_barrier(0);             // (as in the plain kernel: the loads are issued here)
-            uint4 xb[KR];                                 // shortcut operand of pooled row yo: x[2 yo][xs][32 ks + 8 g ..]
+            // shortcut operand of pooled row yo: x[2 yo][xs][32 ks + 8 g ..].  In FRONT of the next row's loads: vmcnt retires
+            // in order, so the wait for these (inside this step) must not be a wait for the row that is needed a step later
+            uint4 xb[KR];
             {
                 const T* xr = xcol + (size_t)(2 * yo) * p.W * CX;
 #pragma unroll
                 for (int ks = 0; ks < KR; ++ks) xb[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
             }
+            load_row(y + 2 <= ye + 1 ? y + 2 : ye + 1);
+            __builtin_amdgcn_sched_barrier(0);             // (as in the plain kernel: the loads are issued here)
             dws.template push<true>(tap, row, a_lane, AST);
             f32x4 acc[NF];
             pointwise<T, KS, NF>(smem, a_read, lane, acc);

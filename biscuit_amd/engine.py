@@ -257,6 +257,20 @@ class Engine:
         assert rc == out.numel(), (rc, out.numel())
         return out
 
+    def debug_activation_u8(self, name, tiles_u8, shape_hwc):
+        """The same tap on the path ``mc_infer`` takes in a 16-bit context: uint8 tiles [n,299,299,3] through the fused front
+        kernel (standardise + block1_conv1 + block1_conv2 in one launch), then the network up to ``name``."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
+        n = tiles_u8.shape[0]
+        ws = self._ws_for(n, 1)
+        h, w, c = shape_hwc
+        out = torch.empty((n, h, w, c), dtype=torch.float32, device=self.device)
+        rc = self._lib.bq_debug_activation_u8(self._ctx, name.encode(), _ptr(tiles_u8), n, _ptr(ws), ws.numel(),
+                                              _ptr(out), out.numel(), self._stream())
+        self._check(rc)
+        assert rc == out.numel(), (rc, out.numel())
+        return out
+
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on=True):
         self._check(self._lib.bq_profile_enable(self._ctx, 1 if on else 0))

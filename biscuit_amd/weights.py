@@ -327,8 +327,15 @@ def pack_blob(w, dtype='bf16'):
     add('block1_conv1/w', w['block1_conv1/kernel'].reshape(27, 32))
     s, b = fold_bn(w, 'block1_conv1_bn')
     add_affine('block1_conv1', s, b, 32)
+    if half:
+        # kernels_front.hip (round 4): the same weights for the matrix cores -- 16x16x32 fragment order, K = 27 padded to 32,
+        # every fp32 weight as two IEEE halves hi + lo / 2^11 (f16 MFMAs for both 16-bit storage types): [hi, lo][2][64][8]
+        hi, lo = split_f16(pack_fragments16(w['block1_conv1/kernel'].reshape(27, 32), 32, 32))
+        add('block1_conv1/w16', np.concatenate([hi.reshape(-1), lo.reshape(-1)]))
     # stem conv2 as im2col GEMM: k = (dy*3+dx)*32 + c
     npad = add_mat('block1_conv2', w['block1_conv2/kernel'].reshape(288, 64), 288)
+    if half:   # ... and in 16x16x32 fragment order, one k-step per tap (kernels_front.hip)
+        add('block1_conv2/wp16', to_bits(pack_fragments16(w['block1_conv2/kernel'].reshape(288, 64), 288, 64)))
     s, b = fold_bn(w, 'block1_conv2_bn')
     add_affine('block1_conv2', s, b, npad)
     for name, cin, cout in residual_plan():

@@ -186,6 +186,13 @@ int64_t bq_debug_activation(bq_ctx* ctx, const char* name, const void* d_in_nchw
                             void* d_ws, size_t ws_bytes, float* d_out, size_t out_elems,
                             bq_stream_t stream);
 
+/* The same test hook on the path bq_mc_infer takes in a 16-bit context: from the uint8 tiles [n,299,299,3] through the fused
+ * front kernel (standardise + block1_conv1 + block1_conv2 in one launch, csrc/kernels_front.hip), then as above.  "staged"
+ * and "block1_conv1" are not materialised on this path and are refused; every name from "block1_conv2" on is available. */
+int64_t bq_debug_activation_u8(bq_ctx* ctx, const char* name, const uint8_t* d_tiles, int n,
+                               void* d_ws, size_t ws_bytes, float* d_out, size_t out_elems,
+                               bq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,6 +195,44 @@ def test_f16_saturates_instead_of_overflowing(engines):
     assert torch.isfinite(feat).all()
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_fused_front_kernel_against_oracle(engines, oracles, dtype):
+    """The path ``mc_infer`` takes in a 16-bit context: uint8 tiles -> ONE kernel for standardisation + block1_conv1 (on the
+    matrix cores, fp32 weights as two halves) + block1_conv2 (csrc/kernels_front.hip), tapped through
+    ``bq_debug_activation_u8``.  Against the oracle that rounds where the kernels round, at the layer bounds of the
+    three-kernel path it replaces; on tiles whose first byte is not 4-byte aligned (views into a larger tensor: every
+    alignment 0..3 -- the kernel fetches aligned dwords and shifts), on a low-contrast tile, a constant tile (the 1/sqrt(N)
+    floor of the standard deviation) and with the last tile ending exactly at the end of the allocation."""
+    from oracle.xception_ref import standardize
+    eng, orc = engines[dtype], oracles[dtype]
+    t = make_tiles(5, seed=41)
+    t[1] = (t[1] * 0.15 + 100).astype(np.uint8)
+    t[2] = 9
+    taps = {}
+    orc.backbone(standardize(t), taps)
+    big = dev(np.concatenate([np.zeros((1, 299, 299, 3), np.uint8), t]))           # 6 tiles; views from tile 1 on: address % 4 = 3, 2, 1, 0
+    for first in (1, 2, 3, 4, 5):
+        view = big[first:]
+        assert view.data_ptr() % 4 == (first * 299 * 299 * 3) % 4 and view.is_contiguous()
+        for k, (name, shp) in enumerate((('block1_conv2', (147, 147, 64)), ('block2_out', (74, 74, 128)))):
+            got = eng.debug_activation_u8(name, view, shp).cpu().numpy()
+            ref = taps[name].permute(0, 2, 3, 1).numpy()[first - 1:]
+            ulp = ULP[dtype] * np.abs(ref).max()
+            assert np.isfinite(got).all()
+            assert np.abs(got - ref).max() < layer_maxabs_ulps(2 + 4 * k) * ulp, (first, name, np.abs(got - ref).max() / ulp)
+    # the three-kernel path (staging, vector-ALU stem, tile conv2) agrees with it to an occasional last place
+    old = eng.debug_activation('block1_conv2', eng.stage(big[1:]), (147, 147, 64)).cpu().numpy()
+    new = eng.debug_activation_u8('block1_conv2', big[1:], (147, 147, 64)).cpu().numpy()
+    ulp = ULP[dtype] * np.abs(old).max()
+    assert np.abs(new - old).max() <= 1.01 * ulp and float((new != old).mean()) < 0.01
+    with pytest.raises(Exception):
+        eng.debug_activation_u8('block1_conv1', big[1:], (149, 149, 32))      # not materialised on this path: refused, loudly
+    # end to end on the same views: mc_infer from an unaligned view = mc_infer from an aligned copy, bit for bit
+    m0, s0 = eng.mc_infer(big[2:].clone(), 5, 1234)
+    m1, s1 = eng.mc_infer(big[2:], 5, 1234)
+    assert torch.equal(m0, m1) and torch.equal(s0, s1)
+
+
 def test_f16_small_magnitudes_against_the_emulating_oracle():
     """Half precision below 6.1e-5 is subnormal (steps of 6e-8); a trained network's BatchNorm scales can put whole
     channels there.  Weights whose folded BN scale is 1e-4 x (and bias 0) on every other channel of six layers drive those

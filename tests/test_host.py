@@ -155,8 +155,16 @@ def test_blob_directory_roundtrip():
     # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 30 wide layers, of the two streaming
     # layers of block 2 and of the block-2 shortcut inside the fused tail (round 4), and the 32x32x16 copy of the two fused
     # shortcuts (16-bit blobs only)
-    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 30 + 2 + 1 + 2
-    assert {'block2_sepconv1/wp16', 'block2_sepconv2/wp16', 'block2_res/wp16'} <= set(names)
+    # ... and the fused front kernel's two copies: block1_conv1 as f16 hi | lo fragments, block1_conv2 one k-step per tap
+    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 30 + 2 + 1 + 2 + 2
+    assert {'block2_sepconv1/wp16', 'block2_sepconv2/wp16', 'block2_res/wp16', 'block1_conv1/w16', 'block1_conv2/wp16'} <= set(names)
+    assert names['block1_conv1/w16'][1] == 2 * 2 * 64 * 8 * 2 and names['block1_conv2/wp16'][1] == 9 * 4 * 64 * 8 * 2
+    # the two halves of the stem weights give the fp32 weights back to 22 bits: hi + lo / 2^11
+    off, ln = names['block1_conv1/w16']
+    hl = np.frombuffer(blob, np.uint16, ln // 2, off).reshape(2, 2, 64, 8)
+    back = hl[0].view(np.float16).astype(np.float64) + hl[1].view(np.float16).astype(np.float64) / 2048.0
+    want = W.pack_fragments16(w['block1_conv1/kernel'].reshape(27, 32), 32, 32)[0]
+    assert np.abs(back - want).max() <= 2.0 ** -21 * np.abs(want).max()
     assert names['block3_res/wp32'][1] == 8 * 8 * 64 * 8 * 2 and names['block2_res/wp32'][1] == 4 * 4 * 64 * 8 * 2
     assert 'block4_res/wp32' not in names and 'block13_res/wp32' not in names
     assert names['block5_sepconv1/wp16'][1] == 23 * 48 * 64 * 8 * 2 and 'block4_sepconv2/wp16' in names
