@@ -294,8 +294,8 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
         // Stores are raw buffer stores: a lane whose pixel lies outside the strip gets an offset beyond the buffer and the
         // hardware drops its store.  Under `if (px < nc)` hipcc cannot count the stores in vmcnt any more and the wait for
         // the next input row becomes a wait for this row's stores as well (vmcnt retires in order).  (+ 64 q must stay
-        // below 2^32: the offset sum wraps there.)
-        unsigned ooff = px < nc ? (unsigned)(((((size_t)img * p.H + y0) * p.W + x0 + px) * COUT + 8 * g) * sizeof(T)) : 0xffffff00u;
+        // below 2^32: the offset sum wraps there: 0xfffff000 + 64 * 7.)
+        unsigned ooff = px < nc ? (unsigned)(((((size_t)img * p.H + y0) * p.W + x0 + px) * COUT + 8 * g) * sizeof(T)) : 0xfffff000u;
         const unsigned ostep = px < nc ? (unsigned)((size_t)p.W * COUT * sizeof(T)) : 0u;
         // NQ stores the hardware drops, so that the vector-memory queue looks the same on entry to the loop as on its back
         // edge -- the next row's loads, then a row's stores: the compiler then waits for the LOADS at the top of a step
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
         // step's stores to be acknowledged.
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)(0xffffff00u + 16 * q), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)(0xfffff000u + 16 * q), 0, 0);
         for (int y = y0; y < y1; ++y, ooff += ostep) {
             take_row(y + 1);
             // the row after next, one step ahead of its use (the last step re-reads row y1: an L2 hit, branch-free)
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
         // (dropped stores: the queue on entry looks like the queue on the back edge, see the plain kernel)
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)(0xffffff00u + 16 * q), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)(0xfffff000u + 16 * q), 0, 0);
 
         for (int y = ys; y <= ye; ++y) {
             // the pooled row this convolution row completes (t even) -- or the next one will (t odd)
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
                 }
             }
             {
-                const unsigned off = (do_emit && lane_out) ? obase + (unsigned)yo * (unsigned)(p.Wo * COUT * sizeof(T)) : 0xffffff00u;
+                const unsigned off = (do_emit && lane_out) ? obase + (unsigned)yo * (unsigned)(p.Wo * COUT * sizeof(T)) : 0xfffff000u;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     if (!(STREAM_ABL & 1) || po[q][0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(po[q], orsrc, (int)off + 64 * q, 0, 0);
@@ -578,7 +578,8 @@ inline int pick_bands(long long base_items, int rows, int rows_per_band, int min
 
 template <typename T, int CIN, int COUT, bool RELU_IN>
 int launch_stream(StreamParams<T> p, int num_cus, hipStream_t s) {
-    constexpr int NW = STREAM_NW;
+    // 256 output channels: 64 accumulator registers, 64 KB of weights -> 8 waves (2 per SIMD, 256 registers)
+    constexpr int NW = COUT > 128 ? 8 : STREAM_NW;
     constexpr size_t lds = (size_t)(CIN / 32) * (COUT / 16) * 1024 + 2 * COUT * 4 + (size_t)NW * 16 * (CIN * 2 + 16);
     static_assert(lds <= 160 * 1024, "stream kernel LDS budget");
     auto kern = sepconv_stream_kernel<T, CIN, COUT, RELU_IN, NW>;
@@ -586,7 +587,9 @@ int launch_stream(StreamParams<T> p, int num_cus, hipStream_t s) {
     if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     p.nstrips = (p.W + 15) / 16;
     const long long base_items = (long long)p.n * p.nstrips;
-    p.nbands = pick_bands(base_items, p.H, 25, 4, num_cus * NW);     // bands of ~25 rows (2 halo rows per band)
+    // bands of ~25 rows (2 halo rows per band); the 74 x 74 map: 8 bands, so that 256 images x 5 strips x 8 bands fill the
+    // 2 048 waves five times exactly
+    p.nbands = p.H <= 80 ? pick_bands(base_items, p.H, 10, 4, num_cus * NW) : pick_bands(base_items, p.H, 25, 4, num_cus * NW);
     p.items = (int)(base_items * p.nbands);
     int grid = (p.items + NW - 1) / NW;
     if (grid > num_cus) grid = num_cus;
@@ -625,19 +628,22 @@ int launch_stream_t(int cin, int cout, bool relu_in, const void* in, const void*
     p.nstrips = p.nbands = p.items = 0;
     if (cin == 64 && cout == 128 && !relu_in) return launch_stream<T, 64, 128, false>(p, num_cus, s);
     if (cin == 128 && cout == 128 && !relu_in) return launch_stream<T, 128, 128, false>(p, num_cus, s);
+    if (cin == 128 && cout == 256 && relu_in) return launch_stream<T, 128, 256, true>(p, num_cus, s);
     return (int)hipErrorInvalidValue;
 }
 
 }  // namespace
 
 bool stream_supported(int dtype, int cin, int cout, bool relu_in, long long n, int H, int W) {
-    return dtype != 0 && !relu_in && cout == 128 && (cin == 64 || cin == 128) && H >= 4 && W >= 1 &&
-           n * H * W * (long long)cout * 2 <= 0xffffff00ll;
+    const bool b2 = !relu_in && cout == 128 && (cin == 64 || cin == 128);     // block 2 (147 x 147)
+    const bool b3 = relu_in && cout == 256 && cin == 128;                       // block3_sepconv1 (74 x 74)
+    return dtype != 0 && (b2 || b3) && H >= 4 && W >= 1 &&
+           n * H * W * (long long)cout * 2 <= 0xfffff000ll;
 }
 
 bool tail_supported(int dtype, int cin, int cout, int cx, long long n, int H, int W) {
     return dtype != 0 && cin == 128 && cout == 128 && cx == 64 && H >= 8 && W >= 8 &&
-           n * H * W * (long long)cin * 2 <= 0xffffff00ll;
+           n * H * W * (long long)cin * 2 <= 0xfffff000ll;
 }
 
 // out = maxpool3x3/s2(BN(sepconv2(y1))) + BN(conv1x1/s2(x)); wp16 / wr16: "<sepconv2>/wp16", "<res>/wp16"
