@@ -54,8 +54,9 @@ HALF = ('f16', 'bf16')                            # the 16-bit storage / matrix-
 PEAK_F32 = 157.3e12
 TILES_PER_SLIDE = 1000
 # profiling classes of the entry side (stage, stem, block1_conv2, blocks 2 and 3 with their fused ends): `entry_side_ms`
-ENTRY_SIDE = ('stage_u8', 'stem_conv1', 'conv3x3_k32_n64_147', 'sepconv_k64_n128_147', 'sepconv_k128_n128_147',
-              'respool_147', 'blocktail_147', 'sepconv_k128_n256_74', 'sepconv_k256_n256_74', 'respool_74', 'blocktail_74')
+ENTRY_SIDE = ('stage_u8', 'stage_stats', 'front_stage_stem_conv2', 'stem_conv1', 'conv3x3_k32_n64_147', 'sepconv_k64_n128_147',
+              'sepconv_k128_n128_147', 'respool_147', 'blocktail_147', 'sepconv_k128_n256_74', 'sepconv_k256_n256_74', 'respool_74',
+              'blocktail_74')
 NORM_FIT = {'target_means': [65.0, 12.0, -8.0], 'target_stds': [14.0, 7.0, 6.0]}   # a plausible H&E fit (synthetic)
 
 
@@ -471,10 +472,20 @@ def run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks):
         return load
     slides = [Slide(f's{i:05d}', tiles_of(i, T), T, y_true=i % 2) for i in range(S)]
     wt = min(T, 2 * B)
-    warm = [Slide(f'w{i}', tiles_of(i, wt), wt, y_true=0) for i in range(world * max(1, args.warmup))]
-    # one batch in flight on the whole chip: 25.8 k tiles/s through evaluate() against 25.4 k with two on half the chip each
-    pool_e.set_in_flight(1)
+    warm = [Slide(f'w{i}', tiles_of(i, wt), wt, y_true=0) for i in range(world * max(4, args.warmup))]
+    # batches in flight: calibrated like config 2's loop -- the warm-up slides once with two batches on half the chip each,
+    # once with one on the whole chip, the faster setting kept (every rank adopts the same choice)
     evaluate(pool_e, warm, mc_n=args.mc, seed=1234, batch=B, mc_mode=args.mode, keep_tiles=False, rank=rank, world=world)
+    cands = [n for n in (2, 1) if n <= len(pool_e.engines)]
+    times = []
+    for nfl in cands:
+        pool_e.set_in_flight(nfl)
+        barrier()
+        t0 = time.perf_counter()
+        evaluate(pool_e, warm, mc_n=args.mc, seed=1234, batch=B, mc_mode=args.mode, keep_tiles=False, rank=rank, world=world)
+        barrier()
+        times.append(max_over_ranks(time.perf_counter() - t0))
+    pool_e.set_in_flight(cands[int(np.argmin(times))])
     barrier()
     t0 = time.perf_counter()
     res = evaluate(pool_e, slides, mc_n=args.mc, seed=1234, batch=B, mc_mode=args.mode, keep_tiles=False,

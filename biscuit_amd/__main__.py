@@ -108,6 +108,23 @@ def main(argv=None):
     if args.mc is None:
         args.mc = hp.uq_n
     pool = EnginePool(w, n_streams=args.streams, hp=hp, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local)
+    if args.dtype == 'f16' and (args.model or args.weights) and slides:
+        # f16 clamps at +-65504 without a signal (MODE.FP16_OVFL): with weights from outside, look once before trusting it
+        import torch
+        first = next((s for s in slides if s.n_tiles), None)
+        if first is not None:
+            t = first.load()
+            t = t.rows if hasattr(t, 'rows') else t
+            if not (torch.is_tensor(t) and t.dim() == 3):          # (filtered PNG scanlines are not tiles yet)
+                t = torch.as_tensor(np.ascontiguousarray(t[:8]) if not torch.is_tensor(t) else t[:8]).to(pool.engines[0].device)
+                if norm_fit is not None:
+                    t = pool.engines[0].reinhard_fast(t, norm_fit['target_means'], norm_fit['target_stds'])
+                hr = pool.engines[0].f16_headroom(t)
+                if any(hr['saturated'].values()):
+                    raise SystemExit(f'f16 storage saturates with these weights ({hr["saturated"]}): run with --dtype bf16 or f32')
+                if hr['headroom'] < 8:
+                    print(f'warning: f16 headroom only {hr["headroom"]:.1f}x on the first tiles ({hr["max_abs"]}); '
+                          f'consider --dtype bf16', flush=True)
     res = evaluate(pool, slides, outcome=args.outcome, mc_n=args.mc, seed=args.seed, batch=args.batch,
                    save_dir=args.out, rank=rank, world=world, norm_fit=norm_fit)
     if rank == 0:

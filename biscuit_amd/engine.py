@@ -271,6 +271,32 @@ class Engine:
         assert rc == out.numel(), (rc, out.numel())
         return out
 
+    # layers whose outputs the 16-bit storage can clip: the largest activations of Xception sit behind the un-normalised sums
+    # of the residual stream and in front of the pooled features
+    HEADROOM_TAPS = (('block1_conv2', (147, 147, 64)), ('block2_out', (74, 74, 128)), ('block4_out', (19, 19, 728)),
+                     ('block8_out', (19, 19, 728)), ('block12_out', (19, 19, 728)), ('block13_out', (10, 10, 1024)),
+                     ('block14_sepconv1', (10, 10, 1536)), ('block14_sepconv2', (10, 10, 2048)))
+
+    def f16_headroom(self, tiles_u8, limit=65504.0):
+        """Saturation indicator for the f16 storage type (round-3 advisory): every f16 kernel runs with MODE.FP16_OVFL, so
+        an activation beyond +-65504 is clamped SILENTLY -- harmless on the synthetic weights (peak 10-22), but a trained
+        checkpoint with a saturating layer would give plausible, wrong predictions.  Runs up to eight of ``tiles_u8``
+        through tapped layers and returns ``{'max_abs': {layer: value}, 'saturated': {layer: count}, 'headroom': min over
+        layers of limit / max_abs}``; a caller loading real weights should call it once (the CLI does, on its first tiles)
+        and fall back to bf16 or fp32 if anything saturates.  Meaningless (inf headroom) for the other storage types."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda
+        t = tiles_u8[:min(8, tiles_u8.shape[0], self.max_batch)].contiguous()
+        out = {'max_abs': {}, 'saturated': {}, 'headroom': float('inf'), 'dtype': self.dtype}
+        if self.dtype != 'f16' or t.shape[0] == 0:
+            return out
+        for name, shp in self.HEADROOM_TAPS:
+            a = self.debug_activation_u8(name, t, shp)
+            m = float(a.abs().max())
+            out['max_abs'][name] = m
+            out['saturated'][name] = int((a.abs() >= limit).sum())
+            out['headroom'] = min(out['headroom'], limit / max(m, 1e-30))
+        return out
+
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on=True):
         self._check(self._lib.bq_profile_enable(self._ctx, 1 if on else 0))

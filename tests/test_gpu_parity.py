@@ -311,6 +311,22 @@ def test_headline_mode_against_the_committed_stress_fixture():
         eng.close()
 
 
+def test_f16_headroom_indicator(engines, tiles):
+    """The saturation indicator of the f16 mode (round-3 advisory): quiet on the synthetic weights (activations peak at a few
+    tens), loud on a network whose first BatchNorm scales its outputs beyond 65504."""
+    from biscuit_amd.engine import Engine
+    hr = engines['f16'].f16_headroom(dev(tiles))
+    assert set(hr['max_abs']) == {n for n, _ in Engine.HEADROOM_TAPS} and not any(hr['saturated'].values())
+    assert hr['headroom'] > 100 and max(hr['max_abs'].values()) < 600
+    assert engines['bf16'].f16_headroom(dev(tiles))['headroom'] == float('inf')
+    w = dict(synthetic_weights(1))
+    w['block1_conv2_bn/gamma'] = w['block1_conv2_bn/gamma'] * 3.0e4          # conv2 outputs far beyond the f16 range
+    e = Engine(w, dtype='f16', max_batch=8, max_mc=8)
+    hr = e.f16_headroom(dev(tiles))
+    assert hr['saturated']['block1_conv2'] > 0 and hr['max_abs']['block1_conv2'] == 65504.0 and hr['headroom'] <= 1.0
+    e.close()
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_full_mode_batching_and_determinism_bit_exact(engines, tiles, dtype):
     eng = engines[dtype]
