@@ -6,8 +6,8 @@
 // 708 MB of output.  Here the two intermediate tensors never leave the CU:
 //  * the per-tile statistics (exact integer sums, kernels_misc.hip: stage_stats_kernel) are the only pre-pass;
 //  * a work item is a strip of <= 16 conv2 output columns x a band of rows; the wave walks down, one conv2 row per step,
-//    and keeps the three stem rows that row needs in a 3 KB ring in LDS;
-//  * a step fetches the three uint8 rows of ONE new stem row (99 bytes each, as aligned dwords, one step ahead), and
+//    two conv2 rows per step, and keeps the four stem rows they need in a 4 KB ring in LDS;
+//  * a step fetches the uint8 rows of its two new stem rows (three rows of 99 bytes each, as aligned dwords, one step ahead), and
 //    builds the stem convolution's MFMA operand from them: lane (pixel slot, k-group) picks its eight bytes of the
 //    27-byte window (k = (dy, dx, c), the order of the weights), standardises them with the arithmetic of the staging
 //    kernel -- ((float)u8 - mean) * inv, rounded to the storage type: the same values the planar tensor held -- ;
@@ -22,6 +22,12 @@
 //  * epilogue straight from the accumulators: BN + ReLU, two 16-byte stores per lane (64 contiguous bytes of 16 pixels each).
 // 11 independent waves per CU, no workgroup barrier after the weights are in LDS.
 #include "gemm_common.h"
+
+// ablation switches of tools/ubench/stream_bench.hip (timing only, wrong results): 1 no stores, 4 no conv2 MFMAs, 8 no uint8
+// loads, 32 no stem (operand build + MFMAs + epilogue).  The product build has none of them.
+#ifndef FRONT_ABL
+#define FRONT_ABL 0
+#endif
 
 namespace {
 using namespace bqk;
@@ -86,7 +92,8 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
     constexpr int U8_PITCH = 112;               // bytes per staged uint8 row (99 + up to 3 of alignment, as 26 dwords)
     constexpr int U8_DW = 26;
     constexpr int RING_PITCH = 16 * 64;         // one stem row of the strip: 16 pixels x 32 channels
-    constexpr int PRIV = 3 * U8_PITCH + 3 * RING_PITCH;
+    constexpr int NRING = 4;                    // stem rows y .. y + 3: two conv2 rows per step
+    constexpr int PRIV = 3 * U8_PITCH + NRING * RING_PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,7 +111,7 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
     __syncthreads();                            // the only workgroup barrier
 
     unsigned char* const u8l = smem + PRIV_OFF + wave * PRIV;          // three staged uint8 rows
-    unsigned char* const ring = u8l + 3 * U8_PITCH;                    // three stem rows
+    unsigned char* const ring = u8l + 3 * U8_PITCH;                    // four stem rows
     const int px = lane & 15, g = lane >> 4;
     const float* const sbs = reinterpret_cast<const float*>(smem + SB_OFF) + 8 * g;         // stem scale (+32: bias)
     const float* const sbc = reinterpret_cast<const float*>(smem + SB_OFF) + 64 + 8 * g;    // conv2 scale (+64: bias)
@@ -159,20 +166,23 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
             a4 = a4 < 0 ? 0 : (a4 > last4 ? last4 : a4);
             shr_out = (int)over * 8;
             shl_out = shl;
+            if constexpr (FRONT_ABL & 8) return (unsigned)a4;
             return *reinterpret_cast<const unsigned*>(p.tiles + a4);
         };
         const int lrow = lane >> 5, ldw = lane & 31;
-        unsigned ua = 0, ub = 0;
-        int ua_r = 0, ua_l = 0, ub_r = 0, ub_l = 0;
-        auto load_u8 = [&](int sy) {
+        struct U8 { unsigned a, b; int a_r, a_l, b_r, b_l; };
+        U8 uA{}, uB{};                              // the uint8 rows of the two stem rows of the next step
+        auto load_u8 = [&](int sy, U8& u) {
             const int syc = sy > SO - 1 ? SO - 1 : sy;
             const long long r0 = tile_off + (long long)(2 * syc) * ROWB + 6 * x0;
-            ua = load_dw(r0 + lrow * ROWB, ldw, ua_r, ua_l);
-            ub = load_dw(r0 + 2 * ROWB, ldw, ub_r, ub_l);
+            u.a = load_dw(r0 + lrow * ROWB, ldw, u.a_r, u.a_l);
+            u.b = load_dw(r0 + 2 * ROWB, ldw, u.b_r, u.b_l);
         };
         const uint8_t* const tile = p.tiles + tile_off;
-        // stem row sy -> ring slot sy % 3 (its uint8 rows are in ua / ub)
-        auto stem_row = [&](int sy, int slot) {
+        // stem row sy -> ring slot `slot` (its uint8 rows are in u)
+        auto stem_row = [&](int sy, int slot, const U8& u) {
+            const unsigned ua = u.a, ub = u.b;
+            const int ua_r = u.a_r, ua_l = u.a_l, ub_r = u.b_r, ub_l = u.b_l;
             const int syc = sy > SO - 1 ? SO - 1 : sy;
             const uint8_t* r0 = tile + (size_t)(2 * syc) * ROWB + 6 * x0;
             // byte offset of the window's first byte inside each staged row (rows are 897 bytes apart: the shifts differ)
@@ -180,7 +190,11 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
                       sh2 = (int)(reinterpret_cast<uintptr_t>(r0 + 2 * ROWB) & 3);
             {   // every lane stores (lanes past the 26 dwords into the row's padding, both halves the same third row): under
                 // `if (ldw < 26)` the compiler loses count of what is in flight and waits for the previous step's stores too
-                const int dwc = ldw < U8_DW ? ldw : U8_PITCH / 4 - 1;
+                if constexpr (FRONT_ABL & 32) {
+                if (ua == 0x12345u) *reinterpret_cast<unsigned*>(ring + slot * RING_PITCH + lane * 4) = ua ^ ub;
+                return;
+            }
+            const int dwc = ldw < U8_DW ? ldw : U8_PITCH / 4 - 1;
                 *reinterpret_cast<unsigned*>(u8l + lrow * U8_PITCH + 4 * dwc) = (ua >> ua_r) << ua_l;
                 *reinterpret_cast<unsigned*>(u8l + 2 * U8_PITCH + 4 * dwc) = (ub >> ub_r) << ub_l;
             }
@@ -226,38 +240,49 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
             }
         };
 
-        load_u8(y0);
-        stem_row(y0, 0);
-        load_u8(y0 + 1);
-        stem_row(y0 + 1, 1);
-        load_u8(y0 + 2);
-        // Two stores the hardware drops (offset past the buffer), so that the vector-memory queue looks the same on entry
-        // to the loop as on its back edge -- two loads, then two stores: the compiler then waits for the LOADS at the top of a
-        // step (vmcnt(3), vmcnt(2)); with nothing here it merged "loads only" and "loads + stores" into vmcnt(1) / vmcnt(0)
-        // and every step waited for the previous step's stores to be acknowledged.
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)0xffffff00u, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)0xffffff40u, 0, 0);
-        int s0 = 0, s1 = 1, s2 = 2;              // ring slots of stem rows y, y + 1, y + 2
+        load_u8(y0, uA);
+        load_u8(y0 + 1, uB);
+        stem_row(y0, 0, uA);
+        stem_row(y0 + 1, 1, uB);
+        load_u8(y0 + 2, uA);
+        load_u8(y0 + 3, uB);
+        // Four stores the hardware drops (offset past the buffer), so that the vector-memory queue looks the same on entry
+        // to the loop as on its back edge -- four loads, then four stores: the compiler then waits for the LOADS at the top of
+        // a step; with nothing here it merged "loads only" and "loads + stores" into the weaker wait and every step waited for
+        // the previous step's stores to be acknowledged.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)(0xffffff00u + 16 * q), 0, 0);
+        int s0 = 0, s1 = 1, s2 = 2, s3 = 3;      // ring slots of stem rows y .. y + 3
         unsigned ooff = px < nc ? (unsigned)(((((size_t)img * CO + y0) * CO + x0 + px) * 64 + 8 * g) * sizeof(T)) : 0xffffff00u;
         const unsigned ostep = px < nc ? (unsigned)(CO * 64 * sizeof(T)) : 0u;
-        for (int y = y0; y < y1; ++y, ooff += ostep) {
-            stem_row(y + 2, s2);
-            load_u8(y + 3 <= y1 + 1 ? y + 3 : y1 + 1);           // the next stem row's bytes, one step ahead (the last step: a re-read)
+        // TWO conv2 rows per step: they share two of their three stem rows and every weight fragment, so a step reads 36 + 12
+        // KB from LDS for two rows where one row per step read 36 + 9 per row -- the conv2 stage ran at ~45 % of both the LDS
+        // bandwidth and the matrix pipe, each waiting for the other.
+        for (int y = y0; y < y1; y += 2, ooff += 2 * ostep) {
+            stem_row(y + 2, s2, uA);
+            stem_row(y + 3, s3, uB);
+            {   // the next step's stem rows, one step ahead (past the band: re-reads of its last row)
+                const int last = y1 + 1;
+                load_u8(y + 4 <= last ? y + 4 : last, uA);
+                load_u8(y + 5 <= last ? y + 5 : last, uB);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- block1_conv2: nine taps, each one k-step of 32 channels
-            f32x4 acc[4];
+            // ---- block1_conv2: nine taps, each one k-step of 32 channels; accumulators [row][fragment]
+            f32x4 acc[2][4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            {   // an explicit pipeline: the nine B operands first, the weight fragments one tap (four fragments) ahead of their
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[r][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            {   // an explicit pipeline: the twelve B operands first, the weight fragments one tap (four fragments) ahead of their
                 // MFMAs -- LDS returns in order, so the wait in front of a tap is lgkmcnt(4); left as `read; mfma` the compiler
-                // waited lgkmcnt(0) in front of most of the 36 MFMAs, an LDS round trip each
-                uint4 b[9];
+                // waited lgkmcnt(0) in front of most MFMAs, an LDS round trip each
+                uint4 b[4][3];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) {
-                    const int slot = dy == 0 ? s0 : (dy == 1 ? s1 : s2);
+                for (int r = 0; r < 4; ++r) {
+                    const int slot = r == 0 ? s0 : (r == 1 ? s1 : (r == 2 ? s2 : s3));
                     const unsigned char* rp = ring + slot * RING_PITCH + (px < SW ? px : SW - 1) * 64 + g * 16;   // (slots 14, 15 are not outputs)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) b[dy * 3 + dx] = *reinterpret_cast<const uint4*>(rp + dx * 64);
+                    for (int dx = 0; dx < 3; ++dx) b[r][dx] = *reinterpret_cast<const uint4*>(rp + dx * 64);
                 }
                 uint4 w[2][4];
                 auto fetch = [&](int t, uint4 (&dst)[4]) {
@@ -268,23 +293,33 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     if (t + 1 < 9) fetch(t + 1, w[(t + 1) & 1]);
+                    const int dy = t / 3, dx = t % 3;
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[f] = mmaT<T>(w[t & 1][f], b[t], acc[f]);
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            if constexpr (FRONT_ABL & 4) { acc[r][f][0] += __uint_as_float(w[t & 1][f].x ^ b[dy + r][dx].x); acc[r][f][1] += __uint_as_float(w[t & 1][f].y ^ b[dy + r][dx].w); }
+                            else acc[r][f] = mmaT<T>(w[t & 1][f], b[dy + r][dx], acc[r][f]);
+                        }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float4 a0 = *reinterpret_cast<const float4*>(sbc + 32 * q), a1 = *reinterpret_cast<const float4*>(sbc + 32 * q + 4);
-                const float4 b0 = *reinterpret_cast<const float4*>(sbc + 64 + 32 * q), b1 = *reinterpret_cast<const float4*>(sbc + 64 + 32 * q + 4);
-                const f32x4 u = acc[2 * q], v = acc[2 * q + 1];
-                u32x4s o;
-                o[0] = H16<T>::pack2(fmaxf(fmaf(u[0], a0.x, b0.x), 0.f), fmaxf(fmaf(u[1], a0.y, b0.y), 0.f));
-                o[1] = H16<T>::pack2(fmaxf(fmaf(u[2], a0.z, b0.z), 0.f), fmaxf(fmaf(u[3], a0.w, b0.w), 0.f));
-                o[2] = H16<T>::pack2(fmaxf(fmaf(v[0], a1.x, b1.x), 0.f), fmaxf(fmaf(v[1], a1.y, b1.y), 0.f));
-                o[3] = H16<T>::pack2(fmaxf(fmaf(v[2], a1.z, b1.z), 0.f), fmaxf(fmaf(v[3], a1.w, b1.w), 0.f));
-                __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)ooff + 64 * q, 0, 0);
+            for (int r = 0; r < 2; ++r) {
+                const unsigned off = r == 0 ? ooff : (y + 1 < y1 ? ooff + ostep : 0xffffff00u);     // (an odd band: the last step's second row is dropped)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(sbc + 32 * q), a1 = *reinterpret_cast<const float4*>(sbc + 32 * q + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(sbc + 64 + 32 * q), b1 = *reinterpret_cast<const float4*>(sbc + 64 + 32 * q + 4);
+                    const f32x4 u = acc[r][2 * q], v = acc[r][2 * q + 1];
+                    u32x4s o;
+                    o[0] = H16<T>::pack2(fmaxf(fmaf(u[0], a0.x, b0.x), 0.f), fmaxf(fmaf(u[1], a0.y, b0.y), 0.f));
+                    o[1] = H16<T>::pack2(fmaxf(fmaf(u[2], a0.z, b0.z), 0.f), fmaxf(fmaf(u[3], a0.w, b0.w), 0.f));
+                    o[2] = H16<T>::pack2(fmaxf(fmaf(v[0], a1.x, b1.x), 0.f), fmaxf(fmaf(v[1], a1.y, b1.y), 0.f));
+                    o[3] = H16<T>::pack2(fmaxf(fmaf(v[2], a1.z, b1.z), 0.f), fmaxf(fmaf(v[3], a1.w, b1.w), 0.f));
+                    if (!(FRONT_ABL & 1) || o[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)off + 64 * q, 0, 0);
+                }
             }
-            const int t = s0; s0 = s1; s1 = s2; s2 = t;
+            { const int t0 = s0, t1 = s1; s0 = s2; s1 = s3; s2 = t0; s3 = t1; }
         }
     }
 }
@@ -309,7 +344,7 @@ int launch_front_t(const uint8_t* tiles, const unsigned long long* stats, const 
     }
     p.nbands = nb;
     p.items = (int)(base_items * nb);
-    constexpr size_t lds = 2 * 2 * 1024 + 9 * 4 * 1024 + 192 * 4 + (size_t)NWF * (3 * 112 + 3 * 16 * 64);
+    constexpr size_t lds = 2 * 2 * 1024 + 9 * 4 * 1024 + 192 * 4 + (size_t)NWF * (3 * 112 + 4 * 16 * 64);
     static_assert(lds <= 160 * 1024, "front kernel LDS budget");
     auto kern = front_stream_kernel<T>;
     static BqLdsAttr attr;

@@ -3,6 +3,7 @@
 // plain 16-byte copy of the same bytes as the box's calibration.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSTREAM_NW=16 -DSTREAM_ABL=1 ...] -o stream_bench stream_bench.hip
 #include "../../biscuit_amd/csrc/kernels_stream.hip"
+#include "../../biscuit_amd/csrc/kernels_front.hip"
 
 #include <cstdio>
 #include <cstring>
@@ -74,6 +75,32 @@ int main(int argc, char** argv) {
             checksum<<<1024, 256>>>((const unsigned*)out2, (size_t)n * 74 * 74 * 64, cs);
             unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
             printf("%-28s tail    : %.4f ms  %.0f GB/s  checksum %016llx\n", tag, ms, gb / ms * 1e3, h);
+        }
+    }
+    {   // fused front: uint8 tiles -> conv2 output (147 x 147 x 64)
+        uint8_t* u8; unsigned long long* st; uint4 *ws16, *wc16; unsigned short* o3;
+        const size_t tb = (size_t)n * 299 * 299 * 3;
+        CK(hipMalloc(&u8, tb)); CK(hipMalloc(&st, (size_t)n * 16)); CK(hipMalloc(&ws16, 4096)); CK(hipMalloc(&wc16, 36864));
+        CK(hipMalloc(&o3, px * 64 * 2));
+        fill_rand<<<2048, 256>>>((unsigned short*)u8, tb / 2, 11);
+        fill_rand<<<16, 256>>>((unsigned short*)ws16, 2048, 12);
+        fill_rand<<<64, 256>>>((unsigned short*)wc16, 18432, 13);
+        {
+            std::vector<unsigned long long> h(2 * n);
+            for (int i = 0; i < n; ++i) { h[2 * i] = 128ull * 268203; h[2 * i + 1] = (128ull * 128 + 5400) * 268203; }
+            CK(hipMemcpy(st, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+        }
+        const double gb = ((double)tb + (double)px * 64 * 2) / 1e9;
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int i = 0; i < 3; ++i) if (launch_front(2, u8, st, ws16, sc, bi, wc16, sc, bi, o3, n, 256, 0)) { printf("front launch failed\n"); return 1; }
+            CK(hipEventRecord(a));
+            for (int i = 0; i < 20; ++i) launch_front(2, u8, st, ws16, sc, bi, wc16, sc, bi, o3, n, 256, 0);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
+            CK(hipMemset(cs, 0, 8));
+            checksum<<<1024, 256>>>((const unsigned*)o3, px * 32, cs);
+            unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
+            printf("%-28s front   : %.4f ms  %.0f GB/s  checksum %016llx\n", tag, ms, gb / ms * 1e3, h);
         }
     }
     {   // calibration: copy of 1.42 GB (read + write 2.83 GB)
