@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
             const bool t_even = (t & 1) == 0;
             int yo = (t - 1) >> 1;
             yo = yo < 0 ? 0 : (yo > p.Ho - 1 ? p.Ho - 1 : yo);
-            const bool do_emit = ((t_even && t >= 2) || y == p.H - 1) && yo >= p0;
+            const bool do_emit = (t_even ? t >= 2 : y == p.H - 1) && yo >= p0 && y <= ye;
             take_row(y + 1);
             // shortcut operand of pooled row yo: x[2 yo][xs][32 ks + 8 g ..].  In FRONT of the next row's loads: vmcnt retires
             // in order, so the wait for these (inside this step) must not be a wait for the row that is needed a step later
@@ -565,6 +565,261 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
     }
 }
 
+inline int pick_bands(long long base_items, int rows, int rows_per_band, int min_rows, int waves);
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Block tail for 256 channels (block 3 at 74x74): the same fusion, waves COOPERATING on a strip.
+//
+// K = N = 256 does not fit a wave-private strip: 128 KB of pointwise weights per wave is neither LDS nor registers.  Split
+// over the eight waves of a workgroup it fits in REGISTERS: wave w owns output channels [32 w, 32 w + 32) -- one fragment
+// pair, 8 k-steps x 2 fragments = 64 registers of sepconv2 weights and 32 of shortcut weights, loaded once per workgroup --
+// and the depthwise convolution of input channels [32 w, 32 w + 32) (lane = channel pair x a group of four columns).  One
+// strip step:
+//   every wave pushes the new row through ITS channels' running sums and writes its 64-byte slice of the 16 pixels' A rows
+//   (double-buffered) -> ONE workgroup barrier (LDS only: `s_waitcnt lgkmcnt(0); s_barrier`, the row prefetch stays in
+//   flight) -> every wave multiplies the whole A tile (K = 256) by its own 32 columns -> folded BN, running maximum, and on
+//   the rows that complete a pool window the horizontal maximum by DPP, the shortcut's 8 MFMAs on x fetched in operand
+//   layout, add, 16-byte stores -- all per wave on its own 32 channels: pooling is per channel, nothing crosses waves.
+// No weight traffic at all in the loop (the wide kernel streams 128 KB per 148 pixels from L2), no halo image, and the
+// 74x74x256 tensor between the convolution and the pool is never written.
+template <typename T>
+struct CoopParams {
+    const T* in;           // sepconv2's input [n][H][W][256]
+    const uint4* wp16;     // [8][16][64] x 16 B
+    const float* dw;       // [9][256]
+    const float* scale;    // [256]
+    const float* bias;
+    const T* x;            // the block's input [n][H][W][128]
+    const uint4* wr16;     // [4][16][64] x 16 B
+    const float* rscale;
+    const float* rbias;
+    T* out;                // [n][Ho][Wo][256]
+    int n, H, W, Ho, Wo;
+    int nstrips, nbands, items;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(512) block_tail_coop_kernel(const CoopParams<T> p) {
+    if constexpr (H16<T>::F16) bq_f16_saturate();
+    constexpr int CIN = 256, COUT = 256, CX = 128, KS = CIN / 32, KR = CX / 32, NCOL = 4, NWIN = NCOL + 2;
+    constexpr int AST = CIN * 2 + 16;
+    constexpr int A_BYTES = 16 * AST;
+    constexpr int SB_OFF = 2 * A_BYTES;         // scale | bias | rscale | rbias, fp32 [4][COUT]
+    constexpr unsigned NEG = NegInf<T>::v;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < COUT; i += 512) {
+        float* sbw = reinterpret_cast<float*>(smem + SB_OFF);
+        sbw[i] = p.scale[i]; sbw[COUT + i] = p.bias[i]; sbw[2 * COUT + i] = p.rscale[i]; sbw[3 * COUT + i] = p.rbias[i];
+    }
+    // this wave's weights: fragments 2 w and 2 w + 1 of every k-step, in registers for the whole kernel
+    uint4 wq[KS][2], wrq[KR][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wq[ks][i] = p.wp16[((size_t)ks * 16 + 2 * wave + i) * 64 + lane];
+#pragma unroll
+    for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wrq[ks][i] = p.wr16[((size_t)ks * 16 + 2 * wave + i) * 64 + lane];
+    const int pair = lane & 15, cg = lane >> 4;                      // depthwise role: channels 32 w + 2 pair (+1), columns 4 cg .. 4 cg + 3
+    f32x2s tap[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tap[t] = *reinterpret_cast<const f32x2s*>(p.dw + t * CIN + 32 * wave + 2 * pair);
+    __syncthreads();
+
+    const int px = lane & 15, g = lane >> 4;                         // matrix role: pixel slot, channel group
+    const float* const sb = reinterpret_cast<const float*>(smem + SB_OFF) + 32 * wave + 8 * g;
+    const int wgx = xcd_tile(blockIdx.x, gridDim.x);
+    const int pt = p.H & 1, pl = p.W & 1;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.out, 0, (int)((size_t)p.n * p.Ho * p.Wo * COUT * sizeof(T)), 0x00020000);
+
+    for (int item = wgx; item < p.items; item += (int)gridDim.x) {
+        const int strip = item % p.nstrips;
+        const int t1 = item / p.nstrips;
+        const int band = t1 % p.nbands;
+        const int img = t1 / p.nbands;
+        int xo_a, npx, p0, npb;
+        strip_span(strip, p.Wo, p.nstrips, xo_a, npx);
+        band_span(band, p.Ho, p.nbands, p0, npb);
+        const int x0 = 2 * xo_a - pl;
+        int ys = 2 * p0 - pt;
+        int ye = 2 * (p0 + npb - 1) - pt + 2;
+        ye = ye > p.H - 1 ? p.H - 1 : ye;                            // (ys = -1 with a padded top row: a ghost step, below)
+        const int xl = x0 - 1 + NCOL * cg;                           // image column of this lane's window column 0
+        unsigned cmask = 0;
+#pragma unroll
+        for (int j = 0; j < NWIN; ++j) cmask |= ((unsigned)(xl + j) < (unsigned)p.W) ? (1u << j) : 0u;
+        const bool inner = x0 >= 1 && x0 + 16 < p.W;                 // (wave-uniform) no window column outside the image
+        const T* const img_in = p.in + ((size_t)img * p.H * p.W + xl) * CIN + 32 * wave + 2 * pair;
+        const bool col_out = (unsigned)(x0 + px) >= (unsigned)p.W;
+        const bool any_col_out = x0 < 0 || x0 + 15 >= p.W;
+        int xs = x0 + (px | 1) - (1 - pl);
+        xs = xs < 0 ? 0 : (xs > p.W - 1 ? p.W - 1 : xs);
+        const T* const xcol = p.x + ((size_t)img * p.H * p.W + xs) * CX + 8 * g;
+        const bool lane_out = (px & 1) && (px >> 1) < npx;
+        const unsigned obase = (unsigned)((((size_t)img * p.Ho * p.Wo + xo_a + (px >> 1)) * COUT + 32 * wave + 8 * g) * sizeof(T));
+
+        // two register sets for rows in flight: a step consumes the row loaded TWO steps earlier (a step is ~1 us here, less
+        // than an HBM round trip under load: with one set the kernel waited for its loads, 0.57 against 0.40 ms without them)
+        unsigned nxA[NWIN], nxB[NWIN], row[NWIN];
+        auto load_row = [&](int y, unsigned (&nx)[NWIN]) {
+            const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
+            const T* rp = img_in + (size_t)yc * p.W * CIN;
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) {
+                if constexpr (STREAM_ABL & 8) nx[j] = (unsigned)(size_t)rp + j;
+                else nx[j] = *reinterpret_cast<const unsigned*>(rp + j * CIN);
+            }
+        };
+        auto take_row = [&](int y, const unsigned (&nx)[NWIN]) {
+            const unsigned m = (unsigned)y < (unsigned)p.H ? cmask : 0u;
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) row[j] = nx[j];
+            if (inner && (unsigned)y < (unsigned)p.H) return;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < NWIN; ++j) row[j] = ((m >> j) & 1u) ? row[j] : 0u;
+        };
+        DwSums<T, NCOL> dws;
+        dws.clear();
+        unsigned char* a_lane0 = smem + (NCOL * cg) * AST + (32 * wave + 2 * pair) * 2;      // buffer 0; buffer 1 at + A_BYTES
+        // Software pipeline: a step pushes row y + 2 -- the depthwise output of row y + 1 goes to the OTHER A buffer -- and
+        // multiplies row y's A tile, written a step earlier: the vector ALU work of the next row and the matrix work of this
+        // one are independent inside a wave (first form, depthwise -> barrier -> matrix on the same row: both waves of a SIMD
+        // in the same phase at the same time, 0.61 ms).
+        uint4 xb[KR];                                 // shortcut operand x[2 yo][xs][32 ks + 8 g ..] of the next window to complete
+        auto load_x = [&](int yo) {
+            const T* xr = xcol + (size_t)(2 * yo) * p.W * CX;
+#pragma unroll
+            for (int ks = 0; ks < KR; ++ks) {
+                if constexpr (STREAM_ABL & 8) xb[ks] = make_uint4((unsigned)(size_t)xr, ks, 3, 4);
+                else xb[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
+            }
+        };
+        load_x(p0);       // the first window this band completes; OLDEST in the queue: the first emit must not wait for the rows
+        load_row(ys - 1, nxA); load_row(ys, nxB);
+        take_row(ys - 1, nxA); load_row(ys + 1, nxA);
+        dws.template push<false>(tap, row, a_lane0, AST);
+        take_row(ys, nxB); load_row(ys + 2, nxB);
+        dws.template push<false>(tap, row, a_lane0, AST);
+        take_row(ys + 1, nxA); load_row(ys + 3, nxA);
+        dws.template push<true>(tap, row, a_lane0, AST);                 // row ys -> buffer 0
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        unsigned VM[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) VM[i] = NEG;
+        // (queue shape, see the plain kernel: the compiler's wait for a row is the minimum over the paths into the loop of the
+        //  operations behind it -- 17 on the back edge; six dropped stores make the way in from here look the same)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)              // (distinct offsets: identical stores are merged into one)
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4s){0u, 0u, 0u, 0u}, orsrc, (int)(0xfffff000u + 16u * i), 0, 0);
+        // one strip row: `buf` = the A buffer of row y (0 / 1, static), nx = the register set that holds input row y + 2
+        auto step = [&](int y, int buf, unsigned (&nx)[NWIN], auto parity) {
+            const int t = y + pt;
+            constexpr bool t_even = decltype(parity)::value;                  // static: see the loop below
+            int yo = (t - 1) >> 1;
+            yo = yo < 0 ? 0 : (yo > p.Ho - 1 ? p.Ho - 1 : yo);
+            const bool do_emit = (t_even ? t >= 2 : y == p.H - 1) && yo >= p0 && y <= ye;
+            take_row(y + 2, nx);
+            load_row(y + 4 <= ye + 2 ? y + 4 : ye + 2, nx);                 // two steps ahead, into the set just consumed
+            __builtin_amdgcn_sched_barrier(0);
+            // matrix stage of row y (its A tile was completed by the barrier at the end of the previous step) ...
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            {
+                const unsigned char* ar = smem + buf * A_BYTES + px * AST + g * 16;
+                uint4 b[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) b[ks] = *reinterpret_cast<const uint4*>(ar + ks * 64);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if constexpr (STREAM_ABL & 4) { acc[i][0] += __uint_as_float(wq[ks][i].x ^ b[ks].x); acc[i][1] += __uint_as_float(wq[ks][i].y ^ b[ks].y); }
+                        else acc[i] = mma16<T>(wq[ks][i], b[ks], acc[i]);
+                    }
+            }
+            // ... next to the depthwise stage of row y + 1 (-> the other buffer)
+            dws.template push<true>(tap, row, a_lane0 + (buf ^ 1) * A_BYTES, AST);
+            unsigned cur[4];
+            bn_pair<T>(acc[0], acc[1], sb, COUT, cur);
+            if (any_col_out || y < 0) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur[i] = (col_out || y < 0) ? NEG : cur[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) VM[i] = pmax2<T>(VM[i], cur[i]);
+            u32x4s po = {0u, 0u, 0u, 0u};
+            if (do_emit) {
+                asm volatile("" ::: "memory");
+                f32x4 ar[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) ar[i] = mma16<T>(wrq[ks][i], xb[ks], ar[i]);
+                unsigned res[4];
+                bn_pair<T>(ar[0], ar[1], sb + 2 * COUT, COUT, res);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned c = VM[i];
+                    const unsigned lft = (unsigned)__builtin_amdgcn_mov_dpp((int)c, 0x111, 0xf, 0xf, true);
+                    const unsigned rgt = (unsigned)__builtin_amdgcn_mov_dpp((int)c, 0x101, 0xf, 0xf, true);
+                    po[i] = padd2<T>(pmax2<T>(pmax2<T>(lft, c), rgt), res[i]);
+                }
+            }
+            {
+                const unsigned off = (do_emit && lane_out) ? obase + (unsigned)yo * (unsigned)(p.Wo * COUT * sizeof(T)) : 0xfffff000u;
+                if (!(STREAM_ABL & 1) || po[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(po, orsrc, (int)off, 0, 0);
+            }
+            // The shortcut operand of the NEXT regular emit (two steps on: windows complete on every other row), behind this
+            // step's use of the registers.  vmcnt retires in order: fetched at the top of the emitting step itself, the wait
+            // for it was a wait for the row prefetch issued before it and for the previous step's store as well.  (The cut-off
+            // window at the image's bottom completes on row H - 1, t odd, ONE step after a regular one: the clamp below makes
+            // that step's fetch the cut-off window's operand.  No fetch inside the emit: the compiler would drain the queue.)
+            if constexpr (t_even) {
+                load_x((t >> 1) > p.Ho - 1 ? p.Ho - 1 : (t >> 1));           // row t + 2 completes window t / 2
+#pragma unroll
+                for (int i = 0; i < 4; ++i) VM[i] = cur[i];
+            }
+            // row y + 1's A tile is complete, and row y's is read, when every wave is here: ONE LDS-only barrier per row
+            if constexpr (STREAM_ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        };
+        // (input row y + 2 of the first step sits in set B, of the second in set A: see the prologue)
+        // Steps come in pairs with STATIC roles -- A buffer, register set, and the parity of t = y + pt: a band starts on an even
+        // t (ys = 2 p0 - pt; -1 when the image's padded top row is in the band: a ghost step whose row counts as -inf) and ends
+        // with a ghost step when its row count is odd (y = ye + 1: clamped loads, no emit).  Both matter to the compiler's
+        // wait counts, which are a minimum over every path it can see: with `if (y + 1 <= ye) step(...)` there is a path from
+        // the first step straight back to the loop head (vmcnt(5..1) at the top of every pair: no prefetch distance left);
+        // with a runtime parity, a path "fetch x at the end of one step, use it in the next" (the emit waits for the rows).
+        for (int y = ys; y <= ye; y += 2) {
+            step(y, 0, nxB, std::true_type{});
+            step(y + 1, 1, nxA, std::false_type{});
+        }
+    }
+}
+
+template <typename T>
+int launch_coop(CoopParams<T> p, int num_cus, hipStream_t s) {
+    constexpr size_t lds = 2 * 16 * (256 * 2 + 16) + 4 * 256 * 4;
+    auto kern = block_tail_coop_kernel<T>;
+    static BqLdsAttr attr;
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
+    p.Ho = (p.H + 1) / 2; p.Wo = (p.W + 1) / 2;
+    p.nstrips = (p.Wo + 6) / 7;
+    const long long base_items = (long long)p.n * p.nstrips;
+    p.nbands = pick_bands(base_items, p.Ho, p.Ho, 2, num_cus);       // whole-height strips: 256 images x 6 strips = 6 per workgroup
+    p.items = (int)(base_items * p.nbands);
+    int grid = p.items < num_cus ? p.items : num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    return (int)hipGetLastError();
+}
+
 // bands of ~rows_per_band rows; small batches get shorter bands so that every CU still has work
 inline int pick_bands(long long base_items, int rows, int rows_per_band, int min_rows, int waves) {
     int nb = (rows + rows_per_band - 1) / rows_per_band;
@@ -642,7 +897,9 @@ bool stream_supported(int dtype, int cin, int cout, bool relu_in, long long n, i
 }
 
 bool tail_supported(int dtype, int cin, int cout, int cx, long long n, int H, int W) {
-    return dtype != 0 && cin == 128 && cout == 128 && cx == 64 && H >= 8 && W >= 8 &&
+    const bool b2 = cin == 128 && cout == 128 && cx == 64;          // block 2: wave-private strips
+    const bool b3 = cin == 256 && cout == 256 && cx == 128;         // block 3: eight waves per strip, weights in registers
+    return dtype != 0 && (b2 || b3) && H >= 8 && W >= 8 &&
            n * H * W * (long long)cin * 2 <= 0xfffff000ll;
 }
 
@@ -651,6 +908,19 @@ int launch_block_tail(int dtype, int cin, int cout, int cx, const void* y1, cons
                       const float* scale, const float* bias, const void* x, const void* wr16, const float* rscale,
                       const float* rbias, void* out, int n, int H, int W, int num_cus, hipStream_t s) {
     if (!tail_supported(dtype, cin, cout, cx, n, H, W)) return (int)hipErrorInvalidValue;
+    if (cin == 256) {
+        auto go3 = [&](auto tag) {
+            typedef decltype(tag) T;
+            CoopParams<T> p;
+            p.in = reinterpret_cast<const T*>(y1); p.wp16 = reinterpret_cast<const uint4*>(wp16); p.dw = dw;
+            p.scale = scale; p.bias = bias;
+            p.x = reinterpret_cast<const T*>(x); p.wr16 = reinterpret_cast<const uint4*>(wr16); p.rscale = rscale; p.rbias = rbias;
+            p.out = reinterpret_cast<T*>(out);
+            p.n = n; p.H = H; p.W = W; p.Ho = p.Wo = p.nstrips = p.nbands = p.items = 0;
+            return launch_coop<T>(p, num_cus, s);
+        };
+        return dtype == 2 ? go3(f16_t{}) : go3(bf16_t{});
+    }
     auto go = [&](auto tag) {
         typedef decltype(tag) T;
         TailParams<T> p;

@@ -288,7 +288,7 @@ def wide_layers():
 
 # kernels_stream.hip (round 4): the 147x147 separable convolutions of block 2 take the same 16x16x32 fragment order
 STREAM_LAYERS = ('block2_sepconv1', 'block2_sepconv2')      # (block3_sepconv1 has its wp16 as a wide layer)
-TAIL_RES_LAYERS = ('block2_res',)
+TAIL_RES_LAYERS = ('block2_res', 'block3_res')
 
 
 def fold_bn(w, name):

@@ -18,7 +18,7 @@ for hard in (False, True):
         e = Engine(w, dtype=dt, max_batch=max(n, 8), max_mc=8)
         d = torch.from_numpy(tiles).cuda()
         st = e.stage(d)
-        for name, shp in (('block1_conv2', (147, 147, 64)), ('block2_out', (74, 74, 128))):
+        for name, shp in (('block1_conv2', (147, 147, 64)), ('block2_out', (74, 74, 128)), ('block3_out', (37, 37, 256))):
             ref = taps[name].permute(0, 2, 3, 1).numpy()
             old = e.debug_activation(name, st, shp).cpu().numpy()
             new = e.debug_activation_u8(name, d, shp).cpu().numpy()

@@ -77,6 +77,33 @@ int main(int argc, char** argv) {
             printf("%-28s tail    : %.4f ms  %.0f GB/s  checksum %016llx\n", tag, ms, gb / ms * 1e3, h);
         }
     }
+    {   // cooperative block-3 tail: y1 74 x 74 x 256, x 74 x 74 x 128 -> 37 x 37 x 256
+        const size_t p3 = (size_t)n * 74 * 74;
+        unsigned short *y3, *x3, *o3; uint4 *w3, *wr3; float *sc3, *dw3;
+        CK(hipMalloc(&y3, p3 * 256 * 2 + 8192)); CK(hipMalloc(&x3, p3 * 128 * 2)); CK(hipMalloc(&o3, (size_t)n * 37 * 37 * 256 * 2));
+        CK(hipMalloc(&w3, 131072)); CK(hipMalloc(&wr3, 65536)); CK(hipMalloc(&sc3, 1024)); CK(hipMalloc(&dw3, 9 * 256 * 4));
+        y3 += 2048;
+        fill_rand<<<2048, 256>>>(y3, p3 * 256, 21); fill_rand<<<2048, 256>>>(x3, p3 * 128, 22);
+        fill_rand<<<64, 256>>>((unsigned short*)w3, 65536, 23); fill_rand<<<64, 256>>>((unsigned short*)wr3, 32768, 24);
+        {
+            std::vector<float> h(9 * 256), sv(256);
+            for (int i = 0; i < 9 * 256; ++i) h[i] = ((i * 37 % 101) / 101.0f - 0.5f) * 0.6f;
+            for (int i = 0; i < 256; ++i) sv[i] = 0.1f + (i % 7) * 0.01f;
+            CK(hipMemcpy(dw3, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(sc3, sv.data(), 1024, hipMemcpyHostToDevice));
+        }
+        const double gb = ((double)p3 * 256 + (double)n * 37 * 37 * (128 + 256)) * 2 / 1e9;
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int i = 0; i < 3; ++i) if (launch_block_tail(2, 256, 256, 128, y3, w3, dw3, sc3, sc3, x3, wr3, sc3, sc3, o3, n, 74, 74, 256, 0)) { printf("coop launch failed\n"); return 1; }
+            CK(hipEventRecord(a));
+            for (int i = 0; i < 20; ++i) launch_block_tail(2, 256, 256, 128, y3, w3, dw3, sc3, sc3, x3, wr3, sc3, sc3, o3, n, 74, 74, 256, 0);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
+            CK(hipMemset(cs, 0, 8));
+            checksum<<<1024, 256>>>((const unsigned*)o3, (size_t)n * 37 * 37 * 128, cs);
+            unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
+            printf("%-28s coop    : %.4f ms  %.0f GB/s  checksum %016llx\n", tag, ms, gb / ms * 1e3, h);
+        }
+    }
     {   // fused front: uint8 tiles -> conv2 output (147 x 147 x 64)
         uint8_t* u8; unsigned long long* st; uint4 *ws16, *wc16; unsigned short* o3;
         const size_t tb = (size_t)n * 299 * 299 * 3;
