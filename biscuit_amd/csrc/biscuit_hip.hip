@@ -282,6 +282,17 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
         p.in = a.dwtmp; p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = gap ? (void*)a.gap_out : a.out;
         if (gap) *a.gap_done = true;
+        // round 4: one image's pixels x 256 channels per workgroup on 16x16x32 fragments (kernels_exit.hip) when the layer's
+        // weights are there in that order -- block 14
+        static const bool no_exit = bq_exp_env("BQ_NO_EXIT") != nullptr;
+        if (!no_exit && L.wp16 && !a.residual && a.ldi == L.kpad && a.ldo == L.cout &&
+            exit_supported(dtype, L.kpad, L.cout, a.H * a.W, a.n)) {
+            const int e = launch_exit_gemm(dtype, a.dwtmp, L.wp16, L.scale, L.bias, a.out, gap ? a.gap_out : nullptr, a.n,
+                                           a.H * a.W, L.kpad, L.cout, a.relu, s);
+            if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(exit_gemm) ") + a.layer + ": " +
+                                                       hipGetErrorString((hipError_t)e));
+            return BQ_OK;
+        }
         const int e = launch_gemm_tile(dtype, p, false, s, gap ? 1 : 0);
         if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(gemm_tile) ") + a.layer + ": " +
                                                    hipGetErrorString((hipError_t)e));

@@ -103,6 +103,11 @@ int launch_block_tail(int dtype, int cin, int cout, int cx, const void* y1, cons
                       const float* rbias, void* out, int n, int H, int W, int num_cus, hipStream_t s);
 int launch_dw3x3(int dtype, const void* in, const float* dw, void* out, int n, int H, int W, int C, int relu, hipStream_t s);
 int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s, int epi = 0);   // epi: 1 = + global average pool, 2 = + max-pool + add
+// kernels_exit.hip (round 4): block 14's pointwise GEMMs, one image's pixels x 256 channels per workgroup; gap != nullptr: the
+// per-image means instead of the tensor
+bool exit_supported(int dtype, int K, int N, int HW, long long n);
+int launch_exit_gemm(int dtype, const void* in, const void* wp16, const float* scale, const float* bias, void* out, float* gap,
+                     int n, int HW, int K, int N, int relu, hipStream_t s);
 int launch_tile_conv(int dtype, int kind, const void* in, const void* wp, const float* dw, const float* scale,
                      const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
                      hipStream_t s);

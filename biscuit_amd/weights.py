@@ -289,6 +289,8 @@ def wide_layers():
 # kernels_stream.hip (round 4): the 147x147 separable convolutions of block 2 take the same 16x16x32 fragment order
 STREAM_LAYERS = ('block2_sepconv1', 'block2_sepconv2')      # (block3_sepconv1 has its wp16 as a wide layer)
 TAIL_RES_LAYERS = ('block2_res', 'block3_res')
+# kernels_exit.hip (round 4): block 14's pointwise GEMMs, the same fragment order
+EXIT_LAYERS = ('block14_sepconv1', 'block14_sepconv2')
 
 
 def fold_bn(w, name):
@@ -355,7 +357,7 @@ def pack_blob(w, dtype='bf16'):
         dw[:, :cin] = w[name + '/depthwise_kernel'].reshape(9, cin)
         add(name + '/dw', dw)
         npad = add_mat(name, w[name + '/pointwise_kernel'].reshape(cin, cout), cp)
-        if half and (name in wide or name in STREAM_LAYERS) and cp % 32 == 0:
+        if half and (name in wide or name in STREAM_LAYERS or name in EXIT_LAYERS) and cp % 32 == 0:
             add(name + '/wp16', to_bits(pack_fragments16(w[name + '/pointwise_kernel'].reshape(cin, cout), cp, npad)))
         s, b = fold_bn(w, name + '_bn')
         add_affine(name, s, b, npad)

@@ -155,8 +155,9 @@ def test_blob_directory_roundtrip():
     # stem, conv2, res, sepconvs, hidden, logits + the 16x16x32 fragment copy of the 30 wide layers, of the two streaming
     # layers of block 2 and of the block-2 / block-3 shortcuts inside the fused tails (round 4), and the 32x32x16 copy of the two fused
     # shortcuts (16-bit blobs only)
+    # ... block 14's two pointwise GEMMs in the same order (kernels_exit.hip)
     # ... and the fused front kernel's two copies: block1_conv1 as f16 hi | lo fragments, block1_conv2 one k-step per tap
-    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 30 + 2 + 2 + 2 + 2
+    assert len(names) == 3 + 3 + 3 * 4 + 4 * 34 + 3 * 2 + 2 + 30 + 2 + 2 + 2 + 2 + 2
     assert {'block2_sepconv1/wp16', 'block2_sepconv2/wp16', 'block2_res/wp16', 'block1_conv1/w16', 'block1_conv2/wp16'} <= set(names)
     assert names['block1_conv1/w16'][1] == 2 * 2 * 64 * 8 * 2 and names['block1_conv2/wp16'][1] == 9 * 4 * 64 * 8 * 2
     # the two halves of the stem weights give the fp32 weights back to 22 bits: hi + lo / 2^11
@@ -171,6 +172,7 @@ def test_blob_directory_roundtrip():
     assert names['block3_sepconv2/wp16'][1] == 8 * 16 * 64 * 8 * 2 and names['block3_sepconv1/wp16'][1] == 4 * 16 * 64 * 8 * 2
     assert names['block2_sepconv2/wp16'][1] == 4 * 8 * 64 * 8 * 2 and names['block2_res/wp16'][1] == 2 * 8 * 64 * 8 * 2
     assert names['block3_res/wp16'][1] == 4 * 16 * 64 * 8 * 2
+    assert names['block14_sepconv1/wp16'][1] == 32 * 96 * 64 * 8 * 2 and names['block14_sepconv2/wp16'][1] == 48 * 128 * 64 * 8 * 2
     assert names['block4_sepconv1/wp16'][1] == 8 * 48 * 64 * 8 * 2
     off, ln = names['block5_sepconv2/scale']
     s, b = W.fold_bn(w, 'block5_sepconv2_bn')
