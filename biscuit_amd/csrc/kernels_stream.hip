@@ -520,24 +520,25 @@ inline int pick_bands(long long base_items, int rows, int rows_per_band, int min
 // 74x74x256 tensor between the convolution and the pool is never written.
 template <typename T>
 struct CoopParams {
-    const T* in;           // sepconv2's input [n][H][W][256]
-    const uint4* wp16;     // [8][16][64] x 16 B
-    const float* dw;       // [9][256]
-    const float* scale;    // [256]
+    const T* in;           // sepconv2's input [n][H][W][C]           (C = 256: block 3; 128: block 2)
+    const uint4* wp16;     // [C / 32][C / 16][64] x 16 B
+    const float* dw;       // [9][C]
+    const float* scale;    // [C]
     const float* bias;
-    const T* x;            // the block's input [n][H][W][128]
-    const uint4* wr16;     // [4][16][64] x 16 B
+    const T* x;            // the block's input [n][H][W][C / 2]
+    const uint4* wr16;     // [C / 64][C / 16][64] x 16 B
     const float* rscale;
     const float* rbias;
-    T* out;                // [n][Ho][Wo][256]
+    T* out;                // [n][Ho][Wo][C]
     int n, H, W, Ho, Wo;
     int nstrips, nbands, items;
 };
 
-template <typename T>
-__global__ void __launch_bounds__(512) block_tail_coop_kernel(const CoopParams<T> p) {
+template <typename T, int C, int WGS>
+__global__ void __launch_bounds__(C * 2, WGS) block_tail_coop_kernel(const CoopParams<T> p) {
     if constexpr (H16<T>::F16) bq_f16_saturate();
-    constexpr int CIN = 256, COUT = 256, CX = 128, KS = CIN / 32, KR = CX / 32, NCOL = 4, NWIN = NCOL + 2;
+    constexpr int CIN = C, COUT = C, CX = C / 2, KS = CIN / 32, KR = CX / 32, NCOL = 4, NWIN = NCOL + 2;
+    constexpr int NT = C * 2, NFR = COUT / 16;          // C / 32 waves of 32 output (and depthwise input) channels; 16-wide fragments
     constexpr int AST = CIN * 2 + 16;
     constexpr int A_BYTES = 16 * AST;
     constexpr int SB_OFF = 2 * A_BYTES;         // scale | bias | rscale | rbias, fp32 [4][COUT]
@@ -546,7 +547,7 @@ __global__ void __launch_bounds__(512) block_tail_coop_kernel(const CoopParams<T
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < COUT; i += 512) {
+    for (int i = tid; i < COUT; i += NT) {
         float* sbw = reinterpret_cast<float*>(smem + SB_OFF);
         sbw[i] = p.scale[i]; sbw[COUT + i] = p.bias[i]; sbw[2 * COUT + i] = p.rscale[i]; sbw[3 * COUT + i] = p.rbias[i];
     }
@@ -555,11 +556,11 @@ __global__ void __launch_bounds__(512) block_tail_coop_kernel(const CoopParams<T
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wq[ks][i] = p.wp16[((size_t)ks * 16 + 2 * wave + i) * 64 + lane];
+        for (int i = 0; i < 2; ++i) wq[ks][i] = p.wp16[((size_t)ks * NFR + 2 * wave + i) * 64 + lane];
 #pragma unroll
     for (int ks = 0; ks < KR; ++ks)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) wrq[ks][i] = p.wr16[((size_t)ks * 16 + 2 * wave + i) * 64 + lane];
+        for (int i = 0; i < 2; ++i) wrq[ks][i] = p.wr16[((size_t)ks * NFR + 2 * wave + i) * 64 + lane];
     const int pair = lane & 15, cg = lane >> 4;                      // depthwise role: channels 32 w + 2 pair (+1), columns 4 cg .. 4 cg + 3
     f32x2s tap[9];
 #pragma unroll
@@ -740,19 +741,19 @@ __global__ void __launch_bounds__(512) block_tail_coop_kernel(const CoopParams<T
     }
 }
 
-template <typename T>
+template <typename T, int C, int WGS>
 int launch_coop(CoopParams<T> p, int num_cus, hipStream_t s) {
-    constexpr size_t lds = 2 * 16 * (256 * 2 + 16) + 4 * 256 * 4;
-    auto kern = block_tail_coop_kernel<T>;
+    constexpr size_t lds = 2 * 16 * (C * 2 + 16) + 4 * C * 4;
+    auto kern = block_tail_coop_kernel<T, C, WGS>;
     static BqLdsAttr attr;
     if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
     p.Ho = (p.H + 1) / 2; p.Wo = (p.W + 1) / 2;
     p.nstrips = (p.Wo + 6) / 7;
     const long long base_items = (long long)p.n * p.nstrips;
-    p.nbands = pick_bands(base_items, p.Ho, p.Ho, 2, num_cus);       // whole-height strips: 256 images x 6 strips = 6 per workgroup
+    p.nbands = pick_bands(base_items, p.Ho, p.Ho, 2, num_cus * WGS);  // whole-height strips: 256 images x 6 strips = 6 per workgroup
     p.items = (int)(base_items * p.nbands);
-    int grid = p.items < num_cus ? p.items : num_cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+    int grid = p.items < num_cus * WGS ? p.items : num_cus * WGS;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C * 2), lds, s, p);
     return (int)hipGetLastError();
 }
 
@@ -853,10 +854,25 @@ int launch_block_tail(int dtype, int cin, int cout, int cx, const void* y1, cons
             p.x = reinterpret_cast<const T*>(x); p.wr16 = reinterpret_cast<const uint4*>(wr16); p.rscale = rscale; p.rbias = rbias;
             p.out = reinterpret_cast<T*>(out);
             p.n = n; p.H = H; p.W = W; p.Ho = p.Wo = p.nstrips = p.nbands = p.items = 0;
-            return launch_coop<T>(p, num_cus, s);
+            return launch_coop<T, 256, 1>(p, num_cus, s);
         };
         return dtype == 2 ? go3(f16_t{}) : go3(bf16_t{});
     }
+#ifdef TAIL2_COOP
+    {
+        auto go2 = [&](auto tag) {
+            typedef decltype(tag) T;
+            CoopParams<T> p;
+            p.in = reinterpret_cast<const T*>(y1); p.wp16 = reinterpret_cast<const uint4*>(wp16); p.dw = dw;
+            p.scale = scale; p.bias = bias;
+            p.x = reinterpret_cast<const T*>(x); p.wr16 = reinterpret_cast<const uint4*>(wr16); p.rscale = rscale; p.rbias = rbias;
+            p.out = reinterpret_cast<T*>(out);
+            p.n = n; p.H = H; p.W = W; p.Ho = p.Wo = p.nstrips = p.nbands = p.items = 0;
+            return launch_coop<T, 128, TAIL2_COOP>(p, num_cus, s);
+        };
+        return dtype == 2 ? go2(f16_t{}) : go2(bf16_t{});
+    }
+#endif
     auto go = [&](auto tag) {
         typedef decltype(tag) T;
         TailParams<T> p;

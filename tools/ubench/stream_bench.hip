@@ -27,6 +27,25 @@ __global__ void checksum(const unsigned* p, size_t n, unsigned long long* out) {
     atomicAdd(out, s);
 }
 
+// chip clock while a kernel runs: one wave on a non-blocking stream reads s_memtime (core cycles) and s_memrealtime (100 MHz)
+// around ~2 ms of s_sleep; printed as GHz.  (The clock the power management holds depends on the instruction mix.)
+__global__ void clock_probe(unsigned long long* out, int spins) {
+    unsigned long long c0, r0, c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0));
+    for (int i = 0; i < spins; ++i) asm volatile("s_sleep 127");
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1));
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+static hipStream_t g_ps;
+static unsigned long long* g_pc;
+static void probe_start() { hipLaunchKernelGGL(clock_probe, dim3(1), dim3(64), 0, g_ps, g_pc, 400); }
+static double probe_ghz() {
+    unsigned long long h[2];
+    hipStreamSynchronize(g_ps);
+    hipMemcpy(h, g_pc, 16, hipMemcpyDeviceToHost);
+    return h[1] ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 256, H = 147, W = 147;
     const char* tag = argc > 2 ? argv[2] : "";
@@ -45,18 +64,20 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(sc, s.data(), 512, hipMemcpyHostToDevice)); CK(hipMemcpy(bi, b.data(), 512, hipMemcpyHostToDevice));
     }
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipStreamCreateWithFlags(&g_ps, hipStreamNonBlocking)); CK(hipMalloc(&g_pc, 16));
+    { probe_start(); printf("%-28s clock, idle chip: %.2f GHz\n", tag, probe_ghz()); }
     for (int cin : {128, 64}) {
         const double gb = (double)px * (cin + 128) * 2 / 1e9;
         for (int rep = 0; rep < 2; ++rep) {
             for (int i = 0; i < 3; ++i) if (launch_sepconv_stream(2, cin, 128, false, in, wp, dw, sc, bi, out, n, H, W, 1, 256, 0)) { printf("launch failed\n"); return 1; }
             CK(hipEventRecord(a));
-            for (int i = 0; i < 20; ++i) launch_sepconv_stream(2, cin, 128, false, in, wp, dw, sc, bi, out, n, H, W, 1, 256, 0);
-            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            for (int i = 0; i < 20; ++i) { launch_sepconv_stream(2, cin, 128, false, in, wp, dw, sc, bi, out, n, H, W, 1, 256, 0); if (i == 4) probe_start(); }
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); const double ghz = probe_ghz();
             float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
             CK(hipMemset(cs, 0, 8));
             checksum<<<1024, 256>>>((const unsigned*)out, px * 64, cs);
             unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
-            printf("%-28s cin %3d: %.4f ms  %.0f GB/s  checksum %016llx\n", tag, cin, ms, gb / ms * 1e3, h);
+            printf("%-28s cin %3d: %.4f ms  %.0f GB/s  checksum %016llx  clock %.2f GHz\n", tag, cin, ms, gb / ms * 1e3, h, ghz);
         }
     }
     {   // fused block tail: y1 = in (128 ch), x = second tensor (64 ch), out 74 x 74 x 128
@@ -68,13 +89,13 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; ++rep) {
             for (int i = 0; i < 3; ++i) if (launch_block_tail(2, 128, 128, 64, in, wp, dw, sc, bi, x, wr, sc, bi, out2, n, H, W, 256, 0)) { printf("tail launch failed\n"); return 1; }
             CK(hipEventRecord(a));
-            for (int i = 0; i < 20; ++i) launch_block_tail(2, 128, 128, 64, in, wp, dw, sc, bi, x, wr, sc, bi, out2, n, H, W, 256, 0);
-            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            for (int i = 0; i < 20; ++i) { launch_block_tail(2, 128, 128, 64, in, wp, dw, sc, bi, x, wr, sc, bi, out2, n, H, W, 256, 0); if (i == 4) probe_start(); }
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); const double ghz = probe_ghz();
             float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
             CK(hipMemset(cs, 0, 8));
             checksum<<<1024, 256>>>((const unsigned*)out2, (size_t)n * 74 * 74 * 64, cs);
             unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
-            printf("%-28s tail    : %.4f ms  %.0f GB/s  checksum %016llx\n", tag, ms, gb / ms * 1e3, h);
+            printf("%-28s tail    : %.4f ms  %.0f GB/s  checksum %016llx  clock %.2f GHz\n", tag, ms, gb / ms * 1e3, h, ghz);
         }
     }
     {   // cooperative block-3 tail: y1 74 x 74 x 256, x 74 x 74 x 128 -> 37 x 37 x 256
@@ -95,13 +116,13 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; ++rep) {
             for (int i = 0; i < 3; ++i) if (launch_block_tail(2, 256, 256, 128, y3, w3, dw3, sc3, sc3, x3, wr3, sc3, sc3, o3, n, 74, 74, 256, 0)) { printf("coop launch failed\n"); return 1; }
             CK(hipEventRecord(a));
-            for (int i = 0; i < 20; ++i) launch_block_tail(2, 256, 256, 128, y3, w3, dw3, sc3, sc3, x3, wr3, sc3, sc3, o3, n, 74, 74, 256, 0);
-            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            for (int i = 0; i < 20; ++i) { launch_block_tail(2, 256, 256, 128, y3, w3, dw3, sc3, sc3, x3, wr3, sc3, sc3, o3, n, 74, 74, 256, 0); if (i == 4) probe_start(); }
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); const double ghz = probe_ghz();
             float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
             CK(hipMemset(cs, 0, 8));
             checksum<<<1024, 256>>>((const unsigned*)o3, (size_t)n * 37 * 37 * 128, cs);
             unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
-            printf("%-28s coop    : %.4f ms  %.0f GB/s  checksum %016llx\n", tag, ms, gb / ms * 1e3, h);
+            printf("%-28s coop    : %.4f ms  %.0f GB/s  checksum %016llx  clock %.2f GHz\n", tag, ms, gb / ms * 1e3, h, ghz);
         }
     }
     {   // fused front: uint8 tiles -> conv2 output (147 x 147 x 64)
@@ -121,21 +142,21 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 2; ++rep) {
             for (int i = 0; i < 3; ++i) if (launch_front(2, u8, st, ws16, sc, bi, wc16, sc, bi, o3, n, 256, 0)) { printf("front launch failed\n"); return 1; }
             CK(hipEventRecord(a));
-            for (int i = 0; i < 20; ++i) launch_front(2, u8, st, ws16, sc, bi, wc16, sc, bi, o3, n, 256, 0);
-            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            for (int i = 0; i < 20; ++i) { launch_front(2, u8, st, ws16, sc, bi, wc16, sc, bi, o3, n, 256, 0); if (i == 4) probe_start(); }
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); const double ghz = probe_ghz();
             float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
             CK(hipMemset(cs, 0, 8));
             checksum<<<1024, 256>>>((const unsigned*)o3, px * 32, cs);
             unsigned long long h; CK(hipMemcpy(&h, cs, 8, hipMemcpyDeviceToHost));
-            printf("%-28s front   : %.4f ms  %.0f GB/s  checksum %016llx\n", tag, ms, gb / ms * 1e3, h);
+            printf("%-28s front   : %.4f ms  %.0f GB/s  checksum %016llx  clock %.2f GHz\n", tag, ms, gb / ms * 1e3, h, ghz);
         }
     }
     {   // calibration: copy of 1.42 GB (read + write 2.83 GB)
         const size_t n16 = px * 128 * 2 / 16;
         for (int i = 0; i < 3; ++i) copy16<<<256 * 8, 256>>>((const uint4*)in, (uint4*)out, n16);
         CK(hipEventRecord(a));
-        for (int i = 0; i < 20; ++i) copy16<<<256 * 8, 256>>>((const uint4*)in, (uint4*)out, n16);
-        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        for (int i = 0; i < 20; ++i) { copy16<<<256 * 8, 256>>>((const uint4*)in, (uint4*)out, n16); if (i == 4) probe_start(); }
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); const double ghz = probe_ghz();
         float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 20;
         printf("%-28s copy16 of the same bytes: %.4f ms  %.0f GB/s\n", tag, ms, (double)n16 * 32 / 1e9 / ms * 1e3);
     }
