@@ -300,6 +300,28 @@ def test_jpeg_tfrecords_feed_the_same_tiles(tmp_path):
     eng.close()
 
 
+def test_host_tiles_through_the_pinned_ring_equal_resident_tiles(monkeypatch):
+    """The chunk-source contract of `evaluate` (chunk_shape / read / rows / close) on the simplest source there is -- decoded tiles
+    in pageable host memory, bench.py's PCIe-inclusive leg -- with chunks smaller than a slide, so that slides span ring slots
+    and batches span chunks: the tile table and the slide table equal those of the same tiles handed over whole."""
+    import biscuit_amd.inference as inf
+    from bench import _HostTiles
+    from biscuit_amd.engine import Engine
+    monkeypatch.setattr(inf, 'CHUNK_TILES', 7)
+    n_slides, per = 3, 19
+    tiles, sidx, y = make_slides(n_slides, per, seed=9)
+    whole = [inf.Slide(f'h{i}', tiles[sidx == i], per, y_true=int(y[i])) for i in range(n_slides)]
+    ring = [inf.Slide(f'h{i}', tiles[sidx == i], per, y_true=int(y[i]), source=_HostTiles(np.ascontiguousarray(tiles[sidx == i])))
+            for i in range(n_slides)]
+    eng = Engine(synthetic_weights(1), dtype='f16', max_batch=16, max_mc=5)
+    a = inf.evaluate(eng, whole, outcome='cohort', mc_n=5, seed=7, batch=16)
+    b = inf.evaluate(eng, ring, outcome='cohort', mc_n=5, seed=7, batch=16)
+    for col in ('cohort-y_pred1', 'cohort-uncertainty1'):
+        assert np.array_equal(a.tile_df[col].to_numpy(), b.tile_df[col].to_numpy()), col
+    assert np.array_equal(a.slide_pred, b.slide_pred) and np.array_equal(a.slide_count, b.slide_count)
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------ stress weights
 @pytest.fixture(scope='module')
 def hard():
