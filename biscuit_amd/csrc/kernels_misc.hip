@@ -291,10 +291,13 @@ __global__ void __launch_bounds__(256) gap_kernel(const T* __restrict__ x, int n
 }
 
 // ---------------------------------------------------------------- K6 tail
-// One wave per tile: for each MC pass, dropout(hidden_1 row) . W2 -> 2 logits ->
-// softmax -> Welford update (count, mean[2], M2[2]) carried in registers; W2 lives in
-// registers (16 k per lane x 2 classes).  state layout [n][5] fp32.
-__global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict__ h1, int n, int mc_n,
+// One workgroup of eight waves per tile.  Wave w takes MC passes w, w + 8, ...: dropout(hidden_1 row) . W2 -> 2 logits ->
+// softmax; the two probabilities of a block of eight passes meet in LDS and ONE lane folds them into the Welford state (count,
+// mean[2], M2[2]) in pass order -- the arithmetic, and its order, of the one-wave-per-tile form this replaces (round 4: that
+// form ran 256 waves on the whole chip, each through 30 passes of ~500 vector instructions: 0.036 ms; the passes are
+// independent, only the fold is sequential).  W2 lives in registers (16 k per lane x 2 classes).  state layout [n][5] fp32.
+constexpr int kHeadFinalWaves = 8;
+__global__ void __launch_bounds__(64 * kHeadFinalWaves) head_final_kernel(const float* __restrict__ h1, int n, int mc_n,
                                                          int pass0, long long tile0_imm,
                                                          const long long* __restrict__ tile0_dev, unsigned seed_lo,
                                                          unsigned seed_hi, unsigned thresh, float dscale,
@@ -303,9 +306,9 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict
                                                          int finalize, float* __restrict__ state,
                                                          float* __restrict__ mean2,
                                                          float* __restrict__ std2) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile >= n) return;
+    __shared__ float probs[kHeadFinalWaves][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x;
     const long long tile0 = tile0_imm + (tile0_dev ? *tile0_dev : 0);
     float wa[16], wb[16];
 #pragma unroll
@@ -316,53 +319,64 @@ __global__ void __launch_bounds__(256) head_final_kernel(const float* __restrict
             wa[j * 4 + e] = w2[k * 2];
             wb[j * 4 + e] = w2[k * 2 + 1];
         }
-    float cnt = 0.f, mu0 = 0.f, mu1 = 0.f, q0 = 0.f, q1 = 0.f;
-    if (!init) {
+    float cnt = 0.f, mu0 = 0.f, mu1 = 0.f, q0 = 0.f, q1 = 0.f;       // (kept by thread 0 only)
+    if (!init && threadIdx.x == 0) {
         const float* st = state + (size_t)tile * 5;
         cnt = st[0]; mu0 = st[1]; mu1 = st[2]; q0 = st[3]; q1 = st[4];
     }
-    for (int p = 0; p < mc_n; ++p) {
-        const float* row = h1 + ((size_t)tile * mc_n + p) * 1024;
-        float z0 = 0.f, z1 = 0.f;
+    for (int base = 0; base < mc_n; base += kHeadFinalWaves) {
+        const int p = base + wave;
+        if (p < mc_n) {
+            const float* row = h1 + ((size_t)tile * mc_n + p) * 1024;
+            float z0 = 0.f, z1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int g = lane + 64 * j;  // Philox group = unit / 4
-            const float4 v = *reinterpret_cast<const float4*>(row + 4 * g);
-            unsigned r[4];
-            philox4x32_10((unsigned)g, 2u, (unsigned)(pass0 + p), (unsigned)(tile0 + tile), seed_lo,
-                          seed_hi, r);
-            const float f0 = r[0] >= thresh ? v.x * dscale : 0.f;
-            const float f1 = r[1] >= thresh ? v.y * dscale : 0.f;
-            const float f2 = r[2] >= thresh ? v.z * dscale : 0.f;
-            const float f3 = r[3] >= thresh ? v.w * dscale : 0.f;
-            z0 = fmaf(f0, wa[j * 4], z0); z0 = fmaf(f1, wa[j * 4 + 1], z0);
-            z0 = fmaf(f2, wa[j * 4 + 2], z0); z0 = fmaf(f3, wa[j * 4 + 3], z0);
-            z1 = fmaf(f0, wb[j * 4], z1); z1 = fmaf(f1, wb[j * 4 + 1], z1);
-            z1 = fmaf(f2, wb[j * 4 + 2], z1); z1 = fmaf(f3, wb[j * 4 + 3], z1);
-        }
+            for (int j = 0; j < 4; ++j) {
+                const int g = lane + 64 * j;  // Philox group = unit / 4
+                const float4 v = *reinterpret_cast<const float4*>(row + 4 * g);
+                unsigned r[4];
+                philox4x32_10((unsigned)g, 2u, (unsigned)(pass0 + p), (unsigned)(tile0 + tile), seed_lo,
+                              seed_hi, r);
+                const float f0 = r[0] >= thresh ? v.x * dscale : 0.f;
+                const float f1 = r[1] >= thresh ? v.y * dscale : 0.f;
+                const float f2 = r[2] >= thresh ? v.z * dscale : 0.f;
+                const float f3 = r[3] >= thresh ? v.w * dscale : 0.f;
+                z0 = fmaf(f0, wa[j * 4], z0); z0 = fmaf(f1, wa[j * 4 + 1], z0);
+                z0 = fmaf(f2, wa[j * 4 + 2], z0); z0 = fmaf(f3, wa[j * 4 + 3], z0);
+                z1 = fmaf(f0, wb[j * 4], z1); z1 = fmaf(f1, wb[j * 4 + 1], z1);
+                z1 = fmaf(f2, wb[j * 4 + 2], z1); z1 = fmaf(f3, wb[j * 4 + 3], z1);
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            z0 += __shfl_xor(z0, o);
-            z1 += __shfl_xor(z1, o);
+            for (int o = 32; o > 0; o >>= 1) {
+                z0 += __shfl_xor(z0, o);
+                z1 += __shfl_xor(z1, o);
+            }
+            z0 += b2[0];
+            z1 += b2[1];
+            const float zm = fmaxf(z0, z1);
+            const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+            const float inv = 1.f / (e0 + e1);
+            if (lane == 0) { probs[wave][0] = e0 * inv; probs[wave][1] = e1 * inv; }
         }
-        z0 += b2[0];
-        z1 += b2[1];
-        const float zm = fmaxf(z0, z1);
-        const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
-        const float inv = 1.f / (e0 + e1);
-        float p0 = e0 * inv, p1 = e1 * inv;
-        // Pin the rounded probabilities: if the compiler contracts e*inv into the Welford
-        // differences below (fma(e, inv, -mean)), p - mean keeps the product's rounding error
-        // instead of an exact 0 and a single pass reports std ~1e-4 instead of 0.
-        asm volatile("" : "+v"(p0), "+v"(p1));
-        cnt += 1.f;
-        const float d0 = p0 - mu0, d1 = p1 - mu1;
-        mu0 += d0 / cnt;
-        mu1 += d1 / cnt;
-        q0 = fmaf(d0, p0 - mu0, q0);
-        q1 = fmaf(d1, p1 - mu1, q1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int np = mc_n - base < kHeadFinalWaves ? mc_n - base : kHeadFinalWaves;
+            for (int k = 0; k < np; ++k) {
+                float p0 = probs[k][0], p1 = probs[k][1];
+                // Pin the rounded probabilities: if the compiler contracts a product into the Welford differences below
+                // (fma(e, inv, -mean)), p - mean keeps the product's rounding error instead of an exact 0 and a single pass
+                // reports std ~1e-4 instead of 0.
+                asm volatile("" : "+v"(p0), "+v"(p1));
+                cnt += 1.f;
+                const float d0 = p0 - mu0, d1 = p1 - mu1;
+                mu0 += d0 / cnt;
+                mu1 += d1 / cnt;
+                q0 = fmaf(d0, p0 - mu0, q0);
+                q1 = fmaf(d1, p1 - mu1, q1);
+            }
+        }
+        __syncthreads();
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         float* st = state + (size_t)tile * 5;
         st[0] = cnt; st[1] = mu0; st[2] = mu1; st[3] = q0; st[4] = q1;
         if (finalize) {
@@ -523,7 +537,7 @@ int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long til
                       unsigned seed_hi, unsigned thresh, float dscale, const float* w2, const float* b2,
                       int init, int finalize, float* state, float* mean2, float* std2, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(head_final_kernel, dim3((n + 3) / 4), dim3(256), 0, s, h1, n, mc_n, pass0, tile0, tile0_dev,
+    hipLaunchKernelGGL(head_final_kernel, dim3(n), dim3(64 * kHeadFinalWaves), 0, s, h1, n, mc_n, pass0, tile0, tile0_dev,
                        seed_lo, seed_hi, thresh, dscale, w2, b2, init, finalize, state, mean2, std2);
     return (int)hipGetLastError();
 }
