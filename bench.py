@@ -4,7 +4,7 @@ Default workload (BASELINE.json config 2): synthetic slides of 1000 tiles (299x2
 resident in HBM before the timed region), Xception with 16-bit storage and matrix cores + fp32 MC head, MC = 30,
 batch = 256.  The headline dtype is f16 (IEEE half): the 16-bit mode that holds the north-star tolerance of 1e-3 on
 tile and slide mean / sigma (tests/test_gpu_configs.py::test_hard_weights_throughput_mode_holds_tolerance); bf16, which
-BASELINE config 2 names, runs at the same rate but misses that tolerance on O(1)-logit weights (2.7e-3) and is
+BASELINE config 2 names, runs 5-6 % slower (round 4) and misses that tolerance on O(1)-logit weights (2.7e-3); it is
 reported next to it as ``bf16_value``.  A "step" is one batch of 256 tiles through
     stage (K0) -> backbone (K1-K5) -> 30 Philox-dropout head passes + Welford (K6)
     -> slide-level segmented reduce (K7).
@@ -317,7 +317,7 @@ def run(args):
                                f'Xception {args.dtype} storage + MFMA, fp32 accumulation / BN / MC head, MC={args.mc}, '
                                f'batch={B}, {K * B} tiles/GPU resident in HBM'
                                + ('; f16 is the 16-bit mode that holds the 1e-3 tile/slide tolerance on O(1)-logit weights '
-                                  '(bf16, the type config 2 names, runs at the same rate and misses it: bf16_value)'
+                                  '(bf16, the type config 2 names, runs 5-6 % slower and misses it: bf16_value)'
                                   if args.dtype == 'f16' else ''),
                    'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B, 'hip_streams': streams_used,
                    'parallelism': f'slide-sharded dp{world}, one all-gather of slide (pred, sigma, n)'},
