@@ -81,31 +81,74 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-budget', type=float, default=25.0, help='seconds of CPU work in the baseline sample')
     ap.add_argument('--dist-backend', default=None, help='process-group backend (default: nccl = RCCL); tests: gloo')
     ap.add_argument('--local-device', type=int, default=None, help='GPU index of this rank (default: LOCAL_RANK)')
+    ap.add_argument('--schedule', default='free', choices=['free', 'antiphase', 'pipeline'],
+                    help='free: batches alternate over free-running streams (EnginePool); antiphase / pipeline: every batch cut into '
+                         'its entry part and the rest, the two parts of two batches scheduled against each other (PhasedPool)')
+    ap.add_argument('--cus-entry', type=int, default=None, help='pipeline: compute units of the stream that runs the entry parts')
+    ap.add_argument('--size-grids', action='store_true',
+                    help='free schedule: persistent grids sized for the CUs of each stream (default: for the whole chip)')
+    ap.add_argument('--selftest-exit', default=None, metavar='R:CODE',
+                    help='(tests, no GPU) rank R exits with CODE before the rendezvous ("none": nobody does), the other ranks run a '
+                         'gloo rendezvous and a barrier: exercises the launcher of --gpus N')
+    ap.add_argument('--fixed-streams', action='store_true', help='free schedule: exactly --streams batches in flight, no calibration')
     ap.add_argument('--streams', type=int, default=4,
                     help='batches in flight: independent contexts on HIP streams that own disjoint groups of XCDs (2 or 4)')
     return ap.parse_args(argv)
 
 
 # ----------------------------------------------------------------------------- rank launcher
-def spawn_ranks(args):
+def spawn_ranks(args, argv=None, poll_s=0.2, grace_s=5.0):
     """Start one child process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in its environment), relay rank 0's
     JSON line, return the worst exit code.  The parent never touches the GPU: nothing that has initialised HIP
-    is ever exec'd or forked."""
+    is ever exec'd or forked.  All children are polled: when one exits non-zero the others are terminated (a rank that dies
+    before the rendezvous would otherwise leave them waiting for it -- and this parent waiting for them -- until the
+    process-group timeout), and the parent returns that code within seconds."""
+    import tempfile
+    import threading
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        # ROCm's HIP IPC (RCCL's intra-node transport, CUDA-tensor sharing across processes) must use dmabuf handles on hosts whose
+        # driver supports nothing else: with the legacy mode hipIpcGetMemHandle fails with "invalid argument".  The launcher
+        # environment of this pool exports it already; children started from a clean environment get it here.
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv)),
+                                      env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+    worst, failed_at = 0, None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad and failed_at is None:
+                failed_at = time.time()
+                worst = max(abs(c) for c in bad)
+                for p, c in zip(procs, codes):
+                    if c is None:
+                        p.terminate()
+            if all(c is not None for c in codes):
+                break
+            if failed_at is not None and time.time() - failed_at > grace_s:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+            time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if failed_at is None:
+        worst = max(abs(p.returncode) for p in procs)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    if failed_at is not None:
+        print(f'[bench] a rank exited with code {worst}; the other ranks were stopped', file=sys.stderr)
+    return worst
 
 
 def usable_cores():
@@ -187,6 +230,8 @@ def run(args):
                          f'(or without torchrun: bench.py starts its own ranks)')
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    # this rank's share of the node's cores, next to its GPU where sysfs tells -- before any thread pool exists
+    rank_cpus = D.pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), device_index=local)
     # collectives run on the GPU (RCCL) unless a CPU backend was forced for single-GPU testing
     coll_dev = dev if (world == 1 or dist.get_backend() == 'nccl') else torch.device('cpu')
 
@@ -203,7 +248,12 @@ def run(args):
 
     weights = synthetic_weights(1)
     pool_e = EnginePool(weights, n_streams=args.streams, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc,
-                        device=local)
+                        device=local, size_grids=args.size_grids)
+    phased = None
+    if args.schedule != 'free':
+        from biscuit_amd.engine import PhasedPool
+        phased = PhasedPool(weights, schedule=args.schedule, cus_entry=args.cus_entry, dtype=args.dtype, max_batch=args.batch,
+                            max_mc=args.mc, device=local)
     eng = pool_e.engines[0]
     NS = len(pool_e)
     B, K, Wm = args.batch, args.steps, args.warmup
@@ -242,17 +292,23 @@ def run(args):
     n_slides_local = (NSTEP * B + TILES_PER_SLIDE - 1) // TILES_PER_SLIDE + 1
     slide_of = [torch.div(torch.arange(s * B, (s + 1) * B, device=dev), TILES_PER_SLIDE,
                           rounding_mode='floor').to(torch.int32) for s in range(NSTEP)]
-    mean = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NS)]
-    std = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NS)]
+    NB = max(NS, 2)                               # result buffers / accumulators: one per context of either pool
+    mean = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
+    std = [torch.empty((B, 2), dtype=torch.float32, device=dev) for _ in range(NB)]
     tile_base = rank * K * B                      # global tile index of this rank's shard
 
-    def zero_acc(n=NS):
+    def zero_acc(n=NB):
         # one fixed-point accumulator triple per stream; integer sums add exactly at the end
         return [(torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
                  torch.zeros(n_slides_local, dtype=torch.int64, device=dev),
                  torch.zeros(n_slides_local, dtype=torch.int32, device=dev)) for _ in range(n)]
 
     def step(pe, i, acc, mode, stain=False):
+        if pe is phased and phased is not None:
+            k = i % len(pe.engines)
+            pe.step(i, pool[i % 4], args.mc, seed, tile_base + i * B, (mean[k], std[k]),
+                    after=lambda e: e.slide_reduce(mean[k], std[k], slide_of[i], n_slides_local, acc=acc[k]))
+            return
         k = i % len(pe)               # batches in flight (set by the calibration below)
 
         def work(e):
@@ -294,7 +350,7 @@ def run(args):
     # (10 steps on 4 quarter-chips are 3 rounds), and plain streams (if CU masks are unavailable) are bimodal.
     # So time min(K, 32) steps each way and keep the fastest; every rank adopts the same choice.
     cands = sorted({n for n in (NS, NS // 2, 1) if n >= 1}, reverse=True)
-    if len(cands) > 1:
+    if len(cands) > 1 and not args.fixed_streams:
         cal = min(K, 32)
         times = []
         for n in cands:
@@ -305,7 +361,11 @@ def run(args):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         pool_e.set_in_flight(cands[int(torch.argmin(tt).item())])
     streams_used = len(pool_e)
-    dt = timed(args.mode, K)
+    if phased is not None and args.mode == 'head':
+        timed(args.mode, min(K, 16), pe=phased)          # warm-up of the second set of contexts
+        dt = timed(args.mode, K, pe=phased)
+    else:
+        dt = timed(args.mode, K)
     value = world * K * B / dt
 
     out = {
@@ -319,9 +379,12 @@ def run(args):
                                + ('; f16 is the 16-bit mode that holds the 1e-3 tile/slide tolerance on O(1)-logit weights '
                                   '(bf16, the type config 2 names, runs 5-6 % slower and misses it: bf16_value)'
                                   if args.dtype == 'f16' else ''),
-                   'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B, 'hip_streams': streams_used,
+                   'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B, 'hip_streams': streams_used if phased is None else 2,
+                   'schedule': args.schedule if phased is not None else 'free',
+                   'cus': list(phased.cus) if phased is not None else None,
+                   'grids_sized_for_mask': bool(args.size_grids) if phased is None else True,
                    'parallelism': f'slide-sharded dp{world}, one all-gather of slide (pred, sigma, n)'},
-        'rccl_ranks': coll['rccl_ranks'], 'collective': coll,
+        'rccl_ranks': coll['rccl_ranks'], 'collective': coll, 'host_cores_of_rank0': len(rank_cpus),
     }
 
     flop_head = FLOP_BACKBONE + args.mc * FLOP_HEAD_PASS
@@ -567,6 +630,7 @@ class _HostTiles:
 
     def __init__(self, tiles):
         self.tiles = tiles
+        self.tile_px = int(tiles.shape[1])      # (the pinned ring is sized per tile size, for either chunk layout)
 
     def chunk_shape(self, count):
         return (count,) + tuple(self.tiles.shape[1:])
@@ -674,10 +738,29 @@ def tfrecord_leg(pool_e, args, n_slides=8, tiles_per_slide=256):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def selftest_rank(args):
+    """A rank of the launcher's self-test (tests/test_distributed.py; no GPU is touched): rank R of ``--selftest-exit R:CODE`` leaves
+    with CODE before the rendezvous, every other rank goes through the rendezvous and one barrier of a gloo group."""
+    r, code = (-1, 0) if args.selftest_exit == 'none' else (int(x) for x in args.selftest_exit.split(':'))
+    if int(os.environ.get('RANK', '0')) == r:
+        sys.exit(code)
+    import torch.distributed as dist
+    from biscuit_amd import distributed as D
+    rank, world, _ = D.init_from_env('cpu', backend='gloo')
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'selftest': 'ok', 'world': world}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
+    if args.selftest_exit:
+        return selftest_rank(args)
     run(args)
 
 

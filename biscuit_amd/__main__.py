@@ -46,6 +46,30 @@ def model_hp(params):
     return hp, fit
 
 
+def _first_tiles(slide, n):
+    """The first ``n`` decoded tiles of a slide as a uint8 array, reading no more than those: through the slide's chunk source
+    when it has one (TFRecords: ``n`` records, not the slide -- a 10^4-tile slide is 2.7 GB decoded), with the PNG filters
+    reversed on the host whatever mode the run itself uses."""
+    if slide is None:
+        return None
+    cnt = min(int(n), slide.n_tiles)
+    src = getattr(slide, 'source', None)
+    if src is not None and hasattr(src, 'path'):
+        from .inference import TFRecordSource
+        one = TFRecordSource(src.path, slide.n_tiles, src.tile_px, rows=False)
+        buf = np.empty(one.chunk_shape(cnt), np.uint8)
+        try:
+            one.read(0, cnt, buf)
+        finally:
+            one.close()
+        return buf
+    t = slide.load()
+    if hasattr(t, 'rows'):          # filtered PNG scanlines without a chunk source: not tiles yet
+        return None
+    t = t[:cnt]
+    return np.ascontiguousarray(t.cpu().numpy() if hasattr(t, 'cpu') else t)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog='python -m biscuit_amd', description=__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -68,6 +92,8 @@ def main(argv=None):
     ap.add_argument('--params', help="Slideflow params.json: its norm_fit switches on the reinhard_fast stain normaliser (hp.py:19)")
     ap.add_argument('--tile-uq', type=float, default=0.0, help='tile-level uncertainty threshold (0 = off)')
     ap.add_argument('--slide-uq', type=float, default=0.0, help='slide-level uncertainty threshold (0 = off)')
+    ap.add_argument('--no-calibrate', action='store_true',
+                    help='f16 with external weights: skip the activation-exponent calibration on the first tiles (the headroom check stays)')
     args = ap.parse_args(argv)
 
     from . import distributed as D, threshold, weights as W
@@ -77,6 +103,7 @@ def main(argv=None):
     from .synthetic import make_slides
 
     rank, world, local = D.init_from_env('cuda')
+    D.pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), device_index=local)     # before any thread pool exists
     model_params = None
     if args.model:
         from .keras_import import load_model_dir
@@ -107,24 +134,32 @@ def main(argv=None):
             raise SystemExit(f'{args.params}: no norm_fit block')
     if args.mc is None:
         args.mc = hp.uq_n
-    pool = EnginePool(w, n_streams=args.streams, hp=hp, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local)
+    act_exp, probe = None, None
     if args.dtype == 'f16' and (args.model or args.weights) and slides:
-        # f16 clamps at +-65504 without a signal (MODE.FP16_OVFL): with weights from outside, look once before trusting it
+        # IEEE half ends at 65504 and every f16 kernel clamps there without a signal (MODE.FP16_OVFL).  With weights from outside
+        # the storage is kept in range by construction: the first tiles go through the fp32 kernels once, every stored tensor's
+        # peak is measured, and power-of-two activation exponents are folded into the BatchNorm constants (weights.py).  Every
+        # rank reads the same 16 tiles of the same slide, so every rank packs the same blob.
+        probe = _first_tiles(next((s for s in slides if s.n_tiles), None), 16)
+        if probe is not None and not args.no_calibrate:
+            from .engine import Engine
+            act_exp, peaks = Engine.calibrate(w, probe, hp=hp, device=local, norm_fit=norm_fit)
+            if rank == 0 and any(act_exp.values()):
+                big = {t: k for t, k in act_exp.items() if k}
+                print(f'f16: activation exponents from the first {len(probe)} tiles (peak {max(peaks.values()):.3g}): {big}', flush=True)
+    pool = EnginePool(w, n_streams=args.streams, hp=hp, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local,
+                      act_exp=act_exp)
+    if probe is not None:
         import torch
-        first = next((s for s in slides if s.n_tiles), None)
-        if first is not None:
-            t = first.load()
-            t = t.rows if hasattr(t, 'rows') else t
-            if not (torch.is_tensor(t) and t.dim() == 3):          # (filtered PNG scanlines are not tiles yet)
-                t = torch.as_tensor(np.ascontiguousarray(t[:8]) if not torch.is_tensor(t) else t[:8]).to(pool.engines[0].device)
-                if norm_fit is not None:
-                    t = pool.engines[0].reinhard_fast(t, norm_fit['target_means'], norm_fit['target_stds'])
-                hr = pool.engines[0].f16_headroom(t)
-                if any(hr['saturated'].values()):
-                    raise SystemExit(f'f16 storage saturates with these weights ({hr["saturated"]}): run with --dtype bf16 or f32')
-                if hr['headroom'] < 8:
-                    print(f'warning: f16 headroom only {hr["headroom"]:.1f}x on the first tiles ({hr["max_abs"]}); '
-                          f'consider --dtype bf16', flush=True)
+        t = torch.from_numpy(probe[:8]).to(pool.engines[0].device)
+        if norm_fit is not None:
+            t = pool.engines[0].reinhard_fast(t, norm_fit['target_means'], norm_fit['target_stds'])
+        hr = pool.engines[0].f16_headroom(t)                      # the check behind the construction
+        if any(hr['saturated'].values()):
+            raise SystemExit(f'f16 storage saturates with these weights ({hr["saturated"]}): run with --dtype bf16 or f32')
+        if hr['headroom'] < 8 and rank == 0:
+            print(f'warning: f16 headroom only {hr["headroom"]:.1f}x on the first tiles ({hr["max_abs"]}); '
+                  f'consider --dtype bf16', flush=True)
     res = evaluate(pool, slides, outcome=args.outcome, mc_n=args.mc, seed=args.seed, batch=args.batch,
                    save_dir=args.out, rank=rank, world=world, norm_fit=norm_fit)
     if rank == 0:

@@ -4,6 +4,7 @@
 #include "bq_common.h"
 
 #include <math.h>
+#include <cmath>
 #include <stdlib.h>
 #include <string.h>
 
@@ -53,6 +54,7 @@ struct bq_ctx {
     int num_cus = 256;
     float* d_srgb_lut = nullptr;   // tables of the Reinhard normaliser
     const long long* d_tile0 = nullptr;   // bq_set_tile_index_ptr
+    float feat_mul = 1.f;          // "act/feat_mul" of the blob: 2^k of the pooled tensor's activation exponent (weights.py: pack_blob)
     double* d_stage_stats = nullptr;   // 2 x 64-bit integer sums per tile for the staging kernel pair
     // profiling
     bool prof = false;
@@ -101,13 +103,18 @@ struct WsLayout {
 WsLayout ws_layout(const bq_ctx* c, int n, int mc) {
     const size_t es = esize(c);
     WsLayout L{};
-    size_t off = 4096;   // front pad: the streaming kernel's window column -1 of an image's first row reads (and discards) the
-                         // 16-bit pixel in front of the tensor
+    // The streaming and tail kernels (kernels_stream.hip, kernels_front.hip) read -- and mask -- a few pixels OUTSIDE the tensor
+    // they walk: the 16-bit pixel in front of an image's first row (window column -1) and up to three pixels (<= 768 B) behind
+    // the last row of the last image.  Every activation buffer therefore has kActPad bytes of the workspace on both sides: the
+    // pad in front of A, and a pad behind each of A, B, C and R (which is also the front pad of the next one).  run_conv hands
+    // these kernels workspace buffers only.
+    constexpr size_t kActPad = 4096;
+    size_t off = kActPad;
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
-    L.a = take((size_t)n * kMaxAct * es);
-    L.b = take((size_t)n * kMaxAct * es);
-    L.c = take((size_t)n * kMaxAct * es);
-    L.r = take((size_t)n * kMaxRes * es);
+    L.a = take((size_t)n * kMaxAct * es + kActPad);
+    L.b = take((size_t)n * kMaxAct * es + kActPad);
+    L.c = take((size_t)n * kMaxAct * es + kActPad);
+    L.r = take((size_t)n * kMaxRes * es + kActPad);
     L.staged = take((size_t)n * kStaged * es);
     L.feat = take((size_t)n * 2048 * 4);
     const size_t rows = (size_t)n * (mc > 0 ? mc : 1);
@@ -279,7 +286,7 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
         ProfScope pg(c, s, std::string(gap ? "gemm_gap_" : "gemm_") + cls, 2.0 * M * L.cin * L.cout + (gap ? M * L.cout : 0.0),
                      gap ? es * M * L.cin + 4.0 * a.n * L.cout
                          : es * (M * L.cin + M * L.cout * (a.residual ? 2.0 : 1.0)));
-        p.in = a.dwtmp; p.K = L.kpad; p.k_off = 0; p.kb0 = 0;
+        p.in = a.dwtmp; p.K = L.kpad; p.k_off = 0; p.kb0 = 0; p.gap_mul = c->feat_mul;
         p.scale = L.scale; p.bias = L.bias; p.relu = a.relu; p.residual = a.residual; p.out = gap ? (void*)a.gap_out : a.out;
         if (gap) *a.gap_done = true;
         // round 4: one image's pixels x 256 channels per workgroup on 16x16x32 fragments (kernels_exit.hip) when the layer's
@@ -288,7 +295,7 @@ int run_conv(bq_ctx* c, const ConvArgs& a, hipStream_t s) {
         if (!no_exit && L.wp16 && !a.residual && a.ldi == L.kpad && a.ldo == L.cout &&
             exit_supported(dtype, L.kpad, L.cout, a.H * a.W, a.n)) {
             const int e = launch_exit_gemm(dtype, a.dwtmp, L.wp16, L.scale, L.bias, a.out, gap ? a.gap_out : nullptr, a.n,
-                                           a.H * a.W, L.kpad, L.cout, a.relu, s);
+                                           a.H * a.W, L.kpad, L.cout, a.relu, c->feat_mul, s);
             if (e != 0) return fail(c, BQ_ERR_HIP, std::string("launch(exit_gemm) ") + a.layer + ": " +
                                                        hipGetErrorString((hipError_t)e));
             return BQ_OK;
@@ -522,8 +529,10 @@ int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void*
     return BQ_OK;
 }
 
+// part: bit 0 = stem + entry flow (blocks 1-4; its output stays in the workspace), bit 1 = middle + exit flow (reads it there):
+// bq_mc_infer_part lets a caller schedule the two halves of two batches against each other
 int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned char* ws, hipStream_t s,
-                  Tap* tap, const uint8_t* u8 = nullptr) {
+                  Tap* tap, const uint8_t* u8 = nullptr, int part = 3) {
     const WsLayout L = ws_layout(c, n, 1);
     void* A = ws + L.a; void* B = ws + L.b; void* C = ws + L.c; void* R = ws + L.r;
     const int dt = c->cfg.dtype;
@@ -534,7 +543,7 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     // sub-batches are gathered in the upper half of buffer B (the sub-batches only touch the front).
     static const int env_sub = bq_exp_env("BQ_SUB") ? atoi(bq_exp_env("BQ_SUB")) : 0;
     int sub = (tap && tap->want) ? n : env_sub;
-    if (sub <= 0 || sub > n / 2) sub = n;
+    if (sub <= 0 || sub > n / 2 || part != 3) sub = n;
     const size_t tile4 = (size_t)361 * 736 * esize(c);
     // Block 4 reads its input from B (blocks 2-4 alternate between B and R) and must not write over it: in one piece
     // its output goes to R, and B is the scratch buffer S of the middle and exit flow; in sub-batches it goes to the
@@ -542,8 +551,9 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     unsigned char* X4 = sub == n ? (unsigned char*)R : (unsigned char*)B + (size_t)(n / 2) * kMaxAct * esize(c);
     void* S = sub == n ? B : R;
     if (sub == n) {
-        RUN(entry_flow(c, in_nchw, n, X4, A, B, C, R, s, tap, u8));
+        if (part & 1) RUN(entry_flow(c, in_nchw, n, X4, A, B, C, R, s, tap, u8));
         if (tap && tap->written >= 0) return BQ_OK;
+        if (!(part & 2)) return BQ_OK;
     } else {
         for (int i0 = 0; i0 < n; i0 += sub) {
             const int ns = n - i0 < sub ? n - i0 : sub;
@@ -569,7 +579,9 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
     }
     // exit flow
     RUN(run_conv(c, {"block13_sepconv1", PROD_DW_RELU, X, Y, nullptr, nullptr, n, 19, 19, 19, 19, 736, 736, 1}, s));
+    TAP("block13_sepconv1", Y, 19, 19, 728, 736);
     RUN(run_conv(c, {"block13_sepconv2", PROD_DW, Y, C, nullptr, nullptr, n, 19, 19, 19, 19, 736, 1024, 0}, s));
+    TAP("block13_sepconv2", C, 19, 19, 1024, 1024);
     {   // the block's output goes to S (X is its input); X is scratch from here on
         int tapped = 0;
         RUN(block_end(c, "block13_res", "maxpool_add_19_c1024", X, C, S, n, 19, 736, 1024, 1024, s, tap, &tapped));
@@ -589,7 +601,7 @@ int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned c
         if (!gap_done) {
             TAP("block14_sepconv2", C, 10, 10, 2048, 2048);
             ProfScope ps(c, s, "global_avg_pool", (double)n * 100 * 2048, es * (double)n * 100 * 2048 + 4.0 * n * 2048);
-            if (launch_gap(C, n, 100, 2048, 2048, feat, dt, s)) return fail(c, BQ_ERR_HIP, "gap launch failed");
+            if (launch_gap(C, n, 100, 2048, 2048, feat, c->feat_mul, dt, s)) return fail(c, BQ_ERR_HIP, "gap launch failed");
         }
     }
     if (tap && tap->want) return fail(c, BQ_ERR_ARG, std::string("unknown activation: ") + tap->want);
@@ -804,6 +816,15 @@ int bq_load_weights(bq_ctx* c, const void* host_blob, size_t nbytes) {
     c->logits_b = entry_f32(c, "logits/bias");
     if (!c->stem_w || !c->stem_s || !c->stem_b || !c->logits_w || !c->logits_b)
         return fail(c, BQ_ERR_WEIGHTS, "missing stem/logits tensors");
+    c->feat_mul = 1.f;
+    {
+        auto fm = c->entries.find("act/feat_mul");
+        if (fm != c->entries.end()) {
+            if (fm->second.n < 4) return fail(c, BQ_ERR_WEIGHTS, "bad size for act/feat_mul");
+            memcpy(&c->feat_mul, hb + (fm->second.p - c->d_blob), 4);
+            if (!(c->feat_mul > 0.f) || !std::isfinite(c->feat_mul)) return fail(c, BQ_ERR_WEIGHTS, "act/feat_mul must be a positive finite number");
+        }
+    }
     c->front_ws16 = c->front_wc16 = nullptr;
     {
         auto a = c->entries.find("block1_conv1/w16"), b = c->entries.find("block1_conv2/wp16");
@@ -900,6 +921,17 @@ int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, 
     return BQ_OK;
 }
 
+int bq_set_num_cus(bq_ctx* c, int n) {
+    if (!c || n < 0 || n > 1024) return fail(c, BQ_ERR_ARG, "bq_set_num_cus: bad argument");
+    int dev_cus = 256;
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
+    }
+    c->num_cus = n > 0 ? n : dev_cus;
+    return BQ_OK;
+}
+
 int bq_stream_destroy(bq_ctx* c, bq_stream_t stream) {
     if (!c || !stream) return fail(c, BQ_ERR_ARG, "bq_stream_destroy: bad argument");
     HIPCHK(c, hipStreamDestroy((hipStream_t)stream));
@@ -940,6 +972,21 @@ int bq_set_tile_index_ptr(bq_ctx* c, const int64_t* d_tile_idx0) {
     return BQ_OK;
 }
 
+// uint8 tiles -> pooled features, the kernels bq_mc_infer runs: in a 16-bit context with the front weights loaded staging +
+// block1_conv1 + block1_conv2 are ONE kernel straight from the bytes (kernels_front.hip), otherwise bq_stage + the backbone on
+// the planar tensor.  bq_mc_infer and bq_backbone_u8 share it, so a tile's features do not depend on which of the two a
+// caller used for its batch.
+static int features_from_u8(bq_ctx* c, const uint8_t* d_tiles, int n, float* feat, unsigned char* ws, const WsLayout& L,
+                            bq_stream_t stream, int part = 3) {
+    hipStream_t s = (hipStream_t)stream;
+    static const bool no_front = bq_exp_env("BQ_NO_FRONT") != nullptr;
+    const bool front = !no_front && is16(c->cfg.dtype) && c->front_ws16 && c->front_wc16;
+    if (front) return backbone_impl(c, nullptr, n, feat, ws, s, nullptr, d_tiles, part);
+    void* staged = ws + L.staged;
+    if (part & 1) RUN(bq_stage(c, d_tiles, n, staged, stream));
+    return backbone_impl(c, staged, n, feat, ws, s, nullptr, nullptr, part);
+}
+
 int bq_mc_infer(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int mc_n, uint64_t seed,
                 int mc_mode, float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes, bq_stream_t stream) {
     if (!c || !d_tiles || !d_mean2 || !d_std2 || !d_ws || n <= 0 || mc_n <= 0 || n > c->cfg.max_batch ||
@@ -950,32 +997,41 @@ int bq_mc_infer(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int
     if (ws_bytes < L.total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
     unsigned char* ws = (unsigned char*)d_ws;
     hipStream_t s = (hipStream_t)stream;
-    void* staged = ws + L.staged;
     float* feat = (float*)(ws + L.feat);
     float* state = (float*)(ws + L.state);
-    // 16-bit contexts: staging + stem + block1_conv2 as one kernel straight from the uint8 tiles (kernels_front.hip)
-    static const bool no_front = bq_exp_env("BQ_NO_FRONT") != nullptr;
-    const bool front = !no_front && is16(c->cfg.dtype) && c->front_ws16 && c->front_wc16;
     if (mc_mode == BQ_MC_HEAD) {
-        if (front) {
-            RUN(backbone_impl(c, nullptr, n, feat, ws, s, nullptr, d_tiles));
-        } else {
-            RUN(bq_stage(c, d_tiles, n, staged, stream));
-            RUN(backbone_impl(c, staged, n, feat, ws, s, nullptr));
-        }
+        RUN(features_from_u8(c, d_tiles, n, feat, ws, L, stream));
         return head_impl(c, feat, n, tile_idx0, mc_n, 0, seed, 1, 1, state, d_mean2, d_std2, ws, s);
     }
     // BQ_MC_FULL: the reference's loop structure -- the whole network once per pass.
     for (int p = 0; p < mc_n; ++p) {
-        if (front) {
-            RUN(backbone_impl(c, nullptr, n, feat, ws, s, nullptr, d_tiles));
-        } else {
-            RUN(bq_stage(c, d_tiles, n, staged, stream));
-            RUN(backbone_impl(c, staged, n, feat, ws, s, nullptr));
-        }
+        RUN(features_from_u8(c, d_tiles, n, feat, ws, L, stream));
         RUN(head_impl(c, feat, n, tile_idx0, 1, p, seed, p == 0, p == mc_n - 1, state, d_mean2, d_std2, ws, s));
     }
     return BQ_OK;
+}
+
+int bq_mc_infer_part(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int mc_n, uint64_t seed, int part,
+                     float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes, bq_stream_t stream) {
+    if (!c || !d_tiles || !d_mean2 || !d_std2 || !d_ws || n <= 0 || mc_n <= 0 || n > c->cfg.max_batch ||
+        mc_n > c->cfg.max_mc || (part != BQ_PART_ENTRY && part != BQ_PART_REST && part != BQ_PART_ALL))
+        return fail(c, BQ_ERR_ARG, "bq_mc_infer_part: bad argument");
+    if (!c->loaded) return fail(c, BQ_ERR_WEIGHTS, "weights not loaded");
+    const WsLayout L = ws_layout(c, n, mc_n);
+    if (ws_bytes < L.total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
+    unsigned char* ws = (unsigned char*)d_ws;
+    float* feat = (float*)(ws + L.feat);
+    RUN(features_from_u8(c, d_tiles, n, feat, ws, L, stream, part));
+    if (!(part & BQ_PART_REST)) return BQ_OK;
+    return head_impl(c, feat, n, tile_idx0, mc_n, 0, seed, 1, 1, (float*)(ws + L.state), d_mean2, d_std2, ws, (hipStream_t)stream);
+}
+
+int bq_backbone_u8(bq_ctx* c, const uint8_t* d_tiles, int n, float* d_feat, void* d_ws, size_t ws_bytes, bq_stream_t stream) {
+    if (!c || !d_tiles || !d_feat || !d_ws || n <= 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_backbone_u8: bad argument");
+    if (!c->loaded) return fail(c, BQ_ERR_WEIGHTS, "weights not loaded");
+    const WsLayout L = ws_layout(c, n, 1);
+    if (ws_bytes < L.total) return fail(c, BQ_ERR_WORKSPACE, "workspace too small");
+    return features_from_u8(c, d_tiles, n, d_feat, (unsigned char*)d_ws, L, stream);
 }
 
 int bq_slide_reduce(bq_ctx* c, const float* d_mean2, const float* d_std2, const int32_t* d_slide_idx, int n,

@@ -83,6 +83,7 @@ struct GemmParams {
     int Hi, Wi;            // input spatial size
     int relu;              // ReLU in the epilogue
     int lds_total;         // dynamic LDS bytes of the launch (set by the pipe launcher)
+    float gap_mul;         // EPI_GAP of kernels_split.hip: factor on the means (0 = 1: undoes an activation exponent)
 };
 
 size_t gemm_lds_bytes(int dtype, int shape, int K);
@@ -107,7 +108,7 @@ int launch_gemm_tile(int dtype, const GemmParams& p, bool s2, hipStream_t s, int
 // per-image means instead of the tensor
 bool exit_supported(int dtype, int K, int N, int HW, long long n);
 int launch_exit_gemm(int dtype, const void* in, const void* wp16, const float* scale, const float* bias, void* out, float* gap,
-                     int n, int HW, int K, int N, int relu, hipStream_t s);
+                     int n, int HW, int K, int N, int relu, float gap_mul, hipStream_t s);
 int launch_tile_conv(int dtype, int kind, const void* in, const void* wp, const float* dw, const float* scale,
                      const float* bias, void* out, int n, int H, int W, int Hi, int Wi, int relu, int num_cus,
                      hipStream_t s);
@@ -130,7 +131,7 @@ int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, in
                     int dtype, hipStream_t s);
 int launch_respool(int dtype, const void* x, const void* wp32, const float* scale, const float* bias, const void* y, void* out,
                    int n, int Hi, int Wi, int K, int ldx, int ld, int nf32, hipStream_t s);
-int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s);
+int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, float mul, int dtype, hipStream_t s);
 int launch_head_dense(const float* in, const void* wh, const void* wl, const float* bias, float* out, int rows, int K,
                       int mc_n, int pass0, int in_row_is_tile, int layer, unsigned seed_lo, unsigned seed_hi, unsigned thresh,
                       float dscale, long long tile0, const long long* tile0_dev, hipStream_t s);

@@ -471,8 +471,10 @@ inline bool decode_block(Bits& B, const Huff& dc, const Huff& ac, const uint16_t
     return idct_islow(coef, out, stride);
 }
 
-// data[0..n): a whole JPEG file.  out: px*px*3 RGB bytes.
-inline int decode(const uint8_t* data, size_t n, int px, uint8_t* out, Scratch& S) {
+// data[0..n): a whole JPEG file.  out: px*px*3 RGB bytes.  probe_only: stop in front of the entropy decoder -- everything the
+// markers and the scan's structure can refuse (progressive / arithmetic / lossless frames, sampling factors, colour spaces, restart
+// structure, size) has been checked by then, at the cost of one pass over the bytes; `out` is not written.
+inline int decode(const uint8_t* data, size_t n, int px, uint8_t* out, Scratch& S, bool probe_only = false) {
     if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return UNSUPPORTED;
     color_tables(S);
     for (int i = 0; i < 4; ++i) { S.dc[i].defined = S.ac[i].defined = false; S.qdef[i] = false; }
@@ -612,6 +614,7 @@ inline int decode(const uint8_t* data, size_t n, int px, uint8_t* out, Scratch& 
     const int64_t total_mcu = (int64_t)mcux * mcuy;
     const int64_t per_seg = restart ? restart : total_mcu;
     if ((int64_t)(S.seg.size() - 1) != (total_mcu + per_seg - 1) / per_seg) return UNSUPPORTED;
+    if (probe_only) return OK;
 
     Bits B;
     int64_t mcu = 0;

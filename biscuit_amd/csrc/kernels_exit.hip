@@ -33,6 +33,7 @@ struct ExitParams {
     T* out;               // [n * HW][N]       (GAP: unused)
     float* gap;           // [n][N] fp32 means (GAP only)
     int n, HW, K, N, relu;
+    float gap_mul;        // GAP: factor on the means (2^k: undoes the activation exponent of the pooled tensor; 1.0f otherwise)
 };
 
 template <typename T, bool GAP>
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(256, 2) exit_gemm_kernel(const ExitParams<T> p
                 v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
                 v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
                 v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-                sum[e] = v / (float)p.HW;
+                sum[e] = v / (float)p.HW * p.gap_mul;
             }
             if (px == 15) {
                 float* dst = p.gap + (size_t)img * p.N + ch;
@@ -166,10 +167,10 @@ __global__ void __launch_bounds__(256, 2) exit_gemm_kernel(const ExitParams<T> p
 
 template <typename T>
 int launch_exit_t(const void* in, const void* wp16, const float* scale, const float* bias, void* out, float* gap, int n, int HW,
-                  int K, int N, int relu, hipStream_t s) {
+                  int K, int N, int relu, float gap_mul, hipStream_t s) {
     ExitParams<T> p{};
     p.in = reinterpret_cast<const T*>(in); p.wp16 = reinterpret_cast<const uint4*>(wp16); p.scale = scale; p.bias = bias;
-    p.out = reinterpret_cast<T*>(out); p.gap = gap; p.n = n; p.HW = HW; p.K = K; p.N = N; p.relu = relu;
+    p.out = reinterpret_cast<T*>(out); p.gap = gap; p.n = n; p.HW = HW; p.K = K; p.N = N; p.relu = relu; p.gap_mul = gap_mul;
     const int grid = n * (N / XN);
     const size_t lds = 2 * XA_BUF;
     if (gap) hipLaunchKernelGGL((exit_gemm_kernel<T, true>), dim3(grid), dim3(256), lds, s, p);
@@ -188,8 +189,8 @@ bool exit_supported(int dtype, int K, int N, int HW, long long n) {
 // out = relu?(BN(in[n * HW][K] x W)) as [n * HW][N] -- or, with gap != nullptr, its mean over each image's HW pixels as fp32
 // [n][N] (out is not written).  dtype: 1 = bf16, 2 = f16.
 int launch_exit_gemm(int dtype, const void* in, const void* wp16, const float* scale, const float* bias, void* out, float* gap,
-                     int n, int HW, int K, int N, int relu, hipStream_t s) {
+                     int n, int HW, int K, int N, int relu, float gap_mul, hipStream_t s) {
     if (!exit_supported(dtype, K, N, HW, n)) return (int)hipErrorInvalidValue;
-    return dtype == 2 ? launch_exit_t<f16_t>(in, wp16, scale, bias, out, gap, n, HW, K, N, relu, s)
-                      : launch_exit_t<bf16_t>(in, wp16, scale, bias, out, gap, n, HW, K, N, relu, s);
+    return dtype == 2 ? launch_exit_t<f16_t>(in, wp16, scale, bias, out, gap, n, HW, K, N, relu, gap_mul, s)
+                      : launch_exit_t<bf16_t>(in, wp16, scale, bias, out, gap, n, HW, K, N, relu, gap_mul, s);
 }

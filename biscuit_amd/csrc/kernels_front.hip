@@ -91,7 +91,11 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
     constexpr int PRIV_OFF = SB_OFF + 192 * 4;
     constexpr int U8_PITCH = 112;               // bytes per staged uint8 row (99 + up to 3 of alignment, as 26 dwords)
     constexpr int U8_DW = 26;
-    constexpr int RING_PITCH = 16 * 64;         // one stem row of the strip: 16 pixels x 32 channels
+    constexpr int PXP = 96;                     // bytes per pixel of a ring row: 32 channels + 32 of padding -- 6 slots of 16 B, = 2 (mod 4):
+                                                // the conv2 operand's ds_read_b128 (lane -> pixel l & 15 (+ dx), k-group l >> 4) is conflict-free
+                                                // over its four 16-lane groups and the ring's ds_write_b128 2-way; at 64 B (4 slots) the reads
+                                                // were 2-way and the writes 4-way: 27 % of the kernel's LDS cycles (profiles/r04_sq_counters.txt)
+    constexpr int RING_PITCH = 16 * PXP;        // one stem row of the strip: 16 pixels x 32 channels
     constexpr int NRING = 4;                    // stem rows y .. y + 3: two conv2 rows per step
     constexpr int PRIV = 3 * U8_PITCH + NRING * RING_PITCH;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
                 o.y = H16<T>::pack2(fmaxf(fmaf(v[2], s0.z, c0.z), 0.f), fmaxf(fmaf(v[3], s0.w, c0.w), 0.f));
                 o.z = H16<T>::pack2(fmaxf(fmaf(v[4], s1.x, c1.x), 0.f), fmaxf(fmaf(v[5], s1.y, c1.y), 0.f));
                 o.w = H16<T>::pack2(fmaxf(fmaf(v[6], s1.z, c1.z), 0.f), fmaxf(fmaf(v[7], s1.w, c1.w), 0.f));
-                *reinterpret_cast<uint4*>(ring + slot * RING_PITCH + px * 64 + g * 16) = o;
+                *reinterpret_cast<uint4*>(ring + slot * RING_PITCH + px * PXP + g * 16) = o;
             }
         };
 
@@ -280,9 +284,9 @@ __global__ void __launch_bounds__(NWF * 64) front_stream_kernel(const FrontParam
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int slot = r == 0 ? s0 : (r == 1 ? s1 : (r == 2 ? s2 : s3));
-                    const unsigned char* rp = ring + slot * RING_PITCH + (px < SW ? px : SW - 1) * 64 + g * 16;   // (slots 14, 15 are not outputs)
+                    const unsigned char* rp = ring + slot * RING_PITCH + (px < SW ? px : SW - 1) * PXP + g * 16;   // (slots 14, 15 are not outputs)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) b[r][dx] = *reinterpret_cast<const uint4*>(rp + dx * 64);
+                    for (int dx = 0; dx < 3; ++dx) b[r][dx] = *reinterpret_cast<const uint4*>(rp + dx * PXP);
                 }
                 uint4 w[2][4];
                 auto fetch = [&](int t, uint4 (&dst)[4]) {
@@ -344,7 +348,7 @@ int launch_front_t(const uint8_t* tiles, const unsigned long long* stats, const 
     }
     p.nbands = nb;
     p.items = (int)(base_items * nb);
-    constexpr size_t lds = 2 * 2 * 1024 + 9 * 4 * 1024 + 192 * 4 + (size_t)NWF * (3 * 112 + 4 * 16 * 64);
+    constexpr size_t lds = 2 * 2 * 1024 + 9 * 4 * 1024 + 192 * 4 + (size_t)NWF * (3 * 112 + 4 * 16 * 96);
     static_assert(lds <= 160 * 1024, "front kernel LDS budget");
     auto kern = front_stream_kernel<T>;
     static BqLdsAttr attr;

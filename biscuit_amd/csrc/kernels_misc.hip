@@ -280,14 +280,14 @@ __global__ void __launch_bounds__(256) pool_add_kernel(const T* __restrict__ y, 
 // ---------------------------------------------------------------- K5 global average pool
 template <typename T>
 __global__ void __launch_bounds__(256) gap_kernel(const T* __restrict__ x, int n, int HW, int C, int ld,
-                                                  float* __restrict__ feat) {
+                                                  float* __restrict__ feat, float mul) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)n * C) return;
     const int img = (int)(gid / C), c = (int)(gid - (long long)img * C);
     const T* p = x + (size_t)img * HW * ld + c;
     float s = 0.f;
     for (int i = 0; i < HW; ++i) s += to_f32<T>(p[(size_t)i * ld]);
-    feat[gid] = s / (float)HW;
+    feat[gid] = s / (float)HW * mul;
 }
 
 // ---------------------------------------------------------------- K6 tail
@@ -524,11 +524,11 @@ int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, in
     return (int)hipGetLastError();
 }
 
-int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, int dtype, hipStream_t s) {
+int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, float mul, int dtype, hipStream_t s) {
     const long long total = (long long)n * C;
     BQ_DISPATCH_T(dtype,
                   hipLaunchKernelGGL(gap_kernel<T_>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                                     (const T_*)x, n, HW, C, ld, feat));
+                                     (const T_*)x, n, HW, C, ld, feat, mul));
     return (int)hipGetLastError();
 }
 

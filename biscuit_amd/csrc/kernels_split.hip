@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(const GemmParams p) {
                 float sum = 0.f;
                 for (int r = 0; r < rows_per_tile; ++r)
                     sum += (float)*reinterpret_cast<const T*>(smem + (size_t)r * ST_ROW + tid * 2);
-                reinterpret_cast<float*>(p.out)[(size_t)mt * p.ldo + ncol] = sum / (float)rows_per_tile;
+                reinterpret_cast<float*>(p.out)[(size_t)mt * p.ldo + ncol] = sum / (float)rows_per_tile * (p.gap_mul != 0.f ? p.gap_mul : 1.f);
             }
         }
     } else if constexpr (EPI == EPI_POOL) {

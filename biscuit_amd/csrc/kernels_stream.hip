@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
     constexpr int HALVES = 128 / CIN;           // 1: a lane is a channel pair of all 128; 2: lanes 32-63 take columns 8-15
     constexpr int NCOL = 16 / HALVES;           // output columns per lane
     constexpr int NWIN = NCOL + 2;              // window columns per lane
-    constexpr int AST = CIN * 2 + 16;           // A row stride: an odd number of 16-byte slots
+    constexpr int AST = CIN * 2 + 32;           // A row stride in 16-byte slots = 2 (mod 4): the operand's ds_read_b128 (lane -> row l & 15,
+                                                // k-group l >> 4) is conflict-free over its four 16-lane groups; an ODD slot count (round 4)
+                                                // leaves one 2-way conflict per group: 27 % of the LDS cycles of the cooperative tail
     constexpr int W_BYTES = KS * NF * 1024;
     constexpr int SB_OFF = W_BYTES;             // scale[COUT] | bias[COUT], fp32
     constexpr int A_OFF = SB_OFF + 2 * COUT * 4;
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
     constexpr int NT = NW * 64;
     constexpr int CIN = 128, COUT = 128, KS = CIN / 32, NF = COUT / 16, NQ = COUT / 32, NCOL = 16, NWIN = NCOL + 2;
     constexpr int KR = CX / 32;
-    constexpr int AST = CIN * 2 + 16;
+    constexpr int AST = CIN * 2 + 32;           // slots per row = 2 (mod 4), see sepconv_stream_kernel
     constexpr int W_BYTES = KS * NF * 1024, WR_BYTES = KR * NF * 1024;
     constexpr int WR_OFF = W_BYTES;
     constexpr int SB_OFF = WR_OFF + WR_BYTES;   // scale | bias | rscale | rbias, fp32 [4][COUT]
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(C * 2, WGS) block_tail_coop_kernel(const CoopP
     if constexpr (H16<T>::F16) bq_f16_saturate();
     constexpr int CIN = C, COUT = C, CX = C / 2, KS = CIN / 32, KR = CX / 32, NCOL = 4, NWIN = NCOL + 2;
     constexpr int NT = C * 2, NFR = COUT / 16;          // C / 32 waves of 32 output (and depthwise input) channels; 16-wide fragments
-    constexpr int AST = CIN * 2 + 16;
+    constexpr int AST = CIN * 2 + 32;           // slots per row = 2 (mod 4), see sepconv_stream_kernel
     constexpr int A_BYTES = 16 * AST;
     constexpr int SB_OFF = 2 * A_BYTES;         // scale | bias | rscale | rbias, fp32 [4][COUT]
     constexpr unsigned NEG = NegInf<T>::v;
@@ -743,7 +745,7 @@ __global__ void __launch_bounds__(C * 2, WGS) block_tail_coop_kernel(const CoopP
 
 template <typename T, int C, int WGS>
 int launch_coop(CoopParams<T> p, int num_cus, hipStream_t s) {
-    constexpr size_t lds = 2 * 16 * (C * 2 + 16) + 4 * C * 4;
+    constexpr size_t lds = 2 * 16 * (C * 2 + 32) + 4 * C * 4;
     auto kern = block_tail_coop_kernel<T, C, WGS>;
     static BqLdsAttr attr;
     if (const int e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) return e;
@@ -772,7 +774,7 @@ template <typename T, int CIN, int COUT, bool RELU_IN>
 int launch_stream(StreamParams<T> p, int num_cus, hipStream_t s) {
     // 256 output channels: 64 accumulator registers, 64 KB of weights -> 8 waves (2 per SIMD, 256 registers)
     constexpr int NW = COUT > 128 ? 8 : STREAM_NW;
-    constexpr size_t lds = (size_t)(CIN / 32) * (COUT / 16) * 1024 + 2 * COUT * 4 + (size_t)NW * 16 * (CIN * 2 + 16);
+    constexpr size_t lds = (size_t)(CIN / 32) * (COUT / 16) * 1024 + 2 * COUT * 4 + (size_t)NW * 16 * (CIN * 2 + 32);
     static_assert(lds <= 160 * 1024, "stream kernel LDS budget");
     auto kern = sepconv_stream_kernel<T, CIN, COUT, RELU_IN, NW>;
     static BqLdsAttr attr;
@@ -792,7 +794,7 @@ int launch_stream(StreamParams<T> p, int num_cus, hipStream_t s) {
 template <typename T, int CX>
 int launch_tail(TailParams<T> p, int num_cus, hipStream_t s) {
     constexpr int NW = TAIL_NW;
-    constexpr size_t lds = (size_t)4 * 8 * 1024 + (size_t)(CX / 32) * 8 * 1024 + 4 * 128 * 4 + (size_t)NW * 16 * (128 * 2 + 16);
+    constexpr size_t lds = (size_t)4 * 8 * 1024 + (size_t)(CX / 32) * 8 * 1024 + 4 * 128 * 4 + (size_t)NW * 16 * (128 * 2 + 32);
     static_assert(lds <= 160 * 1024, "tail kernel LDS budget");
     auto kern = block_tail_stream_kernel<T, CX, NW>;
     static BqLdsAttr attr;

@@ -535,6 +535,34 @@ static int decode_impl(bqio_reader* r, int64_t first, int64_t count, int tile_px
     return e;
 }
 
+int bqio_probe(bqio_reader* r, int64_t first, int64_t count, int tile_px, int64_t* bad_index) {
+    if (!r || first < 0 || count < 0 || first + count > (int64_t)r->records.size() || tile_px <= 0) return BQIO_ERR_ARG;
+    if (bad_index) *bad_index = -1;
+    std::unique_ptr<bqjpg::Scratch> jpg;
+    for (int64_t i = first; i < first + count; ++i) {
+        Example ex;
+        int e = BQIO_OK;
+        if (!parse_example(r->records[(size_t)i], ex) || !ex.image.p) e = BQIO_ERR_CORRUPT;
+        else switch (image_format(ex.image)) {
+            case BQIO_IMG_PNG: break;                      // lossless: whichever decoder takes it, the pixels are the same
+            case BQIO_IMG_JPEG: {
+                if (!jpg) jpg.reset(new bqjpg::Scratch());
+                const int j = bqjpg::decode(ex.image.p, ex.image.n, tile_px, nullptr, *jpg, true);
+                e = j == bqjpg::OK ? BQIO_OK : j == bqjpg::WRONG_SIZE ? BQIO_ERR_FORMAT : BQIO_ERR_UNSUPPORTED;
+                break;
+            }
+            default: e = BQIO_ERR_UNSUPPORTED;
+        }
+        if (e != BQIO_OK) {
+            if (bad_index) *bad_index = i;
+            r->err = e == BQIO_ERR_UNSUPPORTED ? "image_raw is not a PNG or baseline JPEG this decoder handles"
+                     : e == BQIO_ERR_FORMAT    ? "tile size differs from tile_px" : "corrupt record";
+            return e;
+        }
+    }
+    return BQIO_OK;
+}
+
 int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc, int n_threads,
                 int64_t* bad_index) {
     return decode_impl(r, first, count, tile_px, out, loc, n_threads, bad_index, false);

@@ -4,6 +4,7 @@ communication is ONE all-gather of the per-slide results at the end (RCCL over x
 the GPU box -- backend "nccl" is RCCL on ROCm; gloo in CPU tests).  The reference is
 single-process and has no counterpart; nothing here is translated from it.
 """
+import datetime
 import os
 
 import numpy as np
@@ -49,7 +50,79 @@ def global_tile_offsets(tile_counts):
     return np.concatenate([[0], np.cumsum(counts)[:-1]]) if len(counts) else counts
 
 
-def init_from_env(device_type='cuda', backend=None, local_device=None, single_rank_group=False):
+def _cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist) -> sorted list of ints."""
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        out += list(range(int(a), int(b or a) + 1))
+    return sorted(set(out))
+
+
+def gpu_numa_node(device_index):
+    """NUMA node of HIP device ``device_index`` from sysfs (``/sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node``), or None when
+    the platform does not say (a single-socket box, a container without that file, -1)."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+        node = int(open(f'/sys/bus/pci/devices/{bdf}/numa_node').read())
+        return node if node >= 0 else None
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None
+
+
+def rank_cores(local_rank, local_world, allowed=None, numa_cpus=None, numa_peers=None):
+    """The CPU cores one of ``local_world`` ranks on a node should confine itself to: its share of ``allowed`` (default: the
+    process's affinity mask) -- of the cores of its GPU's NUMA node when those are known (``numa_cpus``; ``numa_peers`` = (index
+    among, number of) the local ranks whose GPUs sit on the same node), of everything otherwise -- as a contiguous slice, never
+    empty.  Pure function of its arguments (tested on CPU); ``pin_rank`` applies it."""
+    allowed = sorted(os.sched_getaffinity(0)) if allowed is None else sorted(allowed)
+    pool, k, n = allowed, int(local_rank), max(1, int(local_world))
+    if numa_cpus:
+        near = [c for c in allowed if c in set(numa_cpus)]
+        if near:
+            pool = near
+            k, n = numa_peers if numa_peers else (k, n)
+    n = max(1, min(n, len(pool)))
+    k = k % n
+    lo, hi = k * len(pool) // n, (k + 1) * len(pool) // n
+    return pool[lo:hi] or pool[:1]
+
+
+def pin_rank(local_rank, local_world, device_index=None):
+    """Confine this rank to its share of the node's cores, next to its GPU where the platform tells (call BEFORE any thread pool
+    exists: torch's intra-op pool and libbiscuit_io's decoder threads inherit the mask of the thread that creates them).  Eight
+    ranks on one node otherwise each start min(cores, 16) decoder threads on the same cores.  Returns the cores."""
+    if not hasattr(os, 'sched_setaffinity') or local_world <= 1:
+        return sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+    numa_cpus = peers = None
+    if device_index is not None and torch.cuda.is_available():
+        node = gpu_numa_node(device_index)
+        if node is not None:
+            try:
+                numa_cpus = _cpulist(open(f'/sys/devices/system/node/node{node}/cpulist').read())
+                ndev = torch.cuda.device_count()
+                same = [d for d in range(min(ndev, local_world)) if gpu_numa_node(d) == node]
+                if device_index in same:
+                    peers = (same.index(device_index), len(same))
+            except (OSError, ValueError):
+                numa_cpus = None
+    cores = rank_cores(local_rank, local_world, numa_cpus=numa_cpus, numa_peers=peers)
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError:
+        pass
+    return cores
+
+
+# Rendezvous and every collective give up after this long instead of the backend's default (NCCL / RCCL: ten minutes and more): a
+# rank that died before the rendezvous must not leave the others waiting into the launcher's time limit
+DIST_TIMEOUT_S = 120
+
+
+def init_from_env(device_type='cuda', backend=None, local_device=None, single_rank_group=False, timeout_s=DIST_TIMEOUT_S):
     """Initialise torch.distributed from the launcher's rendezvous variables (torchrun's contract: RANK, WORLD_SIZE,
     LOCAL_RANK, MASTER_ADDR, MASTER_PORT -- the only environment this package reads).
 
@@ -66,7 +139,8 @@ def init_from_env(device_type='cuda', backend=None, local_device=None, single_ra
         backend = backend or ('nccl' if device_type == 'cuda' else 'gloo')
         if device_type == 'cuda':
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(timeout_s)))
     elif device_type == 'cuda' and torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local

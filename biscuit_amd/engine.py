@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .hp import ModelParams, nature2022
-from .weights import DTYPE_CODE, pack_blob
+from .weights import DTYPE_CODE, choose_act_exponents, pack_blob, tensor_taps
 
 TILE_PX = 299
 
@@ -49,7 +49,7 @@ class Engine:
     """
 
     def __init__(self, weights, hp: ModelParams = None, dtype='f16', max_batch=256, max_mc=30,
-                 device=None):
+                 device=None, act_exp=None):
         if not torch.cuda.is_available():
             raise BiscuitHipError('no HIP device visible: the MI355X path has no CPU fallback')
         self.hp = hp or nature2022()
@@ -64,11 +64,50 @@ class Engine:
         self._ctx = self._lib.bq_create(self.device.index, C.byref(cfg))
         if not self._ctx:
             raise BiscuitHipError('bq_create: ' + self._lib.bq_last_error(None).decode())
-        blob = pack_blob(weights, dtype)
+        # activation exponents (weights.py: choose_act_exponents / Engine.calibrate): the f16 mode's range by construction
+        self.act_exp = {t: int(k) for t, k in (act_exp or {}).items() if int(k)} if dtype == 'f16' else {}
+        self._tap_exp = {tap: self.act_exp.get(t, 0) for t, taps in tensor_taps().items() for tap in taps}
+        blob = pack_blob(weights, dtype, self.act_exp)
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
         self._check(self._lib.bq_load_weights(self._ctx, C.cast(buf, C.c_void_p), len(blob)))
         self._ws = None
         self._elt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtype]
+
+    # shapes of the stored tensors by debug-tap name
+    TAP_SHAPES = dict([('block1_conv1', (149, 149, 32)), ('block1_conv2', (147, 147, 64))] +
+                      [(f'block2_{n}', (147, 147, 128)) for n in ('sepconv1', 'sepconv2')] +
+                      [(f'block2_{n}', (74, 74, 128)) for n in ('res', 'out')] +
+                      [(f'block3_{n}', (74, 74, 256)) for n in ('sepconv1', 'sepconv2')] +
+                      [(f'block3_{n}', (37, 37, 256)) for n in ('res', 'out')] +
+                      [(f'block4_{n}', (37, 37, 728)) for n in ('sepconv1', 'sepconv2')] +
+                      [(f'block4_{n}', (19, 19, 728)) for n in ('res', 'out')] +
+                      [(f'block{b}_{n}', (19, 19, 728)) for b in range(5, 13) for n in ('sepconv1', 'sepconv2', 'out')] +
+                      [('block13_sepconv1', (19, 19, 728)), ('block13_sepconv2', (19, 19, 1024)), ('block13_res', (10, 10, 1024)),
+                       ('block13_out', (10, 10, 1024)), ('block14_sepconv1', (10, 10, 1536)), ('block14_sepconv2', (10, 10, 2048))])
+
+    @staticmethod
+    def calibrate(weights, tiles_u8, hp=None, device=None, target_log2=12, norm_fit=None):
+        """Activation exponents for the f16 storage type, measured: up to 16 of ``tiles_u8`` (uint8 [n,299,299,3], host or
+        device; the tiles the model will see -- stain-normalised here when ``norm_fit`` is given) go through the fp32 kernels
+        of this library, which have no range limit, every stored tensor is tapped, and ``weights.choose_act_exponents`` turns
+        the peaks into powers of two.  Returns ``(act_exp, peaks)``; pass ``act_exp`` to ``Engine`` / ``EnginePool``.  A
+        network whose activations fit IEEE half as they are gets all-zero exponents and the blob it always had."""
+        t = torch.as_tensor(np.asarray(tiles_u8[:16]) if not torch.is_tensor(tiles_u8) else tiles_u8[:16])
+        eng = Engine(weights, hp=hp, dtype='f32', max_batch=max(1, int(t.shape[0])), max_mc=1, device=device)
+        try:
+            t = t.to(eng.device).contiguous()
+            if norm_fit is not None:
+                t = eng.reinhard_fast(t, norm_fit['target_means'], norm_fit['target_stds'])
+            staged = eng.stage(t)
+            peaks = {}
+            for tensor, taps in tensor_taps().items():
+                peaks[tensor] = max(float(eng.debug_activation(tap, staged, Engine.TAP_SHAPES[tap]).abs().max()) for tap in taps)
+        finally:
+            eng.close()
+        bad = [k for k, v in peaks.items() if not np.isfinite(v)]
+        if bad:
+            raise BiscuitHipError(f'calibration: non-finite activations in {bad[:4]}')
+        return choose_act_exponents(weights, peaks, target_log2), peaks
 
     # ------------------------------------------------------------------ utils
     def close(self):
@@ -98,6 +137,11 @@ class Engine:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def set_num_cus(self, n):
+        """Size the persistent kernels' grids for ``n`` compute units (``bq_set_num_cus``; 0: the whole device): what a context
+        whose launches go to a CU-masked stream wants.  Results do not depend on it."""
+        self._check(self._lib.bq_set_num_cus(self._ctx, int(n)))
 
     # ------------------------------------------------------------------ stages
     def stage(self, tiles_u8):
@@ -155,6 +199,17 @@ class Engine:
                                           self._stream()))
         return feat
 
+    def backbone_u8(self, tiles_u8):
+        """uint8 NHWC tiles (device) -> [n,2048] features through the kernels ``mc_infer`` runs (``bq_backbone_u8``: in a
+        16-bit context the fused front kernel, not stage + stem + conv2)."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
+        n = tiles_u8.shape[0]
+        ws = self._ws_for(n, 1)
+        feat = torch.empty((n, 2048), dtype=torch.float32, device=self.device)
+        self._check(self._lib.bq_backbone_u8(self._ctx, _ptr(tiles_u8), n, _ptr(feat), _ptr(ws), ws.numel(),
+                                             self._stream()))
+        return feat
+
     def mc_head(self, feat, mc_n, seed, tile_idx0=0, out=None):
         """GAP features [n,2048] -> (mean[n,2], std[n,2]) over mc_n dropout passes; the Philox tile counter of row i
         is tile_idx0 + i.  ``out``: (mean, std) to write into (contiguous [n,2] fp32 views are fine)."""
@@ -195,6 +250,19 @@ class Engine:
         self._check(self._lib.bq_mc_infer(self._ctx, _ptr(tiles_u8), n, int(tile_idx0), int(mc_n),
                                           int(seed), mode, _ptr(mean), _ptr(std), _ptr(ws), ws.numel(),
                                           self._stream()))
+        return mean, std
+
+    def mc_infer_part(self, part, tiles_u8, mc_n, seed, tile_idx0=0, out=None):
+        """``mc_infer`` (head mode) in two parts (``bq_mc_infer_part``): part 'entry' = staging + stem + entry flow (its output
+        stays in this engine's workspace), part 'rest' = middle + exit flow + MC head -> ``out``.  'entry' then 'rest' with the
+        same arguments on one engine equals ``mc_infer`` bit for bit; a scheduler may put other engines' work in between."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
+        n = tiles_u8.shape[0]
+        ws = self._ws_for(n, mc_n)
+        mean, std = out
+        code = {'entry': _lib.BQ_PART_ENTRY, 'rest': _lib.BQ_PART_REST, 'all': _lib.BQ_PART_ALL}[part]
+        self._check(self._lib.bq_mc_infer_part(self._ctx, _ptr(tiles_u8), n, int(tile_idx0), int(mc_n), int(seed), code,
+                                               _ptr(mean), _ptr(std), _ptr(ws), ws.numel(), self._stream()))
         return mean, std
 
     def slide_reduce(self, mean2, std2, slide_idx, n_slides, tile_uq=None, acc=None):
@@ -246,7 +314,9 @@ class Engine:
             raise ValueError('ROC undefined: only one class present')
         return float(o[0]), {'j': float(o[1]), 'tpr': float(o[2]), 'fpr': float(o[3]), 'n_pos': int(o[4]), 'n_neg': int(o[5])}
 
-    def debug_activation(self, name, staged, shape_hwc):
+    def debug_activation(self, name, staged, shape_hwc, true_scale=True):
+        """The named activation as fp32 [n,H,W,C]; with activation exponents (``act_exp``) the stored tensor times 2^k, i.e. the
+        network's values, unless ``true_scale=False``."""
         n = staged.shape[0]
         ws = self._ws_for(n, 1)
         h, w, c = shape_hwc
@@ -255,9 +325,10 @@ class Engine:
                                            _ptr(out), out.numel(), self._stream())
         self._check(rc)
         assert rc == out.numel(), (rc, out.numel())
-        return out
+        k = self._tap_exp.get(name, 0)
+        return out * float(2.0 ** k) if (k and true_scale) else out
 
-    def debug_activation_u8(self, name, tiles_u8, shape_hwc):
+    def debug_activation_u8(self, name, tiles_u8, shape_hwc, true_scale=True):
         """The same tap on the path ``mc_infer`` takes in a 16-bit context: uint8 tiles [n,299,299,3] through the fused front
         kernel (standardise + block1_conv1 + block1_conv2 in one launch), then the network up to ``name``."""
         assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
@@ -269,7 +340,8 @@ class Engine:
                                               _ptr(out), out.numel(), self._stream())
         self._check(rc)
         assert rc == out.numel(), (rc, out.numel())
-        return out
+        k = self._tap_exp.get(name, 0)
+        return out * float(2.0 ** k) if (k and true_scale) else out
 
     # layers whose outputs the 16-bit storage can clip: the largest activations of Xception sit behind the un-normalised sums
     # of the residual stream and in front of the pooled features
@@ -290,7 +362,7 @@ class Engine:
         if self.dtype != 'f16' or t.shape[0] == 0:
             return out
         for name, shp in self.HEADROOM_TAPS:
-            a = self.debug_activation_u8(name, t, shp)
+            a = self.debug_activation_u8(name, t, shp, true_scale=False)       # as stored: what the range limit applies to
             m = float(a.abs().max())
             out['max_abs'][name] = m
             out['saturated'][name] = int((a.abs() >= limit).sum())
@@ -313,8 +385,9 @@ class EnginePool:
     flight together; by default every stream owns a disjoint group of XCDs (see __init__ and DESIGN.md).
     Every context owns its weights copy and workspace; results are independent of the stream used."""
 
-    def __init__(self, weights, n_streams=2, cu_split='contig', **kw):
+    def __init__(self, weights, n_streams=2, cu_split='contig', size_grids=False, **kw):
         self.engines = [Engine(weights, **kw) for _ in range(max(1, int(n_streams)))]
+        self.size_grids = bool(size_grids)      # persistent grids sized for the CUs of each stream's mask (Engine.set_num_cus)
         dev = self.engines[0].device
         # Two streams own disjoint halves of the chip (hipExtStreamCreateWithCUMask; mask bits 0..127 and
         # 128..255 = XCDs 0-3 and 4-7, each with its own L2s): two batches in flight then run side by side
@@ -329,6 +402,7 @@ class EnginePool:
         self._sets = {}                 # batches in flight -> list of streams
         self.active = len(self.engines)
         self.streams = self._stream_set(self.active)
+        self._apply_grid_size(self.active)
 
     def _stream_set(self, n):
         """n streams: CU-masked (each owns 1/n of the chip's XCDs) when n >= 2 and masks are available,
@@ -344,10 +418,18 @@ class EnginePool:
                 import warnings
                 warnings.warn(f'CU-masked streams unavailable ({e}); using plain HIP streams')
                 self.cu_split = None
+        masked = streams is not None
         if streams is None:
             streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
         self._sets[n] = streams
+        self._masked = getattr(self, '_masked', {})
+        self._masked[n] = masked
         return streams
+
+    def _apply_grid_size(self, n):
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        for k, eng in enumerate(self.engines):
+            eng.set_num_cus(ncu // n if (self.size_grids and k < n and self._masked.get(n)) else 0)
 
     def set_in_flight(self, n):
         """Use the first n contexts, each on its own share of the chip (n = 1: one whole-chip stream).
@@ -356,6 +438,7 @@ class EnginePool:
         self.synchronize()
         self.active = n
         self.streams = self._stream_set(n)
+        self._apply_grid_size(n)
 
     def _masked_streams(self, split, dev, nst):
         streams = []
@@ -403,6 +486,108 @@ class EnginePool:
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
+
+
+def _mask_stream(eng, cus, ncu):
+    """A HIP stream restricted to the compute units in ``cus`` (bq_stream_create_masked)."""
+    bits = [0] * ((ncu + 31) // 32)
+    for cu in cus:
+        bits[cu // 32] |= 1 << (cu % 32)
+    arr = (C.c_uint32 * len(bits))(*bits)
+    h = C.c_void_p()
+    eng._check(eng._lib.bq_stream_create_masked(eng._ctx, arr, len(bits), C.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device=eng.device)
+
+
+class PhasedPool:
+    """Two batches in flight, each cut into its two parts (``Engine.mc_infer_part``): ENTRY = staging, stem and entry flow --
+    vector-ALU / HBM-bound kernels at 2.0-2.3 GHz --, REST = middle and exit flow + MC head -- matrix-core kernels that run
+    against the chip's power management at 1.35-1.45 GHz.  ``EnginePool`` lets two streams drift; here the pairing is chosen:
+
+    * ``schedule='antiphase'``: two streams on disjoint halves of the chip, batch i on stream i % 2; a batch's ENTRY part does
+      not start before the previous batch's ENTRY part (other stream) has finished, so one half runs ENTRY while the other
+      runs REST for all but |REST - ENTRY| of a period.
+    * ``schedule='pipeline'``: one stream owns ``cus_entry`` compute units and runs every batch's ENTRY part, the other owns the
+      rest of the chip and runs every REST part (uneven splits: the two parts are not equally long); batch i uses engine
+      i % n_engines, whose workspace carries the entry flow's output from one stream to the other.
+    Results are those of ``mc_infer``, bit for bit, whatever the schedule (tests/test_gpu_parity.py)."""
+
+    def __init__(self, weights, schedule='antiphase', cus_entry=None, n_engines=2, size_grids=True, **kw):
+        if schedule not in ('antiphase', 'pipeline'):
+            raise ValueError(schedule)
+        self.schedule = schedule
+        self.engines = [Engine(weights, **kw) for _ in range(max(2, int(n_engines)))]
+        self.device = self.engines[0].device
+        self.hp = self.engines[0].hp
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        self.ncu = ncu
+        self.size_grids = bool(size_grids)
+        e0 = self.engines[0]
+        if schedule == 'antiphase':
+            self.cus = (ncu // 2, ncu - ncu // 2)
+            self.streams = [_mask_stream(e0, range(0, ncu // 2), ncu), _mask_stream(e0, range(ncu // 2, ncu), ncu)]
+            if self.size_grids:
+                for k, eng in enumerate(self.engines):
+                    eng.set_num_cus(self.cus[k % 2])
+        else:
+            ne = int(cus_entry or ncu // 2)
+            if not 8 <= ne <= ncu - 8:
+                raise ValueError(f'cus_entry must lie in [8, {ncu - 8}]')
+            self.cus = (ne, ncu - ne)
+            self.streams = [_mask_stream(e0, range(0, ne), ncu), _mask_stream(e0, range(ne, ncu), ncu)]
+        self._entry_done = None                         # antiphase: the previous batch's ENTRY part
+        self._rest_done = [None] * len(self.engines)    # pipeline: the last REST part on each engine's workspace
+
+    def __len__(self):
+        return 2
+
+    def step(self, i, tiles_u8, mc_n, seed, tile_idx0, out, after=None):
+        """Enqueue batch i: (mean, std) -> ``out``; ``after(engine)`` runs behind the REST part on its stream (the slide reduce).
+        ``tiles_u8`` and ``out`` must already be valid on the streams (resident inputs, pre-allocated outputs)."""
+        k = i % len(self.engines)
+        eng = self.engines[k]
+        if self.schedule == 'antiphase':
+            st = self.streams[k % 2]
+            if self._entry_done is not None:
+                st.wait_event(self._entry_done)
+            with torch.cuda.stream(st):
+                eng.mc_infer_part('entry', tiles_u8, mc_n, seed, tile_idx0=tile_idx0, out=out)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._entry_done = ev
+                eng.mc_infer_part('rest', tiles_u8, mc_n, seed, tile_idx0=tile_idx0, out=out)
+                if after is not None:
+                    after(eng)
+            return
+        se, sr = self.streams
+        if self._rest_done[k] is not None:
+            se.wait_event(self._rest_done[k])            # the workspace is free again
+        with torch.cuda.stream(se):
+            if self.size_grids:
+                eng.set_num_cus(self.cus[0])
+            eng.mc_infer_part('entry', tiles_u8, mc_n, seed, tile_idx0=tile_idx0, out=out)
+            ev = torch.cuda.Event()
+            ev.record(se)
+        sr.wait_event(ev)
+        with torch.cuda.stream(sr):
+            if self.size_grids:
+                eng.set_num_cus(self.cus[1])
+            eng.mc_infer_part('rest', tiles_u8, mc_n, seed, tile_idx0=tile_idx0, out=out)
+            if after is not None:
+                after(eng)
+            ev2 = torch.cuda.Event()
+            ev2.record(sr)
+            self._rest_done[k] = ev2
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def close(self):
+        self.synchronize()
+        for st in self.streams:
+            self.engines[0]._lib.bq_stream_destroy(self.engines[0]._ctx, C.c_void_p(st.cuda_stream))
+        self.streams = []
 
 
 class UncertaintyInterface:

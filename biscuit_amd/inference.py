@@ -66,11 +66,21 @@ class TFRecordSource:
         if self._fallback is None and tn.available():
             if self._reader is None:
                 self._reader = tn.NativeReader(self.path)
-            try:
-                self._reader.decode(first, count, self.tile_px, out=out, rows=self.rows)
-                return
-            except tn.UnsupportedImage:
-                pass
+                # ONE decoder per slide, decided before its first chunk: a record the native decoders refuse (a progressive
+                # JPEG, ...) sends the WHOLE slide to Pillow -- as the whole-slide loader does (Slide.load) -- instead of the chunks
+                # from that record on: the native islow IDCT and Pillow's libjpeg-turbo are not bound to agree to the last bit
+                if self._reader.probe(self.tile_px) is not None:
+                    self._reader.close()
+                    self._reader = None
+                    self._fallback = tfrecord.read_slide(self.path, self.tile_px, rows=self.rows)[1]
+            if self._reader is not None:
+                try:
+                    self._reader.decode(first, count, self.tile_px, out=out, rows=self.rows)
+                    return
+                except tn.UnsupportedImage:
+                    # behind a clean probe only a damaged entropy-coded stream ends here; chunks of this slide went out already
+                    if first > 0:
+                        raise
         if self._fallback is None:                      # Pillow (or the pure-Python reader), the whole slide once
             self._fallback = tfrecord.read_slide(self.path, self.tile_px, rows=self.rows)[1]
         out[...] = self._fallback[first:first + count]
@@ -167,23 +177,46 @@ PREFETCH_CHUNKS = 2      # decoded chunks waiting for the GPU (plus the one bein
 
 
 class _PinnedRing:
-    """RING_SLOTS reusable page-locked buffers (allocated once per process and size: page-locking 137 MB costs tens of
-    milliseconds, which round 3 paid per slide).  A slot is free again when the event recorded behind its last
-    host-to-device copy has completed."""
-    _cache = {}
+    """RING_SLOTS reusable page-locked buffers (page-locking 137 MB costs tens of milliseconds, which round 3 paid per slide).  A
+    slot is free again when the event recorded behind its last host-to-device copy has completed.  Rings are LEASED: one
+    ``evaluate`` call holds a ring from its first chunk to its last and hands it back, so calls that follow each other reuse the
+    same pinned memory and calls that overlap (two threads of one process) never share slots.  A ring is sized for the larger
+    of the two chunk layouts of its tile size -- decoded tiles (px * px * 3 bytes) and filtered PNG scanlines (px * (1 + 3 px))
+    -- so alternating the two modes does not re-allocate it (round 4 did: one size in the cache at a time)."""
+    _idle = []                       # rings not leased at the moment
+    _lock = None
+    MAX_IDLE = 2
 
     def __init__(self, nbytes):
-        self.bufs = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(RING_SLOTS)]
+        self.nbytes = int(nbytes)
+        self.bufs = [torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=True) for _ in range(RING_SLOTS)]
         self.events = [None] * RING_SLOTS
         self.next = 0
 
+    @staticmethod
+    def chunk_bytes(tile_px):
+        return CHUNK_TILES * tile_px * (1 + 3 * tile_px)
+
     @classmethod
-    def get(cls, nbytes):
-        r = cls._cache.get(nbytes)
-        if r is None:
-            cls._cache.clear()                       # one size at a time: a new tile size replaces the old buffers
-            r = cls._cache[nbytes] = cls(nbytes)
-        return r
+    def lease(cls, nbytes):
+        import threading
+        if cls._lock is None:
+            cls._lock = threading.Lock()
+        with cls._lock:
+            for i, r in enumerate(cls._idle):
+                if r.nbytes >= nbytes:
+                    return cls._idle.pop(i)
+            cls._idle.clear()                        # (a larger tile size: the smaller buffers go)
+        return cls(nbytes)
+
+    def release(self):
+        for i, ev in enumerate(self.events):
+            if ev is not None:
+                ev.synchronize()
+                self.events[i] = None
+        with self._lock:
+            if len(self._idle) < self.MAX_IDLE:
+                self._idle.append(self)
 
     def acquire(self):
         i = self.next
@@ -215,6 +248,7 @@ def _feed_chunks(slides, mine, dev, copy_stream):
         return False
 
     def work():
+        ring = None
         try:
             for li, si in enumerate(mine):
                 s = slides[si]
@@ -237,7 +271,12 @@ def _feed_chunks(slides, mine, dev, copy_stream):
                         return
                     continue
                 per = int(np.prod(src.chunk_shape(1)))
-                ring = _PinnedRing.get(CHUNK_TILES * per)
+                px = getattr(src, 'tile_px', None)
+                need = max(CHUNK_TILES * per, _PinnedRing.chunk_bytes(px) if px else 0)
+                if ring is None or ring.nbytes < need:
+                    if ring is not None:
+                        ring.release()
+                    ring = _PinnedRing.lease(need)
                 try:
                     for first in range(0, s.n_tiles, CHUNK_TILES):
                         cnt = min(CHUNK_TILES, s.n_tiles - first)
@@ -257,6 +296,9 @@ def _feed_chunks(slides, mine, dev, copy_stream):
             put(None)
         except BaseException as e:                   # noqa: BLE001 -- re-raised in the consumer
             put(e)
+        finally:
+            if ring is not None:
+                ring.release()
 
     th = threading.Thread(target=work, name='bq-tile-feeder', daemon=True)
     th.start()
@@ -335,8 +377,10 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                     eng.mc_infer(cur, mc_n, seed, tile_idx0=int(cg[0]), mc_mode=mc_mode, out=(mean, std))
                 elif mc_mode == 'head':
                     # a batch that spans slides: the backbone does not care (one launch sequence for the whole
-                    # batch), only the head's Philox counter does -- one head call per run of consecutive indices
-                    feat = eng.backbone(eng.stage(cur))
+                    # batch), only the head's Philox counter does -- one head call per run of consecutive indices.
+                    # bq_backbone_u8 = the kernels mc_infer runs (16-bit: the fused front kernel), so a tile's result
+                    # does not depend on which branch its batch took, i.e. on batch size, sharding or rank count
+                    feat = eng.backbone_u8(cur)
                     for a, b in zip(starts, ends):
                         eng.mc_head(feat[a:b], mc_n, seed, tile_idx0=int(cg[a]), out=(mean[a:b], std[a:b]))
                 else:

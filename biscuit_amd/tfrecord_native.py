@@ -29,6 +29,7 @@ ABI = {
     'bqio_image_bytes': (_i, [_vp, _i64, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]),
     'bqio_decode': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
     'bqio_decode_rows': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
+    'bqio_probe': (_i, [_vp, _i64, _i64, _i, C.POINTER(_i64)]),
     'bqio_masked_crc32c': (C.c_uint32, [C.c_char_p, C.c_size_t]),
     'bqio_inflate': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t]),
     'bqio_inflate2': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp, C.c_size_t,
@@ -111,11 +112,20 @@ class UnsupportedImage(ValueError):
 
 
 def default_threads():
+    """Decoder threads of one process: the cores it may use (its affinity mask, which ``distributed.pin_rank`` narrows to the
+    rank's share of the node, capped by the cgroup's CPU quota) -- no fixed ceiling: a 64-core share decodes on 64 threads, and
+    eight ranks on one node do not start 8 x 16 threads on the same cores."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, 16))
+    try:    # cgroup v2 quota
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 class NativeReader:
@@ -160,6 +170,16 @@ class NativeReader:
         if self._lib.bqio_image_bytes(self._h, index, C.byref(p), C.byref(n)) != 0:
             raise IOError(self._lib.bqio_last_error(self._h).decode())
         return C.string_at(p, n.value)
+
+    def probe(self, tile_px=299, first=0, count=None):
+        """None when ``decode`` would take records [first, first + count) as far as that shows without decoding (``bqio_probe``:
+        record framing, image signatures, the markers and scan structure of JPEG records); otherwise the index of the first
+        record it would refuse.  One pass over the bytes of the JPEG records, nothing for PNG records."""
+        total = len(self)
+        count = total - first if count is None else count
+        bad = _i64(-1)
+        e = self._lib.bqio_probe(self._h, first, count, tile_px, C.byref(bad))
+        return None if e == 0 else int(bad.value)
 
     def decode(self, first=0, count=None, tile_px=299, out=None, threads=None, rows=False):
         """-> (tiles uint8 [count,px,px,3], loc int64 [count,2]).  `out`: optional C-contiguous uint8

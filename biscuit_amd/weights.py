@@ -293,6 +293,93 @@ TAIL_RES_LAYERS = ('block2_res', 'block3_res')
 EXIT_LAYERS = ('block14_sepconv1', 'block14_sepconv2')
 
 
+# ---------------------------------------------------------------------------
+# activation exponents: keeping 16-bit storage in range by construction
+# ---------------------------------------------------------------------------
+# Between its weights the network is positively homogeneous: convolutions are linear, ReLU and max-pooling commute with a
+# positive factor, and a folded BatchNorm y = s * conv(x) + b turns "input stored as x / 2^kin, output wanted as y / 2^kout" into
+# s' = s * 2^(kin - kout), b' = b / 2^kout -- exact in fp32, no weight matrix touched, every mantissa the kernels produce
+# unchanged (a power of two moves exponents only).  So every STORED tensor can carry its own power-of-two exponent, chosen so
+# that it peaks well inside IEEE half's range, as long as tensors that meet in an addition share one: the two branches of a
+# block with a strided shortcut, and the whole residual stream of the middle flow (blocks 4 .. 12: the identity shortcut is
+# added as stored).  The pooled features come back to true scale in the pooling epilogue ("act/feat_mul" = 2^k).
+def tensor_plan():
+    """[(layer, input tensor, output tensor)] over the stored tensors of the backbone; tensors that share an exponent share a
+    name (``block{2,3,4,13}_out``: main branch, shortcut and sum; ``block4_out``: the residual stream through block 12)."""
+    plan = [('block1_conv1', None, 'block1_conv1'), ('block1_conv2', 'block1_conv1', 'block1_conv2')]
+    x = 'block1_conv2'
+    for b in (2, 3, 4):
+        plan += [(f'block{b}_sepconv1', x, f'block{b}_sepconv1'), (f'block{b}_sepconv2', f'block{b}_sepconv1', f'block{b}_out'),
+                 (f'block{b}_res', x, f'block{b}_out')]
+        x = f'block{b}_out'
+    for b in range(5, 13):
+        plan += [(f'block{b}_sepconv1', x, f'block{b}_sepconv1'), (f'block{b}_sepconv2', f'block{b}_sepconv1', f'block{b}_sepconv2'),
+                 (f'block{b}_sepconv3', f'block{b}_sepconv2', x)]
+    plan += [('block13_sepconv1', x, 'block13_sepconv1'), ('block13_sepconv2', 'block13_sepconv1', 'block13_out'),
+             ('block13_res', x, 'block13_out'),
+             ('block14_sepconv1', 'block13_out', 'block14_sepconv1'), ('block14_sepconv2', 'block14_sepconv1', 'block14_sepconv2')]
+    return plan
+
+
+FEATURE_TENSOR = 'block14_sepconv2'      # what the global average pool reads
+
+
+def tensor_taps():
+    """{exponent-sharing tensor name: [debug-tap names whose stored values carry that exponent]} (bq_debug_activation)."""
+    taps = {}
+    for layer, _, out in tensor_plan():
+        taps.setdefault(out, []).append(layer)
+    for b in (2, 3, 4, 13):
+        taps[f'block{b}_out'].append(f'block{b}_out')
+    taps['block4_out'] += [f'block{b}_out' for b in range(5, 13)]
+    # (a sepconv3 output only exists as the sum with the stream: its tap name is the block's output)
+    taps['block4_out'] = [t for t in taps['block4_out'] if not t.endswith('_sepconv3')]
+    return taps
+
+
+def depthwise_gain(w, layer):
+    """max over channels of the l1 norm of ``layer``'s 3x3 depthwise taps: |dw(x)| <= gain * max|x|, the bound on the
+    depthwise result every fused kernel rounds to the storage type before the pointwise product."""
+    k = w.get(layer + '/depthwise_kernel')
+    return 1.0 if k is None else float(np.abs(np.asarray(k, np.float64)).reshape(9, -1).sum(0).max())
+
+
+def choose_act_exponents(w, peaks, target_log2=12):
+    """Power-of-two exponents {tensor: k >= 0} from measured peaks {tensor: max |value|, true scale} (``Engine.calibrate``):
+    the smallest k with peak / 2^k <= 2^target_log2, where a tensor's peak includes the depthwise results of the separable
+    convolutions that read it (``depthwise_gain``).  2^12 leaves a factor 16 to IEEE half's 65504 for tiles unlike the
+    calibration batch.  Tensors never scale UP: a network that fits as it is keeps exponent 0 everywhere and packs to the
+    same blob as without exponents."""
+    need = {}
+    for layer, tin, tout in tensor_plan():
+        need[tout] = max(need.get(tout, 0.0), float(peaks.get(tout, 0.0)))
+        if tin is not None:
+            need[tin] = max(need.get(tin, 0.0), float(peaks.get(tin, 0.0)) * depthwise_gain(w, layer))
+    lim = 2.0 ** target_log2
+    return {t: (0 if p <= lim else int(np.ceil(np.log2(p / lim)))) for t, p in need.items()}
+
+
+def equivalent_rescaled(w, factor):
+    """The same classifier with every stored backbone tensor but the last ``factor`` times larger (any positive real), the way
+    a trained network comes to large activations: the weights keep their size, the BatchNorm statistics grow.  A layer whose
+    input tensor carries the factor gets moving_mean * f and moving_variance -> f^2 (var + eps) - eps (so that sqrt(var' + eps)
+    = f sqrt(var + eps)); a layer whose output tensor carries it gets gamma * f and beta * f; the tensor the global pool reads
+    stays at true scale, so the head is untouched.  In real arithmetic the function is unchanged; in IEEE-half storage the
+    activations now overflow -- the test vehicle for the activation exponents, and a statement of the homogeneity they rest on."""
+    f = np.float64(factor)
+    out = {k: np.array(v, np.float32, copy=True) for k, v in w.items()}
+    for layer, tin, tout in tensor_plan():
+        bn = layer + '_bn'
+        if tin is not None:             # (every tensor a layer reads is scaled: only the network's input is not)
+            out[bn + '/moving_mean'] = (out[bn + '/moving_mean'].astype(np.float64) * f).astype(np.float32)
+            var = out[bn + '/moving_variance'].astype(np.float64)
+            out[bn + '/moving_variance'] = (f * f * (var + BN_EPS) - BN_EPS).astype(np.float32)
+        if tout != FEATURE_TENSOR:
+            out[bn + '/gamma'] = (out[bn + '/gamma'].astype(np.float64) * f).astype(np.float32)
+            out[bn + '/beta'] = (out[bn + '/beta'].astype(np.float64) * f).astype(np.float32)
+    return out
+
+
 def fold_bn(w, name):
     s = w[name + '/gamma'] / np.sqrt(w[name + '/moving_variance'] + np.float32(BN_EPS))
     b = w[name + '/beta'] - w[name + '/moving_mean'] * s
@@ -305,9 +392,25 @@ def _padvec(v, n):
     return out
 
 
-def pack_blob(w, dtype='bf16'):
-    """Fold BN and serialise every tensor the device needs into one BQW1 blob."""
+def pack_blob(w, dtype='bf16', act_exp=None):
+    """Fold BN and serialise every tensor the device needs into one BQW1 blob.  ``act_exp``: {tensor: k} activation
+    exponents (``choose_act_exponents``): the stored tensor is the network's divided by 2^k; missing tensors and None: 0."""
     assert dtype in DTYPE_CODE
+    act_exp = {t: int(k) for t, k in (act_exp or {}).items() if int(k) != 0}
+    io = {layer: (tin, tout) for layer, tin, tout in tensor_plan()}
+    unknown = set(act_exp) - {t for _, _, t in tensor_plan()}
+    if unknown:
+        raise ValueError(f'activation exponents for unknown tensors: {sorted(unknown)}')
+
+    def fold(layer):
+        """folded BN of ``layer`` with the exponents of the tensors it reads and writes applied (exact: powers of two)"""
+        s, b = fold_bn(w, layer + '_bn')
+        tin, tout = io[layer]
+        kin, kout = act_exp.get(tin, 0), act_exp.get(tout, 0)
+        if kin or kout:
+            s = np.ldexp(s, kin - kout).astype(np.float32)
+            b = np.ldexp(b, -kout).astype(np.float32)
+        return s, b
     half = dtype != 'f32'                       # a 16-bit matrix-core type
     vec = 8 if half else 4
     to_bits = {'bf16': f32_to_bf16_bits, 'f16': f32_to_f16_bits}.get(dtype)
@@ -327,7 +430,7 @@ def pack_blob(w, dtype='bf16'):
 
     # stem conv1 on the vector ALU: fp32 [27][32], k = (dy*3+dx)*3 + c
     add('block1_conv1/w', w['block1_conv1/kernel'].reshape(27, 32))
-    s, b = fold_bn(w, 'block1_conv1_bn')
+    s, b = fold('block1_conv1')
     add_affine('block1_conv1', s, b, 32)
     if half:
         # kernels_front.hip (round 4): the same weights for the matrix cores -- 16x16x32 fragment order, K = 27 padded to 32,
@@ -338,7 +441,7 @@ def pack_blob(w, dtype='bf16'):
     npad = add_mat('block1_conv2', w['block1_conv2/kernel'].reshape(288, 64), 288)
     if half:   # ... and in 16x16x32 fragment order, one k-step per tap (kernels_front.hip)
         add('block1_conv2/wp16', to_bits(pack_fragments16(w['block1_conv2/kernel'].reshape(288, 64), 288, 64)))
-    s, b = fold_bn(w, 'block1_conv2_bn')
+    s, b = fold('block1_conv2')
     add_affine('block1_conv2', s, b, npad)
     for name, cin, cout in residual_plan():
         npad = add_mat(name, w[name + '_conv/kernel'].reshape(cin, cout), pad_channels(cin))
@@ -348,7 +451,7 @@ def pack_blob(w, dtype='bf16'):
                                                                   pad_channels(cin), npad)))
         if half and name in TAIL_RES_LAYERS:          # kernels_stream.hip: the shortcut inside the fused block tail
             add(name + '/wp16', to_bits(pack_fragments16(w[name + '_conv/kernel'].reshape(cin, cout), pad_channels(cin), npad)))
-        s, b = fold_bn(w, name + '_bn')
+        s, b = fold(name)
         add_affine(name, s, b, npad)
     wide = set(wide_layers())
     for name, cin, cout in sepconv_plan():
@@ -359,8 +462,11 @@ def pack_blob(w, dtype='bf16'):
         npad = add_mat(name, w[name + '/pointwise_kernel'].reshape(cin, cout), cp)
         if half and (name in wide or name in STREAM_LAYERS or name in EXIT_LAYERS) and cp % 32 == 0:
             add(name + '/wp16', to_bits(pack_fragments16(w[name + '/pointwise_kernel'].reshape(cin, cout), cp, npad)))
-        s, b = fold_bn(w, name + '_bn')
+        s, b = fold(name)
         add_affine(name, s, b, npad)
+    if act_exp.get(FEATURE_TENSOR, 0):
+        # the pooled features return to true scale in the pooling epilogue: means * 2^k (c->feat_mul)
+        add('act/feat_mul', np.array([2.0 ** act_exp[FEATURE_TENSOR]], np.float32))
     # The head keeps fp32 ACCURACY regardless of the backbone dtype (MC std ~1e-2 must not be quantisation noise), at the
     # 16-bit matrix rate: every weight is split into two IEEE halves, w = hi + lo / 2^11 (22 significand bits; the scale
     # keeps lo out of the subnormals), both in 32x32x16 fragment order (kernels_head.hip multiplies three of the four

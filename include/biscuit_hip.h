@@ -84,6 +84,10 @@ int bq_stage(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, void* d_out_nchw,
  * interleaving workgroups on every CU.  No reference counterpart (scheduling only). */
 int bq_stream_create_masked(bq_ctx* ctx, const uint32_t* cu_mask, int mask_words, bq_stream_t* out_stream);
 int bq_stream_destroy(bq_ctx* ctx, bq_stream_t stream);
+/* Number of compute units the persistent kernels of this context size their grids for (default: all of the device's; 0 restores
+ * that).  A context whose launches go to a CU-masked stream sets it to the CUs of the mask: a grid sized for the whole chip runs
+ * there as two rounds of workgroups, each with its own prologue.  Results do not depend on it. */
+int bq_set_num_cus(bq_ctx* ctx, int n);
 
 /* K0, optional front half: the `reinhard_fast` stain normaliser hp.py:19 selects, applied to the
  * uint8 tile before the standardisation exactly where results.py:251-252 calls
@@ -113,6 +117,13 @@ int bq_stage_f32(bq_ctx* ctx, const float* d_tiles_nhwc_f32, int n, void* d_out_
 int bq_backbone(bq_ctx* ctx, const void* d_in_nchw, int n, float* d_feat2048, void* d_ws,
                 size_t ws_bytes, bq_stream_t stream);
 
+/* K0-K5 straight from the bytes: uint8 NHWC tiles -> [n,2048] features through the kernels bq_mc_infer runs (16-bit contexts:
+ * standardisation + block1_conv1 + block1_conv2 fused into one launch; fp32 contexts: bq_stage + bq_backbone).  For callers
+ * that need the features of a batch before they decide how to drive the head -- biscuit_amd.inference.evaluate on a batch whose
+ * Philox tile indices are not one consecutive run: a tile's result is then the same whichever entry its batch took. */
+int bq_backbone_u8(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, float* d_feat2048, void* d_ws,
+                   size_t ws_bytes, bq_stream_t stream);
+
 /* K6: mc_n stochastic passes of the dropout head over n feature rows, Welford-folded
  * on the device.  Dropout masks are Philox4x32-10 keyed by `seed` with counter
  * (unit/4, layer, pass, tile_idx0 + row): independent of batching.
@@ -136,6 +147,14 @@ int bq_set_tile_index_ptr(bq_ctx* ctx, const int64_t* d_tile_idx0);
 int bq_mc_infer(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, int64_t tile_idx0,
                 int mc_n, uint64_t seed, int mc_mode, float* d_mean2, float* d_std2,
                 void* d_ws, size_t ws_bytes, bq_stream_t stream);
+
+/* bq_mc_infer (BQ_MC_HEAD) in two parts, for a caller that schedules two batches in flight against each other: ENTRY = staging,
+ * stem and entry flow (blocks 1-4; vector-ALU / HBM-bound kernels), whose output stays in the workspace; REST = middle and
+ * exit flow + the MC head (matrix-core bound).  ENTRY then REST on one workspace = bq_mc_infer, bit for bit; d_tiles is not
+ * read by REST, d_mean2 / d_std2 not written by ENTRY.  No reference counterpart (scheduling only). */
+enum { BQ_PART_ENTRY = 1, BQ_PART_REST = 2, BQ_PART_ALL = 3 };
+int bq_mc_infer_part(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, int64_t tile_idx0, int mc_n, uint64_t seed, int part,
+                     float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes, bq_stream_t stream);
 
 /* K7: per-slide sums of y_pred (= mean of P(class 1)) and uncertainty (= std of
  * P(class 1)) plus tile counts, restricted to tiles with uncertainty < tile_uq when
@@ -179,7 +198,9 @@ int bq_profile_read(bq_ctx* ctx, bq_prof_entry* out, int max_entries);
 
 /* Test hook: run the backbone on staged tiles up to and including the named layer
  * ("staged", "block1_conv1", "block1_conv2", "block{2,3,4}_{res,sepconv1,sepconv2,out}",
- * "block{5..13}_out", "block14_sepconv{1,2}") and copy that activation as fp32 NHWC
+ * "block{5..12}_sepconv{1,2}", "block{5..13}_out", "block13_{res,sepconv1,sepconv2}", "block14_sepconv{1,2}") and copy that
+ * activation -- as STORED: with activation exponents in the blob (weights.py: pack_blob(act_exp=...)) 2^-k times the network's
+ * value -- as fp32 NHWC
  * [n,H,W,C] (true channel count, padding stripped) into d_out.  Returns the number of
  * elements written, or <0. */
 int64_t bq_debug_activation(bq_ctx* ctx, const char* name, const void* d_in_nchw, int n,

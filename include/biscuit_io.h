@@ -65,6 +65,13 @@ int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8
 int bqio_decode_rows(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out_rows, int64_t* loc,
                      int n_threads, int64_t* bad_index);
 
+/* Would bqio_decode take records [first, first + count)?  Checks what can be checked without decoding: every record parses,
+ * every image is a PNG or a JPEG whose markers and scan structure the baseline decoder accepts (one pass over the bytes of the
+ * JPEG records; PNG records are not looked into -- PNG is lossless, any decoder gives the same pixels).  A caller that falls
+ * back to another JPEG decoder for what this library refuses can so decide ONCE per slide, before the first chunk, and never
+ * mixes two decoders' IDCTs inside a slide.  BQIO_OK, or the error bqio_decode would report, *bad_index = the record. */
+int bqio_probe(bqio_reader* r, int64_t first, int64_t count, int tile_px, int64_t* bad_index);
+
 /* One JPEG file (as bqio_image_bytes returns it) -> out[tile_px][tile_px][3], the decoder
  * bqio_decode uses, exported for tests.  BQIO_OK / BQIO_ERR_UNSUPPORTED / BQIO_ERR_FORMAT. */
 int bqio_decode_jpeg(const uint8_t* data, size_t len, int tile_px, uint8_t* out);

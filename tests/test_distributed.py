@@ -40,6 +40,9 @@ class StandInEngine:
     def backbone(self, staged):
         return staged.reshape(staged.shape[0], -1).double().mean(1, keepdim=True) / 255.0     # the "features"
 
+    def backbone_u8(self, tiles):        # (Engine.backbone_u8: the kernels mc_infer runs, straight from the bytes)
+        return self.backbone(self.stage(tiles))
+
     def mc_head(self, feat, mc_n, seed, tile_idx0=0, out=None):
         n = feat.shape[0]
         g = torch.arange(tile_idx0, tile_idx0 + n, dtype=torch.float64)
@@ -258,3 +261,59 @@ def test_partition_keeps_lpt_loads_and_hands_out_ties_in_order():
                 owners = [r for r in range(world) for i in parts[r] if counts[i] == c]
                 ids = [i for r in range(world) for i in parts[r] if counts[i] == c]
                 assert ids == sorted(ids) and owners == sorted(owners)
+
+
+# ---- the launcher of `bench.py --gpus N` and the host resource plan of N ranks on one node (no GPU involved) ----------------------
+def _bench(*argv, timeout=180):
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), *argv], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=timeout)
+    return p.returncode, p.stdout, p.stderr, time.time() - t0
+
+
+def test_launcher_eight_ranks_rendezvous_and_relay_rank0():
+    rc, out, err, _ = _bench('--gpus', '8', '--selftest-exit', 'none')
+    assert rc == 0, err[-2000:]
+    assert '"selftest": "ok"' in out and '"world": 8' in out
+
+
+def test_launcher_returns_within_seconds_when_a_rank_dies_before_the_rendezvous():
+    """Rank 5 of 8 exits with code 7 before it joins: the other seven sit in the rendezvous (process-group timeout: 120 s; NCCL's
+    default: ten minutes).  The parent polls all children, stops the rest and reports the code -- the 8-GPU command the driver runs
+    cannot hang on a dead rank."""
+    rc, out, err, dt = _bench('--gpus', '8', '--selftest-exit', '5:7')
+    assert rc == 7 and dt < 60, (rc, dt, err[-2000:])
+    assert 'exited with code 7' in err
+
+
+def test_rank_cores_partition_the_node():
+    # eight ranks, 128 allowed cores, no NUMA information: eight disjoint contiguous slices of 16
+    parts = [D.rank_cores(r, 8, allowed=range(128)) for r in range(8)]
+    assert [len(p) for p in parts] == [16] * 8 and sorted(sum(parts, [])) == list(range(128))
+    # two NUMA nodes of 64 cores, four GPUs on each: rank 5 is the second of the four ranks next to node 1
+    near = D.rank_cores(5, 8, allowed=range(128), numa_cpus=range(64, 128), numa_peers=(1, 4))
+    assert near == list(range(80, 96))
+    # a cgroup that left this process fewer cores than ranks: still never empty, never outside the mask
+    few = [D.rank_cores(r, 8, allowed=[3, 9, 11]) for r in range(8)]
+    assert all(len(p) == 1 and p[0] in (3, 9, 11) for p in few)
+    # the NUMA node's cores are not in the mask: fall back to the whole mask
+    assert D.rank_cores(1, 2, allowed=range(8), numa_cpus=range(64, 128), numa_peers=(0, 1)) == [4, 5, 6, 7]
+    assert D._cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_decoder_threads_follow_the_affinity_mask():
+    from biscuit_amd import tfrecord_native as tn
+    if not hasattr(os, 'sched_setaffinity'):
+        pytest.skip('no sched_setaffinity')
+    before = os.sched_getaffinity(0)
+    try:
+        os.sched_setaffinity(0, sorted(before)[:2])
+        assert tn.default_threads() == min(2, len(before))
+    finally:
+        os.sched_setaffinity(0, before)
+    assert tn.default_threads() >= 1

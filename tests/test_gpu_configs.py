@@ -38,22 +38,30 @@ def _free_port():
 
 
 # ------------------------------------------------------------------------------------------------ config 3
-def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
+# [9, 4, 0, 7, 5, 3] partitions into contiguous runs of slides; [9, 3, 7, 4, 5] does not (rank 0 gets slides 0 and 3, rank 1
+# slides 1, 2 and 4): rank 0's second batch is tile 8 of slide 0 + the four tiles of slide 3, two runs of Philox tile indices --
+# evaluate()'s multi-run branch (features once through bq_backbone_u8, one head call per run), which in an f16 / bf16 context
+# must run the same fused front kernel as bq_mc_infer does for the single-run batches of the one-rank reference
+@pytest.mark.parametrize('counts,dtype', [([9, 4, 0, 7, 5, 3], 'bf16'), ([9, 3, 7, 4, 5], 'f16'), ([9, 3, 7, 4, 5], 'bf16')])
+def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, counts, dtype):
     from _rank_worker import build_slides
+    from biscuit_amd import distributed as D
     from biscuit_amd.engine import Engine
     from biscuit_amd.inference import evaluate
-    counts = [9, 4, 0, 7, 5, 3]
     mc_n, batch = 6, 8
+    if len(counts) == 5:
+        parts = D.partition_slides(counts, 2)
+        assert parts == [[0, 3], [1, 2, 4]], parts          # the case exists: rank 0's slides are not neighbours
     out = str(tmp_path / 'res')
     port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_rank_worker.py'), out, 'bf16',
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_rank_worker.py'), out, dtype,
                                        str(mc_n), str(batch), ','.join(map(str, counts)), '0', 'gloo'], env=env, cwd=ROOT))
     assert [p.wait(timeout=600) for p in procs] == [0, 0]
-    eng = Engine(synthetic_weights(1), dtype='bf16', max_batch=batch, max_mc=mc_n)
+    eng = Engine(synthetic_weights(1), dtype=dtype, max_batch=batch, max_mc=mc_n)
     single = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch)
     r0, r1 = (np.load(f'{out}.rank{r}.npz') for r in range(2))
     # both ranks hold the whole gathered slide table, equal to the single-rank one bit for bit
@@ -415,6 +423,62 @@ def test_hard_weights_bf16_kernels_reported(hard):
     dm, ds, dsp, dsu = _hard_deltas(hard, 'bf16')
     print(f'hard weights, bf16 vs fp32 kernels: tile max|dmean|={dm:.3e} max|dstd|={ds:.3e}; slide pred {dsp:.3e} unc {dsu:.3e}')
     assert dm < BF16_HARD_TILE_BOUND and ds < BF16_HARD_TILE_BOUND and dsp < 3e-3 and dsu < 1e-3
+
+
+def test_f16_range_by_construction_with_activation_exponents():
+    """IEEE half ends at 65504 and the f16 kernels clamp there silently.  `equivalent_rescaled(w, 3e4)` is the stress classifier
+    with every stored tensor 30 000 times larger -- the same function in real arithmetic, raw activations up to ~1e6 --: without
+    activation exponents the f16 path saturates and its predictions are wrong; with the exponents `Engine.calibrate` measures on
+    eight tiles (fp32 kernels, powers of two folded into the BatchNorm constants, weights.py) it holds the north-star tolerance
+    of 1e-3 against the fp32 CPU oracle at tile and slide level.  Default weights calibrate to all-zero exponents and the blob
+    they always had; forced exponents on them change no result beyond the last place (a power of two only moves exponents)."""
+    from biscuit_amd.engine import Engine
+    from biscuit_amd.weights import equivalent_rescaled, pack_blob, tensor_plan
+    from oracle.xception_ref import XceptionOracle
+    base = synthetic_weights(3, hard=True)
+    big = equivalent_rescaled(base, 3.0e4)
+    tiles, sidx, _ = make_slides(2, 8, seed=41)
+    d, sl = dev(tiles), dev(sidx).long()
+    mc_n, seed = 30, 1234
+    rm, rs = XceptionOracle(base).mc_predict(tiles, mc_n, seed)                 # the function both weight sets compute
+    bm, bs = XceptionOracle(big).mc_predict(tiles[:4], mc_n, seed)
+    assert np.abs(bm - rm[:4]).max() < 2e-5 and np.abs(bs - rs[:4]).max() < 2e-5     # (the rescaling is an equivalence)
+
+    def deltas(m, s):
+        m, s = m.cpu().numpy(), s.cpu().numpy()
+        sm = lambda x: np.array([x[sidx == k].mean() for k in range(2)])
+        return (np.abs(m - rm).max(), np.abs(s - rs).max(), np.abs(sm(m[:, 1]) - sm(rm[:, 1])).max(),
+                np.abs(sm(s[:, 1]) - sm(rs[:, 1])).max())
+    # 1. as it is: clipped
+    e0 = Engine(big, dtype='f16', max_batch=16, max_mc=mc_n)
+    hr0 = e0.f16_headroom(d)
+    bad = deltas(*e0.mc_infer(d, mc_n, seed))
+    assert any(hr0['saturated'].values()) and max(bad) > 1e-2, (hr0['saturated'], bad)
+    e0.close()
+    # 2. exponents from a calibration batch
+    act_exp, peaks = Engine.calibrate(big, tiles[:8])
+    assert max(peaks.values()) > 3e5 and max(act_exp.values()) >= 5, (max(peaks.values()), act_exp)
+    e1 = Engine(big, dtype='f16', max_batch=16, max_mc=mc_n, act_exp=act_exp)
+    hr1 = e1.f16_headroom(d)
+    good = deltas(*e1.mc_infer(d, mc_n, seed))
+    print(f'weights x 3e4 (peak activation {max(peaks.values()):.3g}): f16 without exponents tile {bad[0]:.2e}; with {act_exp}: '
+          f'tile {good[0]:.2e} / {good[1]:.2e}, slide {good[2]:.2e} / {good[3]:.2e}, headroom {hr1["headroom"]:.1f}x')
+    assert not any(hr1['saturated'].values()) and hr1['headroom'] >= 8
+    assert max(good) < NORTH_STAR_TOL, good
+    # taps come back at true scale: the stored tensor times 2^k
+    k = act_exp['block4_out']
+    a = e1.debug_activation_u8('block8_out', d[:2].contiguous(), (19, 19, 728))
+    b = e1.debug_activation_u8('block8_out', d[:2].contiguous(), (19, 19, 728), true_scale=False)
+    assert k > 0 and torch.equal(a, b * float(2 ** k)) and float(b.abs().max()) <= 4096 * 4
+    e1.close()
+    # 3. weights that fit as they are: no exponents, the same blob; forced exponents: the same results
+    act0, _ = Engine.calibrate(base, tiles[:8])
+    assert not any(act0.values()) and pack_blob(base, 'f16', act0) == pack_blob(base, 'f16')
+    e2 = Engine(base, dtype='f16', max_batch=16, max_mc=mc_n)
+    e3 = Engine(base, dtype='f16', max_batch=16, max_mc=mc_n, act_exp={t: -2 for _, _, t in tensor_plan()})
+    (m2, s2), (m3, s3) = e2.mc_infer(d, mc_n, seed), e3.mc_infer(d, mc_n, seed)
+    assert float((m2 - m3).abs().max()) < 2e-6 and float((s2 - s3).abs().max()) < 2e-6
+    e2.close(); e3.close()
 
 
 NORTH_STAR_TOL = 1e-3

@@ -343,6 +343,27 @@ def test_full_mode_batching_and_determinism_bit_exact(engines, tiles, dtype):
     assert not torch.equal(m_o, m_h)                             # the seed matters
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
+def test_split_entry_points_equal_mc_infer_bit_for_bit(engines, tiles, dtype):
+    """bq_backbone_u8 + bq_mc_head, and bq_mc_infer_part ENTRY then REST, are bq_mc_infer cut in two: the same kernels on the same
+    workspace, so the same bits -- evaluate()'s multi-run batches and a phase-staggered schedule rest on that."""
+    eng = engines[dtype]
+    d = dev(tiles)
+    m, s = eng.mc_infer(d, 5, 31, tile_idx0=40)
+    m2, s2 = eng.mc_head(eng.backbone_u8(d), 5, 31, tile_idx0=40)
+    assert torch.equal(m2, m) and torch.equal(s2, s)
+    out = (torch.full_like(m, -1), torch.full_like(s, -1))
+    eng.mc_infer_part('entry', d, 5, 31, tile_idx0=40, out=out)
+    torch.cuda.synchronize()
+    assert float(out[0].max()) == -1.0                            # ENTRY writes no result
+    junk = torch.zeros_like(d)                                    # REST does not read the tiles
+    eng.mc_infer_part('rest', junk, 5, 31, tile_idx0=40, out=out)
+    assert torch.equal(out[0], m) and torch.equal(out[1], s)
+    out = (torch.empty_like(m), torch.empty_like(s))
+    eng.mc_infer_part('all', d, 5, 31, tile_idx0=40, out=out)
+    assert torch.equal(out[0], m) and torch.equal(out[1], s)
+
+
 @pytest.mark.parametrize('n', [1, 5])
 def test_ragged_batch_sizes(engines, oracles, n):
     """Batches that do not fill a pixel tile / a row fragment (n = 1: 361 pixels at 19x19) and odd n."""
@@ -526,6 +547,28 @@ def test_engine_pool_two_streams_bit_identical(weights):
         assert single.tile_df.equals(got.tile_df)
         assert np.array_equal(single.slide_pred, got.slide_pred, equal_nan=True)
         assert np.array_equal(single.slide_unc, got.slide_unc, equal_nan=True)
+    # the same with the persistent grids sized for each stream's share of the chip (bq_set_num_cus)
+    pool2 = EnginePool(weights, n_streams=2, dtype='bf16', max_batch=8, max_mc=8, size_grids=True)
+    got = evaluate(pool2, slides, mc_n=4, seed=3, batch=4)
+    assert single.tile_df.equals(got.tile_df)
+
+
+@pytest.mark.parametrize('schedule,cus_entry', [('antiphase', None), ('pipeline', 96), ('pipeline', 128)])
+def test_phased_pool_equals_mc_infer_bit_for_bit(weights, engines, schedule, cus_entry):
+    """Every batch cut into ENTRY and REST and the parts of consecutive batches scheduled against each other on CU-masked streams
+    (PhasedPool): the schedule, the split of the chip and the grid sizes change nothing in the results."""
+    from biscuit_amd.engine import PhasedPool
+    pp = PhasedPool(weights, schedule=schedule, cus_entry=cus_entry, dtype='f16', max_batch=6, max_mc=8)
+    batches = [dev(make_tiles(6, seed=300 + i)) for i in range(5)]
+    outs = [(torch.empty((6, 2), device='cuda'), torch.empty((6, 2), device='cuda')) for _ in batches]
+    torch.cuda.synchronize()
+    for i, t in enumerate(batches):
+        pp.step(i, t, 8, 17, 6 * i, outs[i])
+    pp.synchronize()
+    for i, t in enumerate(batches):
+        m, s = engines['f16'].mc_infer(t, 8, 17, tile_idx0=6 * i)
+        assert torch.equal(outs[i][0], m) and torch.equal(outs[i][1], s), (schedule, i)
+    pp.close()
 
 
 @pytest.mark.gpu

@@ -353,3 +353,71 @@ def test_tf_fixture_checker_accepts_a_well_formed_file_and_names_what_is_wrong_w
     assert any('activation' in b for b in mod.check_io(bad))
     # a directory with nothing in it: every file is named
     assert len([b for b in mod.check(str(tmp_path)) if b.startswith('missing file')]) == 4
+
+
+# ---- activation exponents (weights.py): the host side of the f16 range-by-construction scheme
+def test_tensor_plan_covers_every_layer_once_and_shares_exponents_where_tensors_meet():
+    from biscuit_amd import weights as W
+    plan = W.tensor_plan()
+    layers = [l for l, _, _ in plan]
+    want = ['block1_conv1', 'block1_conv2'] + [n for n, _, _ in W.sepconv_plan()] + [n for n, _, _ in W.residual_plan()]
+    assert sorted(layers) == sorted(want) and len(set(layers)) == len(layers)
+    io = {l: (i, o) for l, i, o in plan}
+    for b in (2, 3, 4, 13):                                   # both branches of a strided block end on one exponent
+        assert io[f'block{b}_sepconv2'][1] == io[f'block{b}_res'][1] == f'block{b}_out'
+        assert io[f'block{b}_sepconv1'][0] == io[f'block{b}_res'][0]
+    for b in range(5, 13):                                    # the identity shortcuts: one exponent for the whole stream
+        assert io[f'block{b}_sepconv1'][0] == io[f'block{b}_sepconv3'][1] == 'block4_out'
+    assert io['block13_sepconv1'][0] == io['block13_res'][0] == 'block4_out'
+    assert io['block14_sepconv2'][1] == W.FEATURE_TENSOR
+    taps = W.tensor_taps()
+    assert set(taps) == {o for _, _, o in plan} and 'block12_out' in taps['block4_out'] and 'block4_sepconv2' in taps['block4_out']
+
+
+def test_activation_exponents_fold_into_the_batchnorm_constants_exactly():
+    import struct
+    from biscuit_amd import weights as W
+    w = W.synthetic_weights(2, hard=True)
+
+    def entries(blob):
+        magic, ver, cnt, dt = struct.unpack('<4sIII', blob[:16])
+        out = {}
+        for i in range(cnt):
+            nm, off, ln = struct.unpack('<48sQQ', blob[16 + 64 * i:16 + 64 * (i + 1)])
+            out[nm.rstrip(b'\0').decode()] = blob[off:off + ln]
+        return out
+    a = entries(W.pack_blob(w, 'f16'))
+    exp = {'block1_conv2': 3, 'block2_sepconv1': 1, 'block2_out': 4, 'block4_out': 6, 'block7_sepconv2': 2, 'block14_sepconv2': 5}
+    b = entries(W.pack_blob(w, 'f16', exp))
+    assert set(b) == set(a) | {'act/feat_mul'} and np.frombuffer(b['act/feat_mul'], np.float32)[0] == 32.0
+    io = {l: (i, o) for l, i, o in W.tensor_plan()}
+    for layer, (tin, tout) in io.items():
+        kin, kout = exp.get(tin, 0), exp.get(tout, 0)
+        sa, sb = (np.frombuffer(x[layer + '/scale'], np.float32) for x in (a, b))
+        ba, bb = (np.frombuffer(x[layer + '/bias'], np.float32) for x in (a, b))
+        assert np.array_equal(sb, np.ldexp(sa, kin - kout)) and np.array_equal(bb, np.ldexp(ba, -kout)), layer
+    for name in a:                                            # nothing else moves: no weight matrix, no tap, no head tensor
+        if not name.endswith(('/scale', '/bias')) or name.startswith(('hidden', 'logits')):
+            assert a[name] == b[name], name
+    assert W.pack_blob(w, 'bf16') == W.pack_blob(w, 'bf16', {}) and W.pack_blob(w, 'f16', {t: 0 for t in exp}) == W.pack_blob(w, 'f16')
+    with pytest.raises(ValueError):
+        W.pack_blob(w, 'f16', {'block5_sepconv3': 1})        # not a stored tensor of its own: it only exists as the sum
+
+
+def test_choose_act_exponents_and_the_equivalent_rescaling():
+    from biscuit_amd import weights as W
+    from oracle.xception_ref import XceptionOracle
+    from biscuit_amd.synthetic import make_tiles
+    w = W.synthetic_weights(2, hard=True)
+    peaks = {t: 10.0 for _, _, t in W.tensor_plan()}
+    assert not any(W.choose_act_exponents(w, peaks).values())                  # fits: nothing to do
+    peaks['block4_out'] = 2.0e6
+    k = W.choose_act_exponents(w, peaks)
+    g = max(W.depthwise_gain(w, f'block{b}_sepconv1') for b in range(5, 14))
+    assert k['block4_out'] == int(np.ceil(np.log2(2.0e6 * g / 4096))) and sum(1 for v in k.values() if v) == 1
+    assert 2.0e6 * g / 2 ** k['block4_out'] <= 4096 < 2.0e6 * g / 2 ** (k['block4_out'] - 1)
+    # the rescaled classifier computes the same function (fp32 oracle, two tiles)
+    t = make_tiles(2, seed=9)
+    m0, s0 = XceptionOracle(w).mc_predict(t, 4, 11)
+    m1, s1 = XceptionOracle(W.equivalent_rescaled(w, 3.0e4)).mc_predict(t, 4, 11)
+    assert np.abs(m0 - m1).max() < 2e-5 and np.abs(s0 - s1).max() < 2e-5

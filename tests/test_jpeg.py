@@ -153,3 +153,32 @@ def test_jpeg_slide_through_the_reader(tmp_path):
     assert name == 'slide-j' and np.array_equal(got, want) and np.array_equal(loc, locs)
     _, py, _ = tfr.read_slide(path, native=False)
     assert np.array_equal(py, want)
+
+
+def test_one_decoder_per_slide_decided_before_the_first_chunk(tmp_path):
+    """A slide whose LAST record is a progressive JPEG: ``NativeReader.probe`` names it without decoding anything, and the chunk
+    source of ``evaluate`` sends the whole slide to the fallback decoder from chunk 0 on -- not the chunks from that record on, which
+    would mix two decoders' IDCTs inside one slide (and differ from the whole-slide loader)."""
+    from biscuit_amd.inference import TFRecordSource
+    imgs = [_photo(299, s) for s in range(6)]
+    raws = [_enc(a, quality=85) for a in imgs[:5]] + [_enc(imgs[5], quality=85, progressive=True)]
+    path = str(tmp_path / 'mixed.tfrecords')
+    tfr.write_slide(path, 'mixed', raws, np.zeros((6, 2), np.int64))
+    good = str(tmp_path / 'good.tfrecords')
+    tfr.write_slide(good, 'good', raws[:5], np.zeros((5, 2), np.int64))
+    with tn.NativeReader(path) as r:
+        assert r.probe(299) == 5 and r.probe(299, 0, 5) is None
+    with tn.NativeReader(good) as r:
+        assert r.probe(299) is None
+    want = np.stack([_pillow(x) for x in raws])
+    src = TFRecordSource(path, 6)
+    out = np.zeros((2, 299, 299, 3), np.uint8)
+    src.read(0, 2, out)                                 # the first chunk already comes from the fallback
+    assert src._reader is None and src._fallback is not None and np.array_equal(out, want[:2])
+    src.read(4, 2, out)
+    assert np.array_equal(out, want[4:6])
+    src.close()
+    src = TFRecordSource(good, 5)
+    src.read(0, 2, out)
+    assert src._reader is not None and src._fallback is None and np.array_equal(out, want[:2])
+    src.close()
