@@ -1,3 +1,8 @@
+// WHO STILL RUNS THIS FILE (round 5).  Nobody on the headline path: the 728-wide layers run on kernels_wide.hip.  run_conv falls
+// through to launch_sepconv_pipe when wide_supported() refuses a launch -- a blob without "<layer>/wp16", or more than 2^32 bytes of
+// activations per tensor (n x 361 x 736 x 2: batches beyond ~8 000 tiles) -- and the pipelined form fits (pipe_supported).  Round 1's
+// dominant kernel, kept as the correct fallback; same arithmetic order as the wide kernel.
+//
 // Software-pipelined SeparableConv2D kernel for the 728-wide layers (27 of the 34 separable
 // convolutions, ~80 % of the network's FLOPs), bf16.
 //

@@ -1,3 +1,8 @@
+// WHO STILL RUNS THIS FILE (round 5).  block_end (biscuit_hip.hip) comes here for block 2's end (shortcut K = 64) when the fused
+// block tail of kernels_stream.hip does not run: a debug tap of block2_sepconv2 / block2_res / the float entry's taps, a blob without
+// the "wp16" copies, or a tensor beyond the tail's 32-bit offsets.  Blocks 3, 4 and 13 (K >= 128) take gemm_tile_kernel<EPI_POOL>
+// (kernels_split.hip) in that case; on the headline path blocks 2 and 3 end inside the fused tails.
+//
 // End of an Xception block with a strided shortcut (blocks 2, 3, 4, 13), bf16, one kernel:
 //     out = MaxPool3x3/s2 'same' (y)  +  BN(Conv1x1/s2 'same' (x))
 // y = the block's second separable convolution (full resolution), x = the block's input (the 1x1 / stride 2 / 'same'

@@ -1,3 +1,12 @@
+// WHO STILL RUNS THIS FILE (round 5).  The headline path (bq_mc_infer / bq_backbone_u8 in a 16-bit context) does not: its front is
+// kernels_front.hip, block 2 and block3_sepconv1 are kernels_stream.hip.  run_conv (biscuit_hip.hip) comes here for
+//   * block1_conv2 (kind 0) on the float / planar entry: bq_backbone (UncertaintyInterface: standardised float tiles),
+//     bq_debug_activation, and a blob without "block1_conv1/w16" / "block1_conv2/wp16";
+//   * block2_sepconv1 / block2_sepconv2 (kinds 1, 2) and block3_sepconv1 (kind 3) only when the streaming kernel refuses the launch:
+//     a blob without "<layer>/wp16", or an output tensor beyond the 32-bit byte offsets of its raw buffer stores (n x H x W x C x 2
+//     >= 4 GiB: batches of several thousand tiles).
+// Kept bit-compatible with the streaming kernels (same tap order, same rounding points): tests/test_gpu_parity.py runs both entries.
+//
 // Persistent 2-D tile kernel for the big, HBM-bound entry-flow layers (block1_conv2 at 147x147,
 // the block2/block3 separable convolutions at 147x147 / 74x74), bf16.
 //

@@ -10,8 +10,10 @@ import numpy as np
 TILE_PX = 299
 
 
-def make_tiles(n_tiles, seed, slide_bias=None, px=TILE_PX):
-    """[n_tiles, px, px, 3] uint8 (NHWC, the TFRecord decode layout)."""
+def make_tiles(n_tiles, seed, slide_bias=None, px=TILE_PX, grain=18.0):
+    """[n_tiles, px, px, 3] uint8 (NHWC, the TFRecord decode layout).  ``grain``: standard deviation of the per-pixel noise -- 18
+    (the default of every fixture) makes a tile nearly incompressible (a 226 KB PNG: Sub / Up rows, the worst case for inflate), 4 a
+    photo-like one (smooth texture + sensor grain: a 155 KB PNG, Paeth / Average rows -- the size of a real H&E tile)."""
     rng = np.random.default_rng(seed)
     yy, xx = np.meshgrid(np.arange(px, dtype=np.float32), np.arange(px, dtype=np.float32),
                          indexing='ij')
@@ -24,7 +26,7 @@ def make_tiles(n_tiles, seed, slide_bias=None, px=TILE_PX):
             ph = rng.uniform(0, 2 * np.pi)
             amp = rng.uniform(10, 45, 3).astype(np.float32)
             img += np.cos(fx * xx + fy * yy + ph)[:, :, None] * amp
-        img += rng.normal(0, 18, (px, px, 3)).astype(np.float32)
+        img += rng.normal(0, grain, (px, px, 3)).astype(np.float32)
         img += 128 + bias + rng.normal(0, 12, 3).astype(np.float32)
         out[t] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
     return out

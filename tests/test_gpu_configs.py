@@ -471,13 +471,22 @@ def test_f16_range_by_construction_with_activation_exponents():
     b = e1.debug_activation_u8('block8_out', d[:2].contiguous(), (19, 19, 728), true_scale=False)
     assert k > 0 and torch.equal(a, b * float(2 ** k)) and float(b.abs().max()) <= 4096 * 4
     e1.close()
-    # 3. weights that fit as they are: no exponents, the same blob; forced exponents: the same results
+    # 3. weights that fit as they are: no exponents, the same blob.  Forced exponents on them: a power of two moves exponents only,
+    # so every NORMAL value keeps its mantissa; what differs is the handful of values in IEEE half's subnormal range (|x| < 6.1e-5:
+    # 42 of 2.8 M in block1_conv2), which the scaled-up run stores with more bits -- tools/dbg_exp.py shows the first differences
+    # there, then the one-ulp rounding flips they seed downstream.  The two runs agree like any two roundings of the network do:
+    # well inside the f16 mode's distance from fp32 (2-3e-4), nowhere near the tolerance.
     act0, _ = Engine.calibrate(base, tiles[:8])
     assert not any(act0.values()) and pack_blob(base, 'f16', act0) == pack_blob(base, 'f16')
     e2 = Engine(base, dtype='f16', max_batch=16, max_mc=mc_n)
     e3 = Engine(base, dtype='f16', max_batch=16, max_mc=mc_n, act_exp={t: -2 for _, _, t in tensor_plan()})
     (m2, s2), (m3, s3) = e2.mc_infer(d, mc_n, seed), e3.mc_infer(d, mc_n, seed)
-    assert float((m2 - m3).abs().max()) < 2e-6 and float((s2 - s3).abs().max()) < 2e-6
+    assert float((m2 - m3).abs().max()) < 3e-4 and float((s2 - s3).abs().max()) < 3e-4
+    assert max(deltas(m3, s3)) < NORTH_STAR_TOL
+    a2 = e2.debug_activation_u8('block1_conv2', d[:2].contiguous(), (147, 147, 64))
+    a3 = e3.debug_activation_u8('block1_conv2', d[:2].contiguous(), (147, 147, 64))
+    differ = a2 != a3
+    assert int(differ.sum()) < 1000 and (not bool(differ.any()) or float(a2.abs()[differ].max()) < 6.2e-5)   # subnormals only
     e2.close(); e3.close()
 
 

@@ -1,16 +1,13 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench, optional rocprof.  Logs -> gpurun_out/
-mkdir -p gpurun_out
-python - > gpurun_out/cpuinfo.log 2>&1 <<'PY'
-import os
-print('cpu_count', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))
-for f in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us', '/sys/fs/cgroup/cpu/cpu.cfs_period_us'):
-    try: print(f, open(f).read().strip())
-    except OSError as e: print(f, 'n/a')
-PY
-( timeout 1200 python -m pytest tests -m gpu -x -q -s 2>&1 | grep -v amdgpu.ids | tail -30 ) > gpurun_out/pytest_gpu.log
-grep -q "passed" gpurun_out/pytest_gpu.log && ! grep -q "failed" gpurun_out/pytest_gpu.log || { cat gpurun_out/pytest_gpu.log | cut -c1-300; echo "PYTEST FAILED - stopping"; exit 1; }
-( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4 ) > gpurun_out/smoke.log
-( timeout 600 python bench.py 2>gpurun_out/bench.err | tail -1 ) > gpurun_out/bench.json
-if [ "$1" == "prof" ]; then bash tools/profile.sh ${2:-r01} > gpurun_out/profile.log 2>&1; fi
-cat gpurun_out/cpuinfo.log; tail -5 gpurun_out/pytest_gpu.log; cat gpurun_out/smoke.log; cut -c1-1200 gpurun_out/bench.json; tail -2 gpurun_out/bench.err | cut -c1-300
+# A round's evidence run on the GPU box (bash tools/gpu_round.sh r05): tests, the default bench, config 3's per-GPU share, the MC
+# sweep, rocprofv3 passes (tools/profile.sh), SQ counters (tools/pmc_sq.sh); tools/collect.sh copies the results into profiles/.
+T=${1:-r05}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out
+cd $R
+python -m pytest tests -m gpu -q 2>&1 | tee gpurun_out/pytest_gpu.log | tail -4
+python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err; tail -c 300 gpurun_out/${T}_bench.err
+python bench.py --workload cfg3 --gpus 1 --slides 200 --no-extras --no-cpu-baseline --no-profile > gpurun_out/${T}_bench_cfg3_share.json 2> gpurun_out/${T}_bench_cfg3.err; tail -c 300 gpurun_out/${T}_bench_cfg3.err
+python tools/sweep_mc.py > gpurun_out/${T}_sweep_mc.jsonl 2>/dev/null
+bash tools/profile.sh $T f16 > gpurun_out/profile_${T}.log 2>&1; tail -3 gpurun_out/profile_${T}.log
+bash tools/pmc_sq.sh > gpurun_out/pmc_sq_${T}.log 2>&1; tail -2 gpurun_out/pmc_sq_${T}.log
