@@ -38,9 +38,13 @@ ABI = {
     'bq_stage': (_i, [_vp, _vp, _i, _vp, _vp]),
     'bq_stage_f32': (_i, [_vp, _vp, _i, _vp, _vp]),
     'bq_png_unfilter': (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    'bq_png_inflate_scratch_bytes': (_sz, [_i]),
+    'bq_png_inflate': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp, _vp]),
+    'bq_png_unfilter_strided': (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     'bq_stream_create_masked': (_i, [_vp, C.POINTER(C.c_uint32), _i, C.POINTER(_vp)]),
     'bq_stream_destroy': (_i, [_vp, _vp]),
     'bq_set_num_cus': (_i, [_vp, _i]),
+    'bq_set_option': (_i, [_vp, C.c_char_p, _i]),
     'bq_stain_reinhard_fast': (_i, [_vp, _vp, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp, _vp]),
     'bq_stain_lab_stats': (_i, [_vp, _vp, _i, _vp, _vp]),
     'bq_backbone': (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),

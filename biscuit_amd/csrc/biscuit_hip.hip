@@ -54,6 +54,7 @@ struct bq_ctx {
     int num_cus = 256;
     float* d_srgb_lut = nullptr;   // tables of the Reinhard normaliser
     const long long* d_tile0 = nullptr;   // bq_set_tile_index_ptr
+    int inflate_variant = 0;       // bq_set_option("inflate_variant"): 0 = tables in global memory, 1 = direct tables mirrored in LDS
     float feat_mul = 1.f;          // "act/feat_mul" of the blob: 2^k of the pooled tensor's activation exponent (weights.py: pack_blob)
     double* d_stage_stats = nullptr;   // 2 x 64-bit integer sums per tile for the staging kernel pair
     // profiling
@@ -911,6 +912,28 @@ int bq_png_unfilter(bq_ctx* c, const uint8_t* d_rows, int n, int px, uint8_t* d_
     return BQ_OK;
 }
 
+size_t bq_png_inflate_scratch_bytes(int n) { return inflate_scratch_bytes(n); }
+
+int bq_png_inflate(bq_ctx* c, const uint8_t* d_z, const uint32_t* d_off, const uint32_t* d_len, int n, int px, uint8_t* d_rows,
+                   size_t rows_stride, void* d_scratch, size_t scratch_bytes, int32_t* d_status, bq_stream_t stream) {
+    if (!c || !d_z || !d_off || !d_len || !d_rows || !d_scratch || !d_status || n < 0 || px <= 0 || px > 4096)
+        return fail(c, BQ_ERR_ARG, "bq_png_inflate: bad argument");
+    const size_t row_bytes = (size_t)px * (3 * (size_t)px + 1);
+    if (rows_stride < row_bytes + 4 || (rows_stride & 3) || rows_stride > 0xffffffffull) return fail(c, BQ_ERR_ARG, "bq_png_inflate: rows_stride must be a multiple of 4, >= px (1 + 3 px) + 4");
+    if (scratch_bytes < inflate_scratch_bytes(n)) return fail(c, BQ_ERR_WORKSPACE, "bq_png_inflate: scratch too small");
+    ProfScope ps(c, (hipStream_t)stream, "png_inflate", 0.0, (double)n * row_bytes * 2.0);
+    const int e = launch_inflate(d_z, d_off, d_len, n, d_rows, (unsigned)row_bytes, (unsigned)rows_stride, d_scratch, d_status, (hipStream_t)stream,
+                                 c->inflate_variant);
+    if (e) return fail(c, BQ_ERR_HIP, std::string("png inflate launch: ") + hipGetErrorString((hipError_t)e));
+    return BQ_OK;
+}
+
+int bq_png_unfilter_strided(bq_ctx* c, const uint8_t* d_rows, size_t rows_stride, int n, int px, uint8_t* d_out, bq_stream_t stream) {
+    if (!c || !d_rows || !d_out || n < 0 || px <= 0) return fail(c, BQ_ERR_ARG, "bq_png_unfilter_strided: bad argument");
+    if (launch_png_unfilter(d_rows, n, px, d_out, (hipStream_t)stream, rows_stride)) return fail(c, BQ_ERR_HIP, "png unfilter launch failed");
+    return BQ_OK;
+}
+
 int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, bq_stream_t* out) {
     if (!c || !cu_mask || mask_words <= 0 || !out) return fail(c, BQ_ERR_ARG, "bq_stream_create_masked: bad argument");
     hipStream_t s = nullptr;
@@ -919,6 +942,12 @@ int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, 
     HIPCHK(c, hipExtStreamCreateWithCUMask(&s, (uint32_t)mask_words, cu_mask));
     *out = (bq_stream_t)s;
     return BQ_OK;
+}
+
+int bq_set_option(bq_ctx* c, const char* name, int value) {
+    if (!c || !name) return fail(c, BQ_ERR_ARG, "bq_set_option: bad argument");
+    if (strcmp(name, "inflate_variant") == 0 && value >= 0 && value <= 3) { c->inflate_variant = value; return BQ_OK; }
+    return fail(c, BQ_ERR_ARG, std::string("bq_set_option: unknown option or value: ") + name);
 }
 
 int bq_set_num_cus(bq_ctx* c, int n) {

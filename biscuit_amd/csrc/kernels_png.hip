@@ -53,14 +53,14 @@ __device__ __forceinline__ unsigned paeth3(unsigned a, unsigned b, unsigned c) {
 // but its data, the upper block is the three dwords lane l-1 produced the step before (three DPP moves), and LDS is
 // touched with aligned dwords only.
 __global__ void __launch_bounds__(NTHR) png_unfilter_kernel(const unsigned char* __restrict__ rows, unsigned char* __restrict__ out,
-                                                          int px) {
+                                                          int px, size_t in_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int W3 = 3 * px, RS = W3 + 1;
     const int RSP = row_pitch(px);
     unsigned char* prev = lds + BAND * RSP;                             // the row above the band (its last result row), dword-aligned
     const int tid = threadIdx.x, lane = tid & 63;
     const bool wave0 = tid < 64;
-    const unsigned char* src = rows + (size_t)blockIdx.x * px * RS;
+    const unsigned char* src = rows + (size_t)blockIdx.x * in_stride;      // (px * RS when the tiles' rows are packed)
     unsigned char* dst = out + (size_t)blockIdx.x * px * W3;
     const int nblk = (px + 3) / 4;                                      // blocks of 4 pixels = 3 dwords (the pitch covers the last, partial one)
 
@@ -161,13 +161,16 @@ __global__ void __launch_bounds__(NTHR) png_unfilter_kernel(const unsigned char*
 
 }  // namespace
 
-int launch_png_unfilter(const unsigned char* rows, int n, int px, unsigned char* out, hipStream_t s) {
+// in_stride: bytes between the row data of consecutive tiles (0: packed, px * (1 + 3 px); the device inflate pads to a dword)
+int launch_png_unfilter(const unsigned char* rows, int n, int px, unsigned char* out, hipStream_t s, size_t in_stride) {
     if (n <= 0) return 0;
+    if (in_stride == 0) in_stride = (size_t)px * (3 * px + 1);
+    if (in_stride < (size_t)px * (3 * px + 1)) return (int)hipErrorInvalidValue;
     if (3 * px + 1 > 1024) return (int)hipErrorInvalidValue;         // (the band loader's batch: rows of up to 1 KiB, px <= 341)
     const int dw = 3 * ((px + 3) / 4) + PAD / 4 + 1;
     const int RSP = 4 * (dw | 1);
     const int lds = BAND * RSP + 12 * ((px + 3) / 4) + 16;
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(png_unfilter_kernel, dim3(n), dim3(NTHR), lds, s, rows, out, px);
+    hipLaunchKernelGGL(png_unfilter_kernel, dim3(n), dim3(NTHR), lds, s, rows, out, px, in_stride);
     return (int)hipGetLastError();
 }

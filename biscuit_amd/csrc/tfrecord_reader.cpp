@@ -563,6 +563,87 @@ int bqio_probe(bqio_reader* r, int64_t first, int64_t count, int tile_px, int64_
     return BQIO_OK;
 }
 
+// The zlib streams of records [first, first + count), packed for the device inflate (bq_png_inflate): stream i = the concatenated
+// IDAT payloads of record i at out_z + off[i], len[i] bytes, every off[i] a multiple of 16 and at least 32 zero bytes behind every
+// stream (the device bit reader loads two dwords ahead).  Only what the device path handles passes: 8-bit RGB, non-interlaced PNG tiles of tile_px x tile_px (anything else:
+// BQIO_ERR_UNSUPPORTED / BQIO_ERR_FORMAT with *bad_index, as bqio_decode would answer for a record outside ITS subset -- the caller
+// falls back to bqio_decode for the slide).  *used = bytes of out_z written (<= cap, else BQIO_ERR_ARG with *used = bytes needed).
+int bqio_extract_z(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out_z, size_t cap, uint32_t* off, uint32_t* len,
+                   int64_t* loc, size_t* used, int n_threads, int64_t* bad_index) {
+    if (!r || first < 0 || count < 0 || first + count > (int64_t)r->records.size() || tile_px <= 0 || !off || !len || !used ||
+        (count && !out_z)) return BQIO_ERR_ARG;
+    if (bad_index) *bad_index = -1;
+    *used = 0;
+    struct Piece { const uint8_t* p; uint32_t n; };
+    std::vector<std::vector<Piece>> pieces((size_t)count);
+    size_t at = 0;
+    for (int64_t i = 0; i < count; ++i) {
+        Example ex;
+        int e = BQIO_OK;
+        if (!parse_example(r->records[(size_t)(first + i)], ex) || !ex.image.p) e = BQIO_ERR_CORRUPT;
+        else if (image_format(ex.image) != BQIO_IMG_PNG) e = BQIO_ERR_UNSUPPORTED;
+        else {
+            const uint8_t* p = ex.image.p + 8;
+            const uint8_t* end = ex.image.p + ex.image.n;
+            bool ihdr = false, seen_end = false;
+            uint64_t total = 0;
+            while (end - p >= 12 && !seen_end && e == BQIO_OK) {
+                const uint32_t n = be32(p);
+                if ((uint64_t)n + 12 > (uint64_t)(end - p)) { e = BQIO_ERR_CORRUPT; break; }
+                const uint8_t* type = p + 4;
+                const uint8_t* data = p + 8;
+                if (!memcmp(type, "IHDR", 4)) {
+                    if (n < 13) { e = BQIO_ERR_CORRUPT; break; }
+                    const uint32_t w = be32(data), h = be32(data + 4);
+                    if (data[8] != 8 || data[9] != 2 || data[12] != 0) e = BQIO_ERR_UNSUPPORTED;      // 8-bit RGB, not interlaced
+                    else if ((int)w != tile_px || (int)h != tile_px) e = BQIO_ERR_FORMAT;
+                    ihdr = true;
+                } else if (!memcmp(type, "IDAT", 4)) {
+                    if (n) pieces[(size_t)i].push_back(Piece{data, n});
+                    total += n;
+                } else if (!memcmp(type, "IEND", 4)) seen_end = true;
+                p += (size_t)n + 12;
+            }
+            if (e == BQIO_OK && (!ihdr || total == 0 || total > 0x7fffffffull)) e = BQIO_ERR_CORRUPT;
+            if (e == BQIO_OK) {
+                off[i] = (uint32_t)at;
+                len[i] = (uint32_t)total;
+                if (loc) { loc[2 * i] = ex.loc_x; loc[2 * i + 1] = ex.loc_y; }
+                at = (at + (size_t)total + 32 + 15) & ~(size_t)15;
+                if (at > 0xfffffff0ull) e = BQIO_ERR_ARG;
+            }
+        }
+        if (e != BQIO_OK) {
+            if (bad_index) *bad_index = first + i;
+            r->err = e == BQIO_ERR_UNSUPPORTED ? "image_raw is not an 8-bit RGB PNG the device inflate handles"
+                     : e == BQIO_ERR_FORMAT    ? "tile size differs from tile_px" : "corrupt record or PNG";
+            return e;
+        }
+    }
+    *used = at;
+    if (at > cap) return BQIO_ERR_ARG;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > count) n_threads = (int)(count ? count : 1);
+    std::atomic<int64_t> next(0);
+    auto work = [&]() {
+        for (;;) {
+            const int64_t i = next.fetch_add(8);
+            if (i >= count) return;
+            for (int64_t k = i; k < i + 8 && k < count; ++k) {
+                uint8_t* d = out_z + off[k];
+                for (const Piece& pc : pieces[(size_t)k]) { memcpy(d, pc.p, pc.n); d += pc.n; }
+                const size_t stop = k + 1 < count ? off[k + 1] : at;
+                memset(d, 0, (size_t)(out_z + stop - d));
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    return BQIO_OK;
+}
+
 int bqio_decode(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out, int64_t* loc, int n_threads,
                 int64_t* bad_index) {
     return decode_impl(r, first, count, tile_px, out, loc, n_threads, bad_index, false);

@@ -143,6 +143,10 @@ class Engine:
         whose launches go to a CU-masked stream wants.  Results do not depend on it."""
         self._check(self._lib.bq_set_num_cus(self._ctx, int(n)))
 
+    def set_option(self, name, value):
+        """A tuning knob of the library that changes no result (``bq_set_option``), e.g. ``('inflate_variant', 1)``."""
+        self._check(self._lib.bq_set_option(self._ctx, name.encode(), int(value)))
+
     # ------------------------------------------------------------------ stages
     def stage(self, tiles_u8):
         """uint8 NHWC [n,299,299,3] (device) -> standardised planar NCHW tensor."""
@@ -162,6 +166,35 @@ class Engine:
         out = torch.empty((n, px, px, 3), dtype=torch.uint8, device=self.device)
         self._check(self._lib.bq_png_unfilter(self._ctx, _ptr(rows_u8), n, px, _ptr(out), self._stream()))
         return out
+
+    def png_inflate(self, z, off, length, px=TILE_PX):
+        """The zlib streams of n PNG tiles, inflated on the device (``bq_png_inflate``, kernels_inflate.hip: one stream per lane):
+        ``z`` uint8 [bytes] -- the packed streams of ``NativeReader.extract_z`` --, ``off`` / ``length`` int32 / uint32 [n], all on
+        this device.  Returns ``(rows, status)``: rows uint8 [n, stride] (a tile's px rows of 1 + 3 px bytes, then padding to a
+        multiple of 4) and status int32 [n], 0 where the stream inflated to exactly that many bytes with a matching Adler-32 --
+        what zlib's ``uncompress`` accepts."""
+        assert z.dtype == torch.uint8 and z.is_cuda and z.is_contiguous()
+        n = int(off.shape[0])
+        assert off.is_cuda and length.is_cuda and off.element_size() == 4 and length.element_size() == 4 and length.shape[0] == n
+        row_bytes = px * (1 + 3 * px)
+        stride = (row_bytes + 4 + 3) // 4 * 4
+        rows = torch.empty((n, stride), dtype=torch.uint8, device=self.device)
+        status = torch.empty(n, dtype=torch.int32, device=self.device)
+        need = int(self._lib.bq_png_inflate_scratch_bytes(n))
+        if getattr(self, '_inflate_ws', None) is None or self._inflate_ws.numel() < need:
+            self._inflate_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._check(self._lib.bq_png_inflate(self._ctx, _ptr(z), _ptr(off), _ptr(length), n, px, _ptr(rows), stride,
+                                             _ptr(self._inflate_ws), self._inflate_ws.numel(), _ptr(status), self._stream()))
+        return rows, status
+
+    def png_decode_z(self, z, off, length, px=TILE_PX):
+        """Compressed PNG tiles -> uint8 NHWC [n,px,px,3] entirely on the device: ``png_inflate``, then the scanline filters
+        reversed (``bq_png_unfilter_strided``).  Returns ``(tiles, status)``; a tile whose status is not 0 is undefined."""
+        rows, status = self.png_inflate(z, off, length, px)
+        n = rows.shape[0]
+        out = torch.empty((n, px, px, 3), dtype=torch.uint8, device=self.device)
+        self._check(self._lib.bq_png_unfilter_strided(self._ctx, _ptr(rows), rows.shape[1], n, px, _ptr(out), self._stream()))
+        return out, status
 
     def reinhard_fast(self, tiles_u8, target_means, target_stds, out=None):
         """`reinhard_fast` stain normalisation (hp.py:19; results.py:251-252 `wsi_normalizer.rgb_to_rgb`):

@@ -30,6 +30,7 @@ ABI = {
     'bqio_decode': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
     'bqio_decode_rows': (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, C.POINTER(_i64)]),
     'bqio_probe': (_i, [_vp, _i64, _i64, _i, C.POINTER(_i64)]),
+    'bqio_extract_z': (_i, [_vp, _i64, _i64, _i, _vp, C.c_size_t, _vp, _vp, _vp, C.POINTER(C.c_size_t), _i, C.POINTER(_i64)]),
     'bqio_masked_crc32c': (C.c_uint32, [C.c_char_p, C.c_size_t]),
     'bqio_inflate': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t]),
     'bqio_inflate2': (_i, [C.c_char_p, C.c_size_t, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp, C.c_size_t,
@@ -180,6 +181,28 @@ class NativeReader:
         bad = _i64(-1)
         e = self._lib.bqio_probe(self._h, first, count, tile_px, C.byref(bad))
         return None if e == 0 else int(bad.value)
+
+    def extract_z(self, first, count, tile_px, out_z, off, length, threads=None):
+        """The zlib streams of records [first, first + count) packed into ``out_z`` (uint8 array, usually pinned) for the device
+        inflate (``Engine.png_inflate``): ``off`` / ``length`` (uint32 [count]) receive every stream's offset (a multiple of 16)
+        and size.  Returns (bytes used, loc int64 [count, 2]).  ``UnsupportedImage`` for a record that is not an 8-bit RGB PNG
+        tile of ``tile_px``; ``MemoryError`` (with the bytes needed in ``.args[1]``) when ``out_z`` is too small."""
+        assert out_z.dtype == np.uint8 and out_z.flags['C_CONTIGUOUS'] and off.dtype == np.uint32 and length.dtype == np.uint32
+        assert off.size >= count and length.size >= count
+        loc = np.zeros((count, 2), np.int64)
+        used = C.c_size_t(0)
+        bad = _i64(-1)
+        e = self._lib.bqio_extract_z(self._h, first, count, tile_px, out_z.ctypes.data, out_z.size, off.ctypes.data,
+                                     length.ctypes.data, loc.ctypes.data, C.byref(used), threads or default_threads(), C.byref(bad))
+        if e == ERR_UNSUPPORTED:
+            raise UnsupportedImage(bad.value)
+        if e == ERR_FORMAT:
+            raise ValueError(f'{self.path}: record {bad.value}: tile size differs from {(tile_px, tile_px, 3)}')
+        if e != 0 and used.value > out_z.size:
+            raise MemoryError(f'extract_z: {used.value} bytes needed, {out_z.size} given', used.value)
+        if e != 0:
+            raise IOError(f'{self.path}: {self._lib.bqio_last_error(self._h).decode()} (record {bad.value})')
+        return int(used.value), loc
 
     def decode(self, first=0, count=None, tile_px=299, out=None, threads=None, rows=False):
         """-> (tiles uint8 [count,px,px,3], loc int64 [count,2]).  `out`: optional C-contiguous uint8

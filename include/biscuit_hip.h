@@ -88,6 +88,9 @@ int bq_stream_destroy(bq_ctx* ctx, bq_stream_t stream);
  * that).  A context whose launches go to a CU-masked stream sets it to the CUs of the mask: a grid sized for the whole chip runs
  * there as two rounds of workgroups, each with its own prologue.  Results do not depend on it. */
 int bq_set_num_cus(bq_ctx* ctx, int n);
+/* Tuning knobs that change no result.  "inflate_variant": 0 (default) = bq_png_inflate keeps its decode tables in the scratch buffer
+ * (global memory / L2; throughput from many waves per CU), 1 = the direct halves of the tables mirrored in LDS (two waves per CU). */
+int bq_set_option(bq_ctx* ctx, const char* name, int value);
 
 /* K0, optional front half: the `reinhard_fast` stain normaliser hp.py:19 selects, applied to the
  * uint8 tile before the standardisation exactly where results.py:251-252 calls
@@ -107,6 +110,19 @@ int bq_stain_lab_stats(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, float* d
  * 8-bit RGB non-interlaced PNG, as libbiscuit_io's bqio_decode_rows delivers it (include/biscuit_io.h).  d_out: uint8 NHWC
  * [n][px][px][3], the tiles bq_stage / bq_mc_infer take.  Bit-exact with a host PNG decoder (tests/test_png_unfilter.py). */
 int bq_png_unfilter(bq_ctx* ctx, const uint8_t* d_rows, int n, int px, uint8_t* d_out_nhwc, bq_stream_t stream);
+
+/* Input side, PNG tiles, the inflate itself on the device (round 5): n zlib streams -- the concatenated IDAT payloads of n 8-bit RGB
+ * non-interlaced PNG tiles, as libbiscuit_io's bqio_extract_z packs them: stream i = d_z[d_off[i] .. d_off[i] + d_len[i]), every
+ * d_off[i] a multiple of 16, 32 readable bytes behind every stream -- are inflated to their px rows of 1 + 3 px bytes at d_rows +
+ * i * rows_stride (rows_stride a multiple of 4, >= px (1 + 3 px) + 4), one stream per lane.  d_status[i] = 0 iff stream i is a
+ * well-formed zlib stream that inflates to exactly px (1 + 3 px) bytes with a matching Adler-32 (what zlib's uncompress() accepts);
+ * any other value: the tile's rows are undefined and the caller decodes that record on the host.  d_scratch: table space,
+ * bq_png_inflate_scratch_bytes(n).  Follow with bq_png_unfilter_strided.  No reference counterpart (tf.io.decode_png under tf.data). */
+size_t bq_png_inflate_scratch_bytes(int n);
+int bq_png_inflate(bq_ctx* ctx, const uint8_t* d_z, const uint32_t* d_off, const uint32_t* d_len, int n, int px, uint8_t* d_rows,
+                   size_t rows_stride, void* d_scratch, size_t scratch_bytes, int32_t* d_status, bq_stream_t stream);
+int bq_png_unfilter_strided(bq_ctx* ctx, const uint8_t* d_rows, size_t rows_stride, int n, int px, uint8_t* d_out_nhwc,
+                            bq_stream_t stream);
 
 /* Variant for callers that already hold standardised float32 NHWC tiles (the
  * UncertaintyInterface contract, results.py:256-257): converts to planar NCHW. */

@@ -72,6 +72,15 @@ int bqio_decode_rows(bqio_reader* r, int64_t first, int64_t count, int tile_px, 
  * mixes two decoders' IDCTs inside a slide.  BQIO_OK, or the error bqio_decode would report, *bad_index = the record. */
 int bqio_probe(bqio_reader* r, int64_t first, int64_t count, int tile_px, int64_t* bad_index);
 
+/* The compressed side of the PNG tiles for the DEVICE inflate (libbiscuit_hip: bq_png_inflate): the zlib streams (concatenated
+ * IDAT payloads) of records [first, first + count), packed into out_z -- stream i at off[i] (a multiple of 16), len[i] bytes, at
+ * least 32 zero bytes behind each -- plus the records' loc_x / loc_y (loc may be NULL).  The host does no decompression: it walks the
+ * record framing and the PNG chunk headers and copies.  Only 8-bit RGB non-interlaced tiles of tile_px x tile_px pass
+ * (BQIO_ERR_UNSUPPORTED / BQIO_ERR_FORMAT / BQIO_ERR_CORRUPT with *bad_index otherwise: decode that slide with bqio_decode).
+ * *used = bytes written; a capacity `cap` that is too small returns BQIO_ERR_ARG with *used = the bytes needed. */
+int bqio_extract_z(bqio_reader* r, int64_t first, int64_t count, int tile_px, uint8_t* out_z, size_t cap, uint32_t* off,
+                   uint32_t* len, int64_t* loc, size_t* used, int n_threads, int64_t* bad_index);
+
 /* One JPEG file (as bqio_image_bytes returns it) -> out[tile_px][tile_px][3], the decoder
  * bqio_decode uses, exported for tests.  BQIO_OK / BQIO_ERR_UNSUPPORTED / BQIO_ERR_FORMAT. */
 int bqio_decode_jpeg(const uint8_t* data, size_t len, int tile_px, uint8_t* out);
