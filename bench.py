@@ -695,18 +695,22 @@ def tfrecord_leg(pool_e, args, n_slides=8, tiles_per_slide=1024):
                                  np.zeros((tiles_per_slide, 2), np.int64))
             paths.append(p)
         nbytes = sum(os.path.getsize(p) for p in paths)
-        dec = []
-        for _ in range(3):                              # cold, warm, warm
+        # the decoder alone, the way evaluate() drives it: 512-tile chunks into ONE reused buffer (a fresh 275 MB array per slide
+        # would time the page faults of its first touch, not the decoder) -- cold, then warm twice; then the same stopping at the
+        # filtered scanlines (what the GPU un-filter mode asks of the host)
+        from biscuit_amd.inference import CHUNK_TILES, TFRecordSource
+        def decode_pass(rows):
+            buf = np.empty((CHUNK_TILES, 299, 1 + 3 * 299) if rows else (CHUNK_TILES, 299, 299, 3), np.uint8)
             t0 = time.perf_counter()
             for p in paths:
-                tfrecord.read_slide(p, 299)
-            dec.append(time.perf_counter() - t0)
-        rows_dec = []
-        for _ in range(2):                              # the decoder stopping at the filtered scanlines (what the GPU un-filter mode asks of the host)
-            t0 = time.perf_counter()
-            for p in paths:
-                tfrecord.read_slide(p, 299, rows=True)
-            rows_dec.append(time.perf_counter() - t0)
+                src = TFRecordSource(p, tiles_per_slide, 299, rows=rows)
+                for first in range(0, tiles_per_slide, CHUNK_TILES):
+                    cnt = min(CHUNK_TILES, tiles_per_slide - first)
+                    src.read(first, cnt, buf[:cnt])
+                src.close()
+            return time.perf_counter() - t0
+        dec = [decode_pass(False) for _ in range(3)]
+        rows_dec = [decode_pass(True) for _ in range(2)]
         slides = slides_from_tfrecords(paths, lab)
         gslides = slides_from_tfrecords(paths, lab, gpu_unfilter=True)
         auto, host_rate, rows_rate = pick_unfilter_mode(paths[0])
