@@ -54,6 +54,8 @@ struct bq_ctx {
     int num_cus = 256;
     float* d_srgb_lut = nullptr;   // tables of the Reinhard normaliser
     const long long* d_tile0 = nullptr;   // bq_set_tile_index_ptr
+    int head_variant = 2;          // bq_set_option("head_variant"): 0 = stages in lock step, 1 / 2 = producer and matrix stage overlapped (2: the
+                                   // waves that share a SIMD in opposite stages; bit-identical, 1-7 % faster: tools/ab_head.py)
     int inflate_variant = 0;       // bq_set_option("inflate_variant"): 0 = tables in global memory, 1 = direct tables mirrored in LDS
     float feat_mul = 1.f;          // "act/feat_mul" of the blob: 2^k of the pooled tensor's activation exponent (weights.py: pack_blob)
     double* d_stage_stats = nullptr;   // 2 x 64-bit integer sums per tile for the staging kernel pair
@@ -630,7 +632,7 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
                      4.0 * ((layer == 0 ? (double)n : (double)rows) * K + (double)rows * 1024 + (double)K * 1024));
         const int e = launch_head_dense(layer == 0 ? feat : h0, G.wh, G.wl, G.bias, layer == 0 ? h0 : h1, rows, K, mc_n, pass0,
                                         layer == 0 ? 1 : 0, layer, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), thresh,
-                                        dscale, tile0, c->d_tile0, s);
+                                        dscale, tile0, c->d_tile0, s, c->head_variant);
         if (e) return fail(c, BQ_ERR_HIP, std::string("head dense launch: ") + hipGetErrorString((hipError_t)e));
     }
     {
@@ -947,6 +949,7 @@ int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, 
 int bq_set_option(bq_ctx* c, const char* name, int value) {
     if (!c || !name) return fail(c, BQ_ERR_ARG, "bq_set_option: bad argument");
     if (strcmp(name, "inflate_variant") == 0 && value >= 0 && value <= 3) { c->inflate_variant = value; return BQ_OK; }
+    if (strcmp(name, "head_variant") == 0 && value >= 0 && value <= 2) { c->head_variant = value; return BQ_OK; }
     return fail(c, BQ_ERR_ARG, std::string("bq_set_option: unknown option or value: ") + name);
 }
 

@@ -172,6 +172,7 @@ class EvalResult:
 
 
 CHUNK_TILES = 512        # tiles per pinned buffer: 137 MB at 299 px (a 10^4-tile slide is twenty chunks, never one allocation)
+RAMP_CHUNKS = (128, 256) # the first chunks of a run are short: the GPU starts after 128 decoded tiles (4 ms of the decoder), not 512
 RING_SLOTS = 3
 PREFETCH_CHUNKS = 2      # decoded chunks waiting for the GPU (plus the one being decoded)
 
@@ -249,6 +250,7 @@ def _feed_chunks(slides, mine, dev, copy_stream):
 
     def work():
         ring = None
+        n_chunks = 0                                     # chunks decoded so far in this run (over all slides)
         try:
             for li, si in enumerate(mine):
                 s = slides[si]
@@ -278,8 +280,11 @@ def _feed_chunks(slides, mine, dev, copy_stream):
                         ring.release()
                     ring = _PinnedRing.lease(need)
                 try:
-                    for first in range(0, s.n_tiles, CHUNK_TILES):
-                        cnt = min(CHUNK_TILES, s.n_tiles - first)
+                    first = 0
+                    while first < s.n_tiles:
+                        size = RAMP_CHUNKS[n_chunks] if n_chunks < len(RAMP_CHUNKS) else CHUNK_TILES
+                        n_chunks += 1
+                        cnt = min(size, s.n_tiles - first)
                         slot = ring.acquire()
                         host = ring.bufs[slot][:cnt * per].view(src.chunk_shape(cnt))
                         src.read(first, cnt, host.numpy())
@@ -291,6 +296,7 @@ def _feed_chunks(slides, mine, dev, copy_stream):
                         ring.events[slot] = ev
                         if not put((li, si, first, cnt, d, ev, src.rows)):
                             return
+                        first += cnt
                 finally:
                     src.close()
             put(None)

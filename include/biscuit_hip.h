@@ -89,7 +89,9 @@ int bq_stream_destroy(bq_ctx* ctx, bq_stream_t stream);
  * there as two rounds of workgroups, each with its own prologue.  Results do not depend on it. */
 int bq_set_num_cus(bq_ctx* ctx, int n);
 /* Tuning knobs that change no result.  "inflate_variant": 0 (default) = bq_png_inflate keeps its decode tables in the scratch buffer
- * (global memory / L2; throughput from many waves per CU), 1 = the direct halves of the tables mirrored in LDS (two waves per CU). */
+ * (global memory / L2; throughput from many waves per CU), 1 = the direct halves of the tables mirrored in LDS (two waves per CU),
+ * 2 / 3 = rounds of a literal-only fast phase and a general slow phase (profiles/r05_inflate.txt).  "head_variant": the MC head's
+ * dense layers with their Philox / split stage and their matrix stage in lock step (0) or overlapped (1, 2 = default). */
 int bq_set_option(bq_ctx* ctx, const char* name, int value);
 
 /* K0, optional front half: the `reinhard_fast` stain normaliser hp.py:19 selects, applied to the

@@ -151,6 +151,24 @@ def test_mc_head_against_oracle(engines, oracles):
     assert torch.equal(mb, mf) and torch.equal(sb, sf)
 
 
+def test_head_variants_bit_identical(engines):
+    """The MC head's dense kernels with the dropout / split stage and the matrix stage in lock step (0) or overlapped (1, 2: the
+    default): the same products in the same order, for a full batch, a ragged row count and the one-tile call."""
+    eng = engines['f16']
+    rng = np.random.default_rng(5)
+    try:
+        for n, mc in ((256, 30), (37, 7), (1, 30)):
+            feat = dev(np.abs(rng.normal(0.8, 0.5, (n, 2048))).astype(np.float32))
+            outs = []
+            for v in (0, 1, 2):
+                eng.set_option('head_variant', v)
+                m, s = eng.mc_head(feat, mc, 99, tile_idx0=1000)
+                outs.append((m.clone(), s.clone()))
+            assert all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) for o in outs), (n, mc)
+    finally:
+        eng.set_option('head_variant', 2)
+
+
 def test_end_to_end_fp32(engines, oracles, tiles):
     m, s = engines['f32'].mc_infer(dev(tiles), 5, 1234)
     rm, rs = oracles['f32'].mc_predict(tiles, 5, 1234, mode='head')

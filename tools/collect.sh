@@ -3,8 +3,8 @@
 T=${1:-r05}
 set -e
 python tools/summarize_prof.py gpurun_out/prof_${T} profiles/${T}_rocprof.md f16 > /dev/null
-cp gpurun_out/prof_${T}/trace/runc/*_kernel_stats.csv profiles/${T}_kernel_stats.csv
-cp gpurun_out/prof_${T}/trace1/runc/*_kernel_stats.csv profiles/${T}_kernel_stats_1stream.csv
+cp "$(ls -t gpurun_out/prof_${T}/trace/runc/*_kernel_stats.csv | head -1)" profiles/${T}_kernel_stats.csv      # (gpurun_out accumulates: the newest run's)
+cp "$(ls -t gpurun_out/prof_${T}/trace1/runc/*_kernel_stats.csv | head -1)" profiles/${T}_kernel_stats_1stream.csv
 cp gpurun_out/${T}_sweep_mc.jsonl profiles/
 TAG=$T python - <<'PY'
 import json, os
