@@ -56,7 +56,8 @@ struct bq_ctx {
     const long long* d_tile0 = nullptr;   // bq_set_tile_index_ptr
     int head_variant = 2;          // bq_set_option("head_variant"): 0 = stages in lock step, 1 / 2 = producer and matrix stage overlapped (2: the
                                    // waves that share a SIMD in opposite stages; bit-identical, 1-7 % faster: tools/ab_head.py)
-    int inflate_variant = 0;       // bq_set_option("inflate_variant"): 0 = tables in global memory, 1 = direct tables mirrored in LDS
+    int inflate_variant = 5;       // bq_set_option("inflate_variant"): 0 = tables in global memory, 1 = direct tables mirrored in LDS, 2-8 = rounds of a
+                                   // literal-only fast phase + general phase (kernels_inflate.hip); 5 measured fastest (profiles/r05_inflate.txt)
     float feat_mul = 1.f;          // "act/feat_mul" of the blob: 2^k of the pooled tensor's activation exponent (weights.py: pack_blob)
     double* d_stage_stats = nullptr;   // 2 x 64-bit integer sums per tile for the staging kernel pair
     // profiling
@@ -948,7 +949,7 @@ int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, 
 
 int bq_set_option(bq_ctx* c, const char* name, int value) {
     if (!c || !name) return fail(c, BQ_ERR_ARG, "bq_set_option: bad argument");
-    if (strcmp(name, "inflate_variant") == 0 && value >= 0 && value <= 3) { c->inflate_variant = value; return BQ_OK; }
+    if (strcmp(name, "inflate_variant") == 0 && value >= 0 && value <= 8) { c->inflate_variant = value; return BQ_OK; }
     if (strcmp(name, "head_variant") == 0 && value >= 0 && value <= 2) { c->head_variant = value; return BQ_OK; }
     return fail(c, BQ_ERR_ARG, std::string("bq_set_option: unknown option or value: ") + name);
 }

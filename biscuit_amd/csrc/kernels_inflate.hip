@@ -623,6 +623,219 @@ __global__ void __launch_bounds__(INF_NT) inflate_rounds_kernel(const InflatePar
     }
 }
 
+// ---- variants 4 / 5: the rounds again, with a fast phase that is memory-free AND short ------------------------------------------
+// What variants 2 / 3 lost to: ~30 instructions per fast step (a 128-bit pending register with variable shifts) and a slow phase in
+// which EVERY lane decoded a symbol through the global tables.  Here a literal of the fast phase goes to a 32-byte ring in LDS with
+// one ds_write_b8 (the slow phase stores the ring's complete dwords), the fast step is a table read, a compare and a shift, and only
+// the lanes that stopped on a non-literal take the general path.
+template <int L0, int FAST>
+__global__ void __launch_bounds__(INF_NT) inflate_rounds2_kernel(const InflateParams p) {
+    constexpr int RING = 32;                                   // bytes of output ring per lane
+    constexpr int PER_LANE = (1 << L0) * 2 + RING;             // bytes of LDS per lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int i = blockIdx.x * INF_NT + threadIdx.x;
+    const bool mine = i < p.n;
+    const int ii = mine ? i : 0;
+    unsigned short* const l0 = reinterpret_cast<unsigned short*>(lds_raw + threadIdx.x * PER_LANE);
+    unsigned char* const ring = lds_raw + threadIdx.x * PER_LANE + (1 << L0) * 2;
+    unsigned* const scr = p.scratch + (size_t)ii * SCR_WORDS;
+    unsigned* const lt = scr + SCR_LT;
+    unsigned* const dt = scr + SCR_DT;
+    unsigned char* const lens = reinterpret_cast<unsigned char*>(scr + SCR_LENS);
+    unsigned short* const codes = reinterpret_cast<unsigned short*>(scr + SCR_CODES);
+    unsigned char* const sub_bits = reinterpret_cast<unsigned char*>(scr + SCR_SUB);
+    const unsigned char* const zin = p.z + p.off[ii];
+    const unsigned zlen = p.len[ii];
+    unsigned char* const out0 = p.out + (size_t)ii * p.out_stride;
+    const unsigned out_len = p.out_len;
+    int status = INF_OK;
+
+    Bits b;
+    b.open(reinterpret_cast<const unsigned*>(zin));
+    const unsigned* const p_limit = reinterpret_cast<const unsigned*>(zin) + (zlen + 3) / 4 + 4;
+    {
+        const unsigned cmf = b.take(8), flg = b.take(8);
+        if (zlen < 6 || (cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) status = INF_BAD_HEADER;
+    }
+    unsigned op = 0;                            // bytes produced; byte k of the output waits at ring[k & (RING - 1)] until it is stored
+    unsigned flushed = 0;                       // a multiple of 4: bytes below it are in memory
+    bool final_block = false;
+    enum { ST_HEADER = 0, ST_SYMBOLS = 1, ST_DONE = 2 };
+    int state = mine ? ST_HEADER : ST_DONE;
+    if (status != INF_OK) state = ST_DONE;
+    // complete dwords of the ring -> memory (partial: the dword in progress too, as a dword -- the bytes behind op are overwritten
+    // later, the output stride leaves room behind the last one)
+    auto flush = [&](bool partial) {
+        const unsigned end = partial ? (op + 3u) & ~3u : op & ~3u;
+        for (unsigned k = flushed; k < end; k += 4)
+            *reinterpret_cast<unsigned*>(out0 + k) = *reinterpret_cast<const unsigned*>(ring + (k & (RING - 1)));
+        flushed = op & ~3u;
+    };
+
+    while (__builtin_amdgcn_ballot_w64(state != ST_DONE) != 0ull) {
+        bool stalled = false;                   // stopped on something that is not a short literal
+        // ---- fast phase: no memory access but the table
+        if (state == ST_SYMBOLS) {
+            bool go = out_len - op >= (unsigned)FAST;      // (the last few bytes of a stream take the general path)
+#pragma unroll
+            for (int f = 0; f < FAST; ++f) {
+                const unsigned e = l0[(unsigned)b.buf & ((1u << L0) - 1u)];
+                const int nb = (int)(e >> 8);              // 0 for "not a short literal"
+                const bool hit = nb != 0;
+                stalled = stalled || (go && !hit);
+                go = go && hit && b.cnt >= nb;
+                if (go) {
+                    ring[op & (RING - 1)] = (unsigned char)e;
+                    ++op;
+                    b.drop(nb);
+                }
+            }
+        }
+        // ---- slow phase
+        if (state != ST_DONE) {
+            flush(false);
+            if (b.p > p_limit) { status = INF_OVERRUN; state = ST_DONE; }
+            else b.need();
+        }
+        if (state == ST_SYMBOLS && (stalled || out_len - op < (unsigned)FAST)) {
+            unsigned e = lt[(unsigned)b.buf & ((1u << LT_BITS) - 1u)];
+            if (e & F_SUB) e = lt[(e >> 16) + (((unsigned)(b.buf >> LT_BITS)) & ((1u << ((e >> 8) & 0x1F)) - 1u))];
+            if (e & F_LITERAL) {
+                if (op >= out_len) { status = INF_LENGTH; state = ST_DONE; }
+                else { b.drop((int)(e & 0xFF)); ring[op & (RING - 1)] = (unsigned char)(e >> 16); ++op; }
+            } else if (e & F_SPECIAL) {
+                if (e >> 16) { status = INF_BAD_CODE; state = ST_DONE; }
+                else { b.drop((int)(e & 0xFF)); state = final_block ? ST_DONE : ST_HEADER; }
+            } else {
+                b.drop((int)(e & 0xFF));
+                const unsigned len = (e >> 16) + b.take((int)((e >> 8) & 0x1F));
+                b.need();
+                unsigned d = dt[(unsigned)b.buf & ((1u << DT_BITS) - 1u)];
+                if (d & F_SUB) d = dt[(d >> 16) + (((unsigned)(b.buf >> DT_BITS)) & ((1u << ((d >> 8) & 0x1F)) - 1u))];
+                if (d & F_SPECIAL) { status = INF_BAD_CODE; state = ST_DONE; }
+                else {
+                    b.drop((int)(d & 0xFF));
+                    const unsigned dist = (d >> 16) + b.take((int)((d >> 8) & 0x1F));
+                    if (dist > op) { status = INF_BAD_DISTANCE; state = ST_DONE; }
+                    else if (len > out_len - op) { status = INF_LENGTH; state = ST_DONE; }
+                    else {
+                        flush(true);                        // the copy reads this lane's own output
+                        unsigned k = 0;
+                        if (dist >= 4) {
+                            for (; k + 4 <= len; k += 4) {  // four loads, then four stores
+                                const unsigned b0 = out0[op - dist], b1 = out0[op - dist + 1], b2 = out0[op - dist + 2], b3 = out0[op - dist + 3];
+                                out0[op] = (unsigned char)b0; out0[op + 1] = (unsigned char)b1; out0[op + 2] = (unsigned char)b2; out0[op + 3] = (unsigned char)b3;
+                                ring[op & (RING - 1)] = (unsigned char)b0; ring[(op + 1) & (RING - 1)] = (unsigned char)b1;
+                                ring[(op + 2) & (RING - 1)] = (unsigned char)b2; ring[(op + 3) & (RING - 1)] = (unsigned char)b3;
+                                op += 4;
+                            }
+                        }
+                        for (; k < len; ++k) {
+                            const unsigned v = out0[op - dist];
+                            out0[op] = (unsigned char)v;
+                            ring[op & (RING - 1)] = (unsigned char)v;      // (the ring stays the truth for the dword in progress)
+                            ++op;
+                        }
+                        flushed = op & ~3u;                 // everything below is in memory through the copy's own stores
+                    }
+                }
+            }
+        } else if (state == ST_HEADER) {
+            final_block = b.take(1) != 0;
+            const unsigned type = b.take(2);
+            if (type == 0) {
+                b.drop(b.cnt & 7);
+                b.need();
+                const unsigned len = b.take(16);
+                b.need();
+                const unsigned nlen = b.take(16);
+                if ((len ^ nlen) != 0xFFFFu) { status = INF_BAD_BLOCK; state = ST_DONE; }
+                else if (len > out_len - op) { status = INF_LENGTH; state = ST_DONE; }
+                else {
+                    for (unsigned k = 0; k < len && status == INF_OK; ++k) {
+                        b.need();
+                        ring[op & (RING - 1)] = (unsigned char)b.take(8);
+                        ++op;
+                        if (op - flushed >= (unsigned)RING - 4) flush(false);
+                        if (b.p > p_limit) status = INF_OVERRUN;
+                    }
+                    if (status != INF_OK) state = ST_DONE;
+                    else if (final_block) state = ST_DONE;
+                }
+            } else if (type == 3) { status = INF_BAD_BLOCK; state = ST_DONE; }
+            else {
+                int hlit = 288, hdist = 32;
+                bool bad = false;
+                if (type == 1) {
+                    for (int k = 0; k < 144; ++k) lens[k] = 8;
+                    for (int k = 144; k < 256; ++k) lens[k] = 9;
+                    for (int k = 256; k < 280; ++k) lens[k] = 7;
+                    for (int k = 280; k < 288; ++k) lens[k] = 8;
+                    for (int k = 0; k < 32; ++k) lens[288 + k] = 5;
+                } else {
+                    b.need();
+                    hlit = (int)b.take(5) + 257; hdist = (int)b.take(5) + 1;
+                    const int hclen = (int)b.take(4) + 4;
+                    if (hlit > 286 || hdist > 30) bad = true;
+                    else {
+                        unsigned char* const cl_mem = sub_bits + 256;
+                        for (int k = 0; k < 19; ++k) cl_mem[k] = 0;
+                        for (int k = 0; k < hclen; ++k) {
+                            b.need();
+                            cl_mem[kClOrder[k]] = (unsigned char)b.take(3);
+                        }
+                        if (!build_table(cl_mem, 19, dt, 7, 128, 0, codes, sub_bits, nullptr)) bad = true;
+                        int k = 0;
+                        const int total = hlit + hdist;
+                        while (!bad && k < total) {
+                            if (b.p > p_limit) { bad = true; break; }
+                            b.need();
+                            const unsigned e = dt[b.peek(7)];
+                            if (e & F_SPECIAL) { bad = true; break; }
+                            b.drop((int)(e & 0xFF));
+                            const unsigned sym = e >> 16;
+                            if (sym < 16) { lens[k++] = (unsigned char)sym; continue; }
+                            unsigned rep, val = 0;
+                            if (sym == 16) {
+                                if (k == 0) { bad = true; break; }
+                                val = lens[k - 1]; rep = 3 + b.take(2);
+                            } else if (sym == 17) rep = 3 + b.take(3);
+                            else rep = 11 + b.take(7);
+                            if (k + (int)rep > total) { bad = true; break; }
+                            for (unsigned r = 0; r < rep; ++r) lens[k + r] = (unsigned char)val;
+                            k += (int)rep;
+                        }
+                        if (!bad && lens[256] == 0) bad = true;
+                    }
+                }
+                if (!bad && (!build_table(lens, hlit, lt, LT_BITS, LT_CAP, 1, codes, sub_bits, nullptr) ||
+                             !build_table(lens + hlit, hdist, dt, DT_BITS, DT_CAP, 2, codes, sub_bits, nullptr))) bad = true;
+                if (bad) { status = status == INF_OK ? INF_BAD_TABLE : status; state = ST_DONE; }
+                else {
+                    // the fast table: (code length << 8) | value for the literals whose codes fit L0 bits, 0 for everything else
+                    for (int k = 0; k < (1 << L0); ++k) {
+                        const unsigned e = lt[k];
+                        const unsigned nb = e & 0xFFu;
+                        l0[k] = ((e & F_LITERAL) && !(e & F_SUB) && nb <= (unsigned)L0) ? (unsigned short)((nb << 8) | ((e >> 16) & 0xFFu)) : (unsigned short)0;
+                    }
+                    state = ST_SYMBOLS;
+                }
+            }
+        }
+    }
+    if (mine) {
+        if (status == INF_OK) {
+            flush(true);
+            if (op != out_len) status = INF_LENGTH;
+            else {
+                b.drop(b.cnt & 7);
+                if (b.consumed(zin) != (long long)zlen - 4) status = INF_TRAILING;
+            }
+        }
+        p.status[i] = status;
+    }
+}
+
 // Adler-32 of every stream's output against its trailer: one wave per stream.  a = 1 + sum(x) ; b = n + sum((n - k) x_k), mod 65521.
 __global__ void __launch_bounds__(64) adler_kernel(const InflateParams p) {
     const int i = blockIdx.x;
@@ -671,7 +884,24 @@ int launch_inflate(const unsigned char* d_z, const unsigned* d_off, const unsign
     InflateParams p;
     p.z = d_z; p.off = d_off; p.len = d_len; p.out = d_out; p.out_len = out_len; p.out_stride = out_stride;
     p.scratch = reinterpret_cast<unsigned*>(d_scratch); p.status = d_status; p.n = n;
-    if (variant == 2 || variant == 3) {
+    if (variant >= 4 && variant <= 8) {
+        // the rounds with the short fast phase: (fast-table bits, fast steps) = 4: (8, 8), 5: (7, 8), 6: (7, 12), 7: (6, 8), 8: (6, 12)
+        const int l0 = variant == 4 ? 8 : (variant <= 6 ? 7 : 6);
+        const size_t lds = (size_t)INF_NT * ((1u << l0) * 2 + 32);
+        static BqLdsAttr at[5];
+        const void* kern = variant == 4 ? reinterpret_cast<const void*>(inflate_rounds2_kernel<8, 8>)
+                         : variant == 5 ? reinterpret_cast<const void*>(inflate_rounds2_kernel<7, 8>)
+                         : variant == 6 ? reinterpret_cast<const void*>(inflate_rounds2_kernel<7, 12>)
+                         : variant == 7 ? reinterpret_cast<const void*>(inflate_rounds2_kernel<6, 8>)
+                                        : reinterpret_cast<const void*>(inflate_rounds2_kernel<6, 12>);
+        if (const int e = at[variant - 4].ensure(kern, lds)) return e;
+        const dim3 grid((n + INF_NT - 1) / INF_NT), block(INF_NT);
+        if (variant == 4) hipLaunchKernelGGL((inflate_rounds2_kernel<8, 8>), grid, block, lds, s, p);
+        else if (variant == 5) hipLaunchKernelGGL((inflate_rounds2_kernel<7, 8>), grid, block, lds, s, p);
+        else if (variant == 6) hipLaunchKernelGGL((inflate_rounds2_kernel<7, 12>), grid, block, lds, s, p);
+        else if (variant == 7) hipLaunchKernelGGL((inflate_rounds2_kernel<6, 8>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((inflate_rounds2_kernel<6, 12>), grid, block, lds, s, p);
+    } else if (variant == 2 || variant == 3) {
         // rounds of a fast and a slow phase; 2: an 8-bit fast table (32 KB of LDS per wave, 4-5 waves per CU), 3: 7 bits (16 KB, 8-10)
         const size_t lds = (size_t)INF_NT * (variant == 2 ? 256 : 128) * 2;
         static BqLdsAttr a2, a3;

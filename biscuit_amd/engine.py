@@ -167,7 +167,7 @@ class Engine:
         self._check(self._lib.bq_png_unfilter(self._ctx, _ptr(rows_u8), n, px, _ptr(out), self._stream()))
         return out
 
-    def png_inflate(self, z, off, length, px=TILE_PX):
+    def png_inflate(self, z, off, length, px=TILE_PX, scratch=None):
         """The zlib streams of n PNG tiles, inflated on the device (``bq_png_inflate``, kernels_inflate.hip: one stream per lane):
         ``z`` uint8 [bytes] -- the packed streams of ``NativeReader.extract_z`` --, ``off`` / ``length`` int32 / uint32 [n], all on
         this device.  Returns ``(rows, status)``: rows uint8 [n, stride] (a tile's px rows of 1 + 3 px bytes, then padding to a
@@ -181,11 +181,25 @@ class Engine:
         rows = torch.empty((n, stride), dtype=torch.uint8, device=self.device)
         status = torch.empty(n, dtype=torch.int32, device=self.device)
         need = int(self._lib.bq_png_inflate_scratch_bytes(n))
-        if getattr(self, '_inflate_ws', None) is None or self._inflate_ws.numel() < need:
-            self._inflate_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if scratch is None:                 # (launches that may overlap on different streams bring their own: ``inflate_scratch``)
+            if getattr(self, '_inflate_ws', None) is None or self._inflate_ws.numel() < need:
+                self._inflate_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            scratch = self._inflate_ws
+        assert scratch.numel() >= need
         self._check(self._lib.bq_png_inflate(self._ctx, _ptr(z), _ptr(off), _ptr(length), n, px, _ptr(rows), stride,
-                                             _ptr(self._inflate_ws), self._inflate_ws.numel(), _ptr(status), self._stream()))
+                                             _ptr(scratch), scratch.numel(), _ptr(status), self._stream()))
         return rows, status
+
+    def inflate_scratch(self, n):
+        """Table space for ``png_inflate`` over up to ``n`` streams (one buffer per launch that may be in flight)."""
+        return torch.empty(int(self._lib.bq_png_inflate_scratch_bytes(int(n))), dtype=torch.uint8, device=self.device)
+
+    def png_unfilter_strided(self, rows, px=TILE_PX):
+        """``png_inflate``'s rows [n, stride] -> uint8 NHWC [n,px,px,3] (``bq_png_unfilter_strided``)."""
+        n = rows.shape[0]
+        out = torch.empty((n, px, px, 3), dtype=torch.uint8, device=self.device)
+        self._check(self._lib.bq_png_unfilter_strided(self._ctx, _ptr(rows), rows.shape[1], n, px, _ptr(out), self._stream()))
+        return out
 
     def png_decode_z(self, z, off, length, px=TILE_PX):
         """Compressed PNG tiles -> uint8 NHWC [n,px,px,3] entirely on the device: ``png_inflate``, then the scanline filters
@@ -418,9 +432,15 @@ class EnginePool:
     flight together; by default every stream owns a disjoint group of XCDs (see __init__ and DESIGN.md).
     Every context owns its weights copy and workspace; results are independent of the stream used."""
 
-    def __init__(self, weights, n_streams=2, cu_split='contig', size_grids=False, **kw):
+    def __init__(self, weights, n_streams=2, cu_split='contig', size_grids=False, reserve_cus=0, decode_streams=2, **kw):
         self.engines = [Engine(weights, **kw) for _ in range(max(1, int(n_streams)))]
         self.size_grids = bool(size_grids)      # persistent grids sized for the CUs of each stream's mask (Engine.set_num_cus)
+        # reserve_cus: the LAST compute units of the chip are kept out of every inference stream's mask (and the persistent grids
+        # are sized for what is left) and handed to `decode_streams` streams of their own: the device inflate's waves run for
+        # ~100 ms each and must not sit on CUs the persistent inference kernels want (inference.evaluate, gpu_decode)
+        self.reserve_cus = int(reserve_cus)
+        self._n_decode_streams = int(decode_streams)
+        self.decode_streams = []
         dev = self.engines[0].device
         # Two streams own disjoint halves of the chip (hipExtStreamCreateWithCUMask; mask bits 0..127 and
         # 128..255 = XCDs 0-3 and 4-7, each with its own L2s): two batches in flight then run side by side
@@ -444,7 +464,7 @@ class EnginePool:
             return self._sets[n]
         dev = self.device
         streams = None
-        if n >= 2 and self.cu_split:
+        if (n >= 2 or self.reserve_cus) and self.cu_split:
             try:
                 streams = self._masked_streams(self.cu_split, dev, n)
             except BiscuitHipError as e:       # scheduling aid only: plain streams compute the same results
@@ -460,9 +480,10 @@ class EnginePool:
         return streams
 
     def _apply_grid_size(self, n):
-        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count - self.reserve_cus
+        sized = self.size_grids or self.reserve_cus > 0
         for k, eng in enumerate(self.engines):
-            eng.set_num_cus(ncu // n if (self.size_grids and k < n and self._masked.get(n)) else 0)
+            eng.set_num_cus(ncu // n if (sized and k < n and self._masked.get(n)) else 0)
 
     def set_in_flight(self, n):
         """Use the first n contexts, each on its own share of the chip (n = 1: one whole-chip stream).
@@ -475,10 +496,15 @@ class EnginePool:
 
     def _masked_streams(self, split, dev, nst):
         streams = []
-        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        ncu_all = torch.cuda.get_device_properties(dev).multi_processor_count
+        ncu = ncu_all - self.reserve_cus
+        if self.reserve_cus and not self.decode_streams:
+            if not 8 <= self.reserve_cus <= ncu_all // 2:
+                raise BiscuitHipError(f'reserve_cus must lie in [8, {ncu_all // 2}]')
+            self.decode_streams = [_mask_stream(self.engines[0], range(ncu, ncu_all), ncu_all) for _ in range(max(1, self._n_decode_streams))]
         for k in range(nst):
             eng = self.engines[k]
-            bits = [0] * ((ncu + 31) // 32)
+            bits = [0] * ((ncu_all + 31) // 32)
             for cu in range(ncu):
                 if split == 'contig':
                     mine = cu * nst // ncu == k
@@ -502,6 +528,10 @@ class EnginePool:
                 if isinstance(st, torch.cuda.ExternalStream):
                     self.engines[k]._lib.bq_stream_destroy(self.engines[k]._ctx, C.c_void_p(st.cuda_stream))
             del self._sets[n]
+        for st in self.decode_streams:
+            st.synchronize()
+            self.engines[0]._lib.bq_stream_destroy(self.engines[0]._ctx, C.c_void_p(st.cuda_stream))
+        self.decode_streams = []
         self.streams = []
 
     def __len__(self):

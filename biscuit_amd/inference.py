@@ -52,10 +52,36 @@ class TFRecordSource:
     tiles [first, first + count) into ``out`` (a uint8 numpy view, usually of page-locked memory) on the reader's thread
     pool.  ``rows``: stop at the inflated PNG scanlines ([count,px,1+3*px]; the GPU reverses the filters).  A slide with
     a record outside the native decoders' subset is decoded whole with Pillow once and served from memory."""
-    def __init__(self, path, n_tiles, tile_px=299, rows=False):
+    def __init__(self, path, n_tiles, tile_px=299, rows=False, z=False):
         self.path, self.n_tiles, self.tile_px, self.rows = path, int(n_tiles), int(tile_px), bool(rows)
+        # z: hand the tiles over COMPRESSED (``read_z``: the records' zlib streams, packed; the device inflates them -- bq_png_inflate);
+        # decided per slide before its first chunk: a slide with a record that is not an 8-bit RGB PNG tile stays on ``read``
+        self.z = bool(z)
         self._reader = None
         self._fallback = None
+
+    def z_ok(self):
+        """True when the whole slide can go the compressed way (every record an 8-bit RGB, non-interlaced PNG of the tile size)."""
+        from . import tfrecord_native as tn
+        if not (self.z and tn.available() and self.n_tiles):
+            return False
+        if self._reader is None:
+            self._reader = tn.NativeReader(self.path)
+        probe = np.zeros(1, np.uint8)
+        off, ln = np.zeros(CHUNK_TILES_Z, np.uint32), np.zeros(CHUNK_TILES_Z, np.uint32)
+        for first in range(0, self.n_tiles, CHUNK_TILES_Z):      # (chunk-wise: the offsets of one call are 32-bit)
+            try:
+                self._reader.extract_z(first, min(CHUNK_TILES_Z, self.n_tiles - first), self.tile_px, probe, off, ln)
+            except MemoryError:
+                continue                                 # (headers fine, only the buffer was too small: as intended)
+            except (tn.UnsupportedImage, ValueError, IOError):
+                return False
+        return True
+
+    def read_z(self, first, count, z, off, length):
+        """The zlib streams of tiles [first, first + count) packed into ``z`` (uint8), offsets / lengths into ``off`` / ``length``
+        (uint32 [count]).  Returns the bytes used; MemoryError (bytes needed in ``.args[1]``) when ``z`` is too small."""
+        return self._reader.extract_z(first, count, self.tile_px, z, off, length)[0]
 
     def chunk_shape(self, count):
         px = self.tile_px
@@ -115,7 +141,7 @@ def pick_unfilter_mode(path, tile_px=299, sample=48):
     return (full < 26000.0 and rows > 1.08 * full), full, rows
 
 
-def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None, gpu_unfilter=None):
+def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None, gpu_unfilter=None, gpu_decode=False):
     """One ``Slide`` per ``*.tfrecords`` file (Slideflow writes one file per slide).  Tiles are
     decoded lazily when the slide's turn comes (``evaluate`` decodes one slide ahead on a host thread);
     only the record headers are scanned up front.  labels: {slide name (file stem): 0/1}.
@@ -131,6 +157,10 @@ def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None
     if gpu_unfilter == 'auto':                          # a short measurement on the first slide decides
         gpu_unfilter = bool(paths) and tile_px <= 341 and torch.cuda.is_available() and pick_unfilter_mode(paths[0], tile_px)[0]
     gpu_unfilter = bool(gpu_unfilter)
+    # gpu_decode (round 5): the host only walks the record framing and copies the PNG tiles' zlib streams; the GPU inflates them
+    # (one stream per lane, on compute units an ``EnginePool(reserve_cus=...)`` keeps out of the inference streams' masks) and
+    # reverses the scanline filters.  For hosts with few cores per GPU: 16 CUs inflate 27-39 k tiles/s (profiles/r05_inflate.txt).
+    gpu_decode = bool(gpu_decode) and bool(pinned)
     out = []
     for path in paths:
         name = os.path.splitext(os.path.basename(path))[0]
@@ -148,7 +178,7 @@ def slides_from_tfrecords(paths, labels, patients=None, tile_px=299, pinned=None
             return tfrecord.read_slide(pth, tile_px)[1]
         out.append(Slide(name, loader, count, y_true=int(labels.get(name, 0)),
                          patient=(patients or {}).get(name),
-                         source=TFRecordSource(path, count, tile_px, rows=gpu_unfilter) if pinned else None))
+                         source=TFRecordSource(path, count, tile_px, rows=gpu_unfilter and not gpu_decode, z=gpu_decode) if pinned else None))
     return out
 
 
@@ -173,6 +203,10 @@ class EvalResult:
 
 CHUNK_TILES = 512        # tiles per pinned buffer: 137 MB at 299 px (a 10^4-tile slide is twenty chunks, never one allocation)
 RAMP_CHUNKS = (128, 256) # the first chunks of a run are short: the GPU starts after 128 decoded tiles (4 ms of the decoder), not 512
+CHUNK_TILES_Z = 4096     # compressed chunks (gpu_decode): one zlib stream per LANE, so a chunk is what keeps the decode CUs' waves full
+RAMP_CHUNKS_Z = (512, 1024, 2048)
+Z_FRACTION = 0.9         # pinned bytes per tile of a compressed chunk, as a fraction of the raw scanlines (a nearly incompressible 299-px
+                         # PNG: 227 KB of 268 KB = 0.85; a photograph-like one 0.58); a chunk that does not fit is cut in two
 RING_SLOTS = 3
 PREFETCH_CHUNKS = 2      # decoded chunks waiting for the GPU (plus the one being decoded)
 
@@ -248,7 +282,24 @@ def _feed_chunks(slides, mine, dev, copy_stream):
                 continue
         return False
 
+    zc = None                                            # the compressed chunk being filled (gpu_decode), if any
+
+    def emit_z():
+        nonlocal zc
+        c, zc = zc, None
+        if c is None or not c['segs']:
+            return True
+        total = c['hdr'] + c['pos']
+        with torch.cuda.stream(copy_stream):
+            d = torch.empty(total, dtype=torch.uint8, device=dev)
+            d.copy_(c['ring'].bufs[c['slot']][:total], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        c['ring'].events[c['slot']] = ev
+        return put((c['segs'], c['cap'], 0, c['n'], d, ev, 'z'))
+
     def work():
+        nonlocal zc
         ring = None
         n_chunks = 0                                     # chunks decoded so far in this run (over all slides)
         try:
@@ -256,6 +307,8 @@ def _feed_chunks(slides, mine, dev, copy_stream):
                 s = slides[si]
                 src = getattr(s, 'source', None)
                 if src is None or s.n_tiles == 0 or copy_stream is None:
+                    if not emit_z():
+                        return
                     if copy_stream is None:
                         item = (li, si, 0, s.n_tiles, s.load(), None, False)
                     else:
@@ -272,6 +325,58 @@ def _feed_chunks(slides, mine, dev, copy_stream):
                     if not put(item):
                         return
                     continue
+                if getattr(src, 'z', False) and src.z_ok():
+                    # compressed chunks: [off u32[cap] | len u32[cap] | packed zlib streams] in one pinned slot, one H2D copy.  A
+                    # chunk runs ACROSS slides (the device inflates one stream per lane: a 1 000-tile slide alone would leave the
+                    # decode CUs' waves mostly empty); item = (segments [(li, si, first, count)], cap, 0, tiles, buffer, event, 'z')
+                    px = src.tile_px
+                    need = CHUNK_TILES_Z * (8 + int(Z_FRACTION * px * (1 + 3 * px))) + 64
+                    if ring is None or ring.nbytes < need:
+                        if not emit_z():
+                            return
+                        if ring is not None:
+                            ring.release()
+                        ring = _PinnedRing.lease(need)
+                    try:
+                        first = 0
+                        while first < s.n_tiles:
+                            if zc is None:
+                                cap = RAMP_CHUNKS_Z[n_chunks] if n_chunks < len(RAMP_CHUNKS_Z) else CHUNK_TILES_Z
+                                n_chunks += 1
+                                slot = ring.acquire()
+                                zc = {'slot': slot, 'buf': ring.bufs[slot].numpy(), 'cap': cap, 'hdr': (8 * cap + 15) & ~15, 'n': 0,
+                                      'pos': 0, 'segs': [], 'px': px, 'ring': ring}
+                            elif zc['px'] != px:
+                                if not emit_z():
+                                    return
+                                continue
+                            k, cap, buf = zc['n'], zc['cap'], zc['buf']
+                            cnt = min(cap - k, s.n_tiles - first)
+                            off = buf[:4 * cap].view(np.uint32)[k:]
+                            ln = buf[4 * cap:8 * cap].view(np.uint32)[k:]
+                            room = buf[zc['hdr'] + zc['pos']:ring.nbytes]
+                            while cnt:
+                                try:
+                                    used = src.read_z(first, cnt, room, off, ln)
+                                    break
+                                except MemoryError:
+                                    if cnt == 1 and not zc['segs']:
+                                        raise
+                                    cnt //= 2                      # (tiles that compress worse than the slot was sized for)
+                            if cnt:
+                                off[:cnt] += np.uint32(zc['pos'])
+                                zc['segs'].append((li, si, first, cnt))
+                                zc['n'] += cnt
+                                zc['pos'] += used
+                                first += cnt
+                            if not cnt or zc['n'] == cap:
+                                if not emit_z():
+                                    return
+                    finally:
+                        src.close()
+                    continue
+                if not emit_z():                                   # (a slide that goes the decoded way: what is open goes first)
+                    return
                 per = int(np.prod(src.chunk_shape(1)))
                 px = getattr(src, 'tile_px', None)
                 need = max(CHUNK_TILES * per, _PinnedRing.chunk_bytes(px) if px else 0)
@@ -299,7 +404,8 @@ def _feed_chunks(slides, mine, dev, copy_stream):
                         first += cnt
                 finally:
                     src.close()
-            put(None)
+            if emit_z():
+                put(None)
         except BaseException as e:                   # noqa: BLE001 -- re-raised in the consumer
             put(e)
         finally:
@@ -434,23 +540,45 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     import contextlib
     copy_stream = torch.cuda.Stream(device=dev) if torch.device(dev).type == 'cuda' else None
 
+    # gpu_decode: compressed chunks are inflated on the pool's decode streams (CU-masked: the compute units it keeps out of the
+    # inference streams; without a pool, the current stream), round-robin, each with its own table scratch; the status words are
+    # looked at once, at the end
+    z_state = {'k': 0, 'scratch': {}, 'status': []}
+
+    def decode_z(buf, cap, count, ev, px, segs):
+        eng0 = engines[0]
+        dstreams = getattr(pool, 'decode_streams', None) if pool else None
+        main = torch.cuda.current_stream(dev)
+        dec = dstreams[z_state['k'] % len(dstreams)] if dstreams else main
+        z_state['k'] += 1
+        off = buf[:4 * count].view(torch.int32)
+        ln = buf[4 * cap:4 * cap + 4 * count].view(torch.int32)
+        z = buf[(8 * cap + 15) & ~15:]
+        dec.wait_event(ev)
+        buf.record_stream(dec)
+        key = dec.cuda_stream
+        with torch.cuda.stream(dec):
+            if key not in z_state['scratch'] or z_state['scratch'][key].numel() < eng0._lib.bq_png_inflate_scratch_bytes(count):
+                z_state['scratch'][key] = eng0.inflate_scratch(max(count, CHUNK_TILES_Z))
+            rows, status = eng0.png_inflate(z, off, ln, px=px, scratch=z_state['scratch'][key])
+            done = torch.cuda.Event()
+            done.record(dec)
+        main.wait_event(done)
+        rows.record_stream(main)
+        z_state['status'].append((segs, status))
+        return eng0.png_unfilter_strided(rows, px=px)
+
     def stream_slides():
         nonlocal pend_n, rows_slide, rows_true
         cur_stream = (lambda: torch.cuda.current_stream(dev)) if copy_stream is not None else None
-        for li, si, first, count, loaded, ev, is_rows in _feed_chunks(slides, mine, dev, copy_stream):
+        def push(li, si, first, count, t):
+            nonlocal pend_n, rows_slide, rows_true
             s = slides[si]
-            if ev is not None:                       # made on the copy stream: order it before this stream's work
-                cur_stream().wait_event(ev)
-                loaded.record_stream(cur_stream())
-                t = engines[0].png_unfilter(loaded) if is_rows else loaded.contiguous()
-            elif isinstance(loaded, PngRows):        # filtered PNG scanlines: H2D, then the filters are reversed on the device
-                t = engines[0].png_unfilter(_to_device(loaded.rows, dev))
-            else:
-                t = _to_device(loaded, dev)
-            assert t.shape[0] == count, (s.name, t.shape, count)
             if count == 0:
-                continue
-            pend_tiles.append(t)
+                return
+            if t is not None:                        # (None: the tiles are part of a tensor that is already in the list)
+                assert t.shape[0] == count, (s.name, t.shape, count)
+                pend_tiles.append(t)
             pend_sidx.append(torch.full((count,), li, dtype=torch.int32, device=dev))
             pend_gidx.append(offsets[si] + first + np.arange(count, dtype=np.int64))
             pend_n += count
@@ -459,6 +587,26 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 rows_true += [s.y_true] * count
                 if s.loc is not None:
                     rows_loc.append(np.asarray(s.loc)[first:first + count])
+
+        for li, si, first, count, loaded, ev, is_rows in _feed_chunks(slides, mine, dev, copy_stream):
+            if is_rows == 'z':                       # a compressed chunk: inflate on the decode CUs, un-filter here
+                segs, cap = li, si
+                t = decode_z(loaded, cap, count, ev, slides[segs[0][1]].source.tile_px, segs)
+                assert t.shape[0] == count == sum(c for *_, c in segs)
+                pend_tiles.append(t)
+                for (li, si, first, c) in segs:
+                    push(li, si, first, c, None)
+                flush()
+                continue
+            if ev is not None:                       # made on the copy stream: order it before this stream's work
+                cur_stream().wait_event(ev)
+                loaded.record_stream(cur_stream())
+                t = engines[0].png_unfilter(loaded) if is_rows else loaded.contiguous()
+            elif isinstance(loaded, PngRows):        # filtered PNG scanlines: H2D, then the filters are reversed on the device
+                t = engines[0].png_unfilter(_to_device(loaded.rows, dev))
+            else:
+                t = _to_device(loaded, dev)
+            push(li, si, first, count, t)
             flush()
         flush(final=True)
 
@@ -469,6 +617,16 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
 
     if pool:
         pool.synchronize()
+    for segs, status in z_state['status']:          # (one look at the end: a stream the device refused is a damaged PNG)
+        bad = torch.nonzero(status).flatten().tolist()
+        if bad:
+            at, where = 0, None
+            for (_, si, first, c) in segs:
+                if at <= bad[0] < at + c:
+                    where = f'{slides[si].name}, tile {first + bad[0] - at}'
+                at += c
+            raise IOError(f'the device inflate refused {len(bad)} tile(s) (first: {where}, status {int(status[bad[0]])}): damaged PNG '
+                          f'data; decode on the host (gpu_decode=False) to see the decoder\'s own error')
     live = [a for a in acc if a is not None]
     if live:
         # per-stream fixed-point accumulators are integers: their sum is exact and order-free

@@ -17,7 +17,7 @@ from biscuit_amd.weights import synthetic_weights
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=[0, 1, 2, 3], ids=['tables_in_l2', 'direct_tables_in_lds', 'rounds_l0_8bit', 'rounds_l0_7bit'])
+@pytest.fixture(scope='module', params=[0, 1, 2, 3, 4, 5], ids=['tables_in_l2', 'direct_tables_in_lds', 'rounds_l0_8bit', 'rounds_l0_7bit', 'rounds2_8bit', 'rounds2_7bit'])
 def eng(request):
     from biscuit_amd.engine import Engine
     e = Engine(synthetic_weights(1), dtype='f16', max_batch=8, max_mc=2)
@@ -139,3 +139,66 @@ def test_png_tiles_from_a_tfrecord_equal_the_host_decoder(eng, tmp_path):
                                    torch.from_numpy(ln.view(np.int32)).cuda())
     assert not status.cpu().numpy().any()
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+def _slides_on_disk(tmp_path, n_slides, per, seed):
+    from biscuit_amd.synthetic import make_slides
+    tiles, sidx, y = make_slides(n_slides, per, seed=seed)
+    paths = []
+    for i in range(n_slides):
+        p = str(tmp_path / f'z{i}.tfrecords')
+        tfr.write_slide(p, f'z{i}', tiles[sidx == i])
+        paths.append(p)
+    return paths, {f'z{i}': int(y[i]) for i in range(n_slides)}
+
+
+@pytest.mark.parametrize('pooled', [False, True], ids=['one_engine', 'pool_with_decode_cus'])
+def test_evaluate_from_compressed_chunks_equals_host_decoded_tiles(tmp_path, pooled, monkeypatch):
+    """``slides_from_tfrecords(gpu_decode=True)``: the host copies zlib streams, the device inflates and un-filters -- the same tile
+    table and slide results, bit for bit, as the host decoder's tiles; with an ``EnginePool(reserve_cus=16)`` the inflate runs on
+    CU-masked streams of its own.  A slide holding a JPEG record goes to the host decoder as a whole.  Small compressed chunks so
+    that several are in flight and a slide spans chunks."""
+    import io
+    from PIL import Image
+    from biscuit_amd import inference as inf
+    from biscuit_amd.engine import Engine, EnginePool
+    monkeypatch.setattr(inf, 'CHUNK_TILES_Z', 8)
+    monkeypatch.setattr(inf, 'RAMP_CHUNKS_Z', (3, 5))
+    paths, labels = _slides_on_disk(tmp_path, 3, 19, seed=31)
+    # a fourth slide with one JPEG among its PNG records
+    t = make_tiles(4, seed=8)
+    b = io.BytesIO(); Image.fromarray(t[2]).save(b, format='JPEG', quality=92)
+    pj = str(tmp_path / 'zj.tfrecords')
+    tfr.write_slide(pj, 'zj', [tfr.encode_image(t[0]), tfr.encode_image(t[1]), b.getvalue(), tfr.encode_image(t[3])])
+    paths.append(pj); labels['zj'] = 1
+    w = synthetic_weights(1)
+    if pooled:
+        e = EnginePool(w, n_streams=2, reserve_cus=16, dtype='f16', max_batch=16, max_mc=5)
+        assert len(e.decode_streams) == 2
+    else:
+        e = Engine(w, dtype='f16', max_batch=16, max_mc=5)
+    a = inf.evaluate(e, inf.slides_from_tfrecords(paths, labels, gpu_decode=True), outcome='cohort', mc_n=5, seed=3, batch=16)
+    ref = inf.evaluate(e, inf.slides_from_tfrecords(paths, labels), outcome='cohort', mc_n=5, seed=3, batch=16)
+    assert list(a.slide_count) == [19, 19, 19, 4]
+    for col in ('cohort-y_pred1', 'cohort-uncertainty1'):
+        assert np.array_equal(a.tile_df[col].to_numpy(), ref.tile_df[col].to_numpy()), col
+    assert np.array_equal(a.slide_pred, ref.slide_pred) and np.array_equal(a.slide_unc, ref.slide_unc)
+    srcs = [s.source for s in inf.slides_from_tfrecords(paths, labels, gpu_decode=True)]
+    assert [s.z_ok() for s in srcs] == [True, True, True, False]
+    if pooled:
+        e.close()
+
+
+def test_a_damaged_stream_fails_the_run_loudly(tmp_path):
+    """One flipped byte inside a tile's zlib stream: the device path raises (at the end of the run, from the status words) --
+    never a silently wrong tile."""
+    from biscuit_amd import inference as inf
+    from biscuit_amd.engine import Engine
+    raws = [bytearray(tfr.encode_image(t)) for t in make_tiles(6, seed=5)]
+    at = raws[4].find(b'IDAT') + 2000
+    raws[4][at] ^= 0x5a
+    path = str(tmp_path / 'd.tfrecords')
+    tfr.write_slide(path, 'd', [bytes(r) for r in raws])
+    e = Engine(synthetic_weights(1), dtype='f16', max_batch=8, max_mc=2)
+    with pytest.raises(IOError, match='device inflate refused 1 tile'):
+        inf.evaluate(e, inf.slides_from_tfrecords([path], {'d': 1}, gpu_decode=True), outcome='cohort', mc_n=2, seed=3, batch=8)
