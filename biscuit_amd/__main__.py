@@ -92,6 +92,10 @@ def main(argv=None):
     ap.add_argument('--params', help="Slideflow params.json: its norm_fit switches on the reinhard_fast stain normaliser (hp.py:19)")
     ap.add_argument('--tile-uq', type=float, default=0.0, help='tile-level uncertainty threshold (0 = off)')
     ap.add_argument('--slide-uq', type=float, default=0.0, help='slide-level uncertainty threshold (0 = off)')
+    ap.add_argument('--gpu-decode', type=int, default=0, metavar='CUS',
+                    help='decode PNG tiles on the GPU: the host only copies their zlib streams, CUS compute units (16-32) kept out of '
+                         'the inference streams inflate them.  For hosts with few free cores per GPU and runs of >= 30 k tiles; '
+                         'slower than 16 host threads otherwise (profiles/r05_inflate.txt)')
     ap.add_argument('--no-calibrate', action='store_true',
                     help='f16 with external weights: skip the activation-exponent calibration on the first tiles (the headroom check stays)')
     args = ap.parse_args(argv)
@@ -119,7 +123,7 @@ def main(argv=None):
         labels = dict(zip(lab['slide'], lab['label']))
         patients = dict(zip(lab['slide'], lab['patient'])) if 'patient' in lab.columns else None
         paths = sorted(glob.glob(os.path.join(args.tfrecords, '*.tfrecords')))
-        slides = slides_from_tfrecords(paths, labels, patients)
+        slides = slides_from_tfrecords(paths, labels, patients, gpu_decode=args.gpu_decode > 0)
     else:
         s, t = (int(x) for x in args.synthetic.lower().split('x'))
         tiles, sidx, y = make_slides(s, t, seed=0)
@@ -148,7 +152,7 @@ def main(argv=None):
                 big = {t: k for t, k in act_exp.items() if k}
                 print(f'f16: activation exponents from the first {len(probe)} tiles (peak {max(peaks.values()):.3g}): {big}', flush=True)
     pool = EnginePool(w, n_streams=args.streams, hp=hp, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc, device=local,
-                      act_exp=act_exp)
+                      act_exp=act_exp, reserve_cus=max(0, args.gpu_decode))
     if probe is not None:
         import torch
         t = torch.from_numpy(probe[:8]).to(pool.engines[0].device)
