@@ -1,4 +1,5 @@
-"""Fill the R05_* placeholders of DESIGN.md from profiles/<tag>_bench.json (python tools/fill_design.py r05 <cpu tests> <gpu tests>)."""
+"""DESIGN.md and README.md from their templates (tools/templates/*.in: the text, with R05_* placeholders where a measured number goes) and
+profiles/<tag>_bench.json: python tools/fill_design.py r05 <cpu tests> <gpu tests>.  Edit the TEMPLATES, then run this."""
 import json, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 d = json.load(open(f'profiles/{tag}_bench.json'))
@@ -29,11 +30,11 @@ rep = {
     'R05_DEC': f"{t['decode_only_tiles_per_s'] / 1e3:.1f} k tiles/s ({t['decode_rows_only_tiles_per_s'] / 1e3:.1f} k stopping at the scanlines)",
     'R05_HOST': f"{d['host_tiles']['value'] / 1e3:.1f} k tiles/s",
 }
-s = open('DESIGN.md').read()
+s = open('tools/templates/DESIGN.md.in').read()
 for k in sorted(rep, key=len, reverse=True):
     s = s.replace(k, rep[k])
 open('DESIGN.md', 'w').write(s)
-r = open('README.md').read()
+r = open('tools/templates/README.md.in').read()
 line = (f"{d['value']:,.0f} tiles/s ({d['ms_per_step']:.2f} ms per batch; bf16 {d['bf16_value']:,.0f}), {d['with_reinhard_value']:,.0f} with the `reinhard_fast` "
         f"stain normaliser in the timed region, {d['full_mode_value']:,.0f} with the reference's loop structure (30 complete passes), {d['f32_value']:,.0f} on the "
         f"exact fp32 kernels, {d['host_tiles']['value'] / 1e3:.1f} k when the decoded tiles start in pageable host memory (the PCIe-inclusive rate), "
