@@ -42,6 +42,9 @@
 #ifndef WIDE_ABLATE
 #define WIDE_ABLATE 0
 #endif
+#ifndef WIDE_ZERO_PAD
+#define WIDE_ZERO_PAD 1
+#endif
 
 namespace {
 using namespace bqk;
@@ -534,6 +537,17 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             *reinterpret_cast<uint4*>(smem + OFF_RAW + RAW_BYTES + (wave + WN * t) * 1024 + voff) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
+#if WIDE_ZERO_PAD
+    // A rows past the tile's last pixel (76..79 of 80) are never written: whatever LDS held goes through the MFMAs of every k-step
+    // and is thrown away.  Zeros cost the matrix pipe less energy than noise (the kernel runs against the power management).
+    if constexpr (TR * IW < MT) {
+        constexpr int NB = (MT - TR * IW) * A_STR / 16;          // 16-byte pieces per buffer
+        for (int i = tid; i < 2 * NB; i += 64 * WN) {
+            const int b = i / NB, k = i - b * NB;
+            *reinterpret_cast<uint4*>(smem + OFF_A + b * A_BYTES + TR * IW * A_STR + k * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+#endif
     f32x4v acc[MF][RN];                                          // first written by the first k-step's MFMAs (C = 0)
 
     WSTAMP(1);
