@@ -534,6 +534,9 @@ def run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks):
 
     def tiles_of(i, count):
         def load():
+            if count <= npool:                                   # a window of the resident tiles: no copy (a gather of 1 000 tiles
+                start = (i * T) % (npool - count + 1)            # through index_select took 0.9 ms, 2 % of config 3's run)
+                return allt[start:start + count]
             idx = (torch.arange(count, device=dev) + i * T) % npool
             return allt.index_select(0, idx)
         return load

@@ -427,6 +427,19 @@ def _feed_chunks(slides, mine, dev, copy_stream):
         th.join(timeout=30)
 
 
+def _take_front(parts, k, cat):
+    """(the first k rows of the arrays in ``parts``, what is left of the list): views where possible, ``cat`` only over the pieces of a
+    front that spans several arrays."""
+    out, i = [], 0
+    while k > 0:
+        t = parts[i]
+        if t.shape[0] <= k:
+            out.append(t); k -= t.shape[0]; i += 1
+        else:
+            out.append(t[:k]); parts = parts[:i] + [t[k:]] + parts[i + 1:]; k = 0
+    return (out[0] if len(out) == 1 else cat(out)), parts[i:]
+
+
 def _to_device(t, device):
     if torch.is_tensor(t):
         return t.to(device=device, dtype=torch.uint8, non_blocking=True).contiguous()
@@ -467,13 +480,14 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     def flush(final=False):
         nonlocal pend_tiles, pend_sidx, pend_gidx, pend_n, n_batches
         while pend_n >= batch or (final and pend_n > 0):
-            tiles = torch.cat(pend_tiles) if len(pend_tiles) > 1 else pend_tiles[0]
-            sidx = torch.cat(pend_sidx) if len(pend_sidx) > 1 else pend_sidx[0]
-            gidx = np.concatenate(pend_gidx)
             take = min(batch, pend_n)
-            cur, rest = tiles[:take].contiguous(), tiles[take:]
-            cs, rs = sidx[:take].contiguous(), sidx[take:]
-            cg, rg = gidx[:take], gidx[take:]
+            # the first `take` rows of what is pending: a VIEW when they lie in one tensor, one batch-sized copy when the batch spans
+            # two (round 4 concatenated everything pending -- a 1 000-tile slide behind a 200-tile remainder: 330 MB copied to cut 256
+            # tiles off the front, 0.11 ms per batch in config 3's trace)
+            cur, pend_tiles = _take_front(pend_tiles, take, torch.cat)
+            cs, pend_sidx = _take_front(pend_sidx, take, torch.cat)
+            cg, pend_gidx = _take_front(pend_gidx, take, np.concatenate)
+            cur, cs = cur.contiguous(), cs.contiguous()
             # global tile indices inside a batch are contiguous per slide but not across
             # slides: run one bq_mc_infer per contiguous run so the Philox counter is exact
             mean = torch.empty((take, 2), dtype=torch.float32, device=dev)
@@ -514,9 +528,7 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             n_batches += 1
             if keep_tiles:          # device tensors; copied to the host once everything has been enqueued
                 rows_mean.append(mean); rows_std.append(std)
-            pend_tiles, pend_sidx, pend_gidx = ([rest] if rest.shape[0] else []), \
-                ([rs] if rs.shape[0] else []), ([rg] if rg.shape[0] else [])
-            pend_n = rest.shape[0]
+            pend_n -= take
 
     # With a pool, everything this function itself enqueues (H2D copies, concatenations, a device-side loader) goes to
     # a side stream, not to the default stream: the pool's CU-masked streams are ordinary (blocking) HIP streams, and
