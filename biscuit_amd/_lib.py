@@ -51,6 +51,7 @@ ABI = {
     'bq_backbone_u8': (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
     'bq_mc_head': (_i, [_vp, _vp, _i, _i64, _i, _i, _u64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'bq_set_tile_index_ptr': (_i, [_vp, _vp]),
+    'bq_set_tile_index_array': (_i, [_vp, _vp]),
     'bq_mc_infer': (_i, [_vp, _vp, _i, _i64, _i, _u64, _i, _vp, _vp, _vp, _sz, _vp]),
     'bq_mc_infer_part': (_i, [_vp, _vp, _i, _i64, _i, _u64, _i, _vp, _vp, _vp, _sz, _vp]),
     'bq_slide_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),

@@ -54,6 +54,7 @@ struct bq_ctx {
     int num_cus = 256;
     float* d_srgb_lut = nullptr;   // tables of the Reinhard normaliser
     const long long* d_tile0 = nullptr;   // bq_set_tile_index_ptr
+    const long long* d_tile_idx = nullptr;   // bq_set_tile_index_array
     int head_variant = 2;          // bq_set_option("head_variant"): 0 = stages in lock step, 1 / 2 = producer and matrix stage overlapped (2: the
                                    // waves that share a SIMD in opposite stages; bit-identical, 1-7 % faster: tools/ab_head.py)
     int inflate_variant = 5;       // bq_set_option("inflate_variant"): 0 = tables in global memory, 1 = direct tables mirrored in LDS, 2-8 = rounds of a
@@ -633,12 +634,12 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
                      4.0 * ((layer == 0 ? (double)n : (double)rows) * K + (double)rows * 1024 + (double)K * 1024));
         const int e = launch_head_dense(layer == 0 ? feat : h0, G.wh, G.wl, G.bias, layer == 0 ? h0 : h1, rows, K, mc_n, pass0,
                                         layer == 0 ? 1 : 0, layer, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), thresh,
-                                        dscale, tile0, c->d_tile0, s, c->head_variant);
+                                        dscale, tile0, c->d_tile0, c->d_tile_idx, s, c->head_variant);
         if (e) return fail(c, BQ_ERR_HIP, std::string("head dense launch: ") + hipGetErrorString((hipError_t)e));
     }
     {
         ProfScope ps(c, s, "mc_head_softmax_welford", 2.0 * rows * 1024 * 2, 4.0 * rows * 1024);
-        if (launch_head_final(h1, n, mc_n, pass0, tile0, c->d_tile0, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32),
+        if (launch_head_final(h1, n, mc_n, pass0, tile0, c->d_tile0, c->d_tile_idx, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32),
                               thresh, dscale, c->logits_w, c->logits_b, init, finalize, state, mean2, std2, s))
             return fail(c, BQ_ERR_HIP, "head_final launch failed");
     }
@@ -1002,6 +1003,12 @@ int bq_mc_head(bq_ctx* c, const float* d_feat, int n, int64_t tile_idx0, int mc_
 int bq_set_tile_index_ptr(bq_ctx* c, const int64_t* d_tile_idx0) {
     if (!c) return BQ_ERR_ARG;
     c->d_tile0 = reinterpret_cast<const long long*>(d_tile_idx0);
+    return BQ_OK;
+}
+
+int bq_set_tile_index_array(bq_ctx* c, const int64_t* d_tile_idx) {
+    if (!c) return BQ_ERR_ARG;
+    c->d_tile_idx = reinterpret_cast<const long long*>(d_tile_idx);
     return BQ_OK;
 }
 

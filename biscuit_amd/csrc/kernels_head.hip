@@ -40,6 +40,7 @@ struct HeadParams {
     float dscale;
     long long tile0;
     const long long* tile0_dev;
+    const long long* tile_idx;  // per-tile Philox indices [tiles] (bq_set_tile_index_array) or null: tile i counts as tile0 + i
 };
 
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
@@ -64,6 +65,7 @@ __global__ void __launch_bounds__(512) head_dense_kernel(const HeadParams p) {
     const bool plive = pm < p.rows;
     const int ptile = plive ? pm / p.mc_n : 0;
     const int ppass = p.pass0 + (plive ? pm - ptile * p.mc_n : 0);
+    const unsigned pctr = (unsigned)(tile0 + (p.tile_idx ? p.tile_idx[ptile] : (long long)ptile));   // the Philox tile counter of this row
     const float* prow_ptr = p.in + (size_t)(p.in_row_is_tile ? ptile : (plive ? pm : 0)) * p.K;
 
     f32x16 acc1[2][2], acc2[2][2];
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(512) head_dense_kernel(const HeadParams p) {
                     const int gi = (half * 8 + i) * 8 + pseg;
                     const int g = (k0 >> 2) + gi;               // Philox group = unit / 4
                     unsigned rnd[4];
-                    philox4x32_10((unsigned)g, (unsigned)p.layer, (unsigned)ppass, (unsigned)(tile0 + ptile), p.seed_lo, p.seed_hi, rnd);
+                    philox4x32_10((unsigned)g, (unsigned)p.layer, (unsigned)ppass, pctr, p.seed_lo, p.seed_hi, rnd);
                     const float f0 = (plive && rnd[0] >= p.thresh) ? v[i].x * p.dscale : 0.f;
                     const float f1 = (plive && rnd[1] >= p.thresh) ? v[i].y * p.dscale : 0.f;
                     const float f2 = (plive && rnd[2] >= p.thresh) ? v[i].z * p.dscale : 0.f;
@@ -193,6 +195,7 @@ __global__ void __launch_bounds__(512) head_dense_pipe_kernel(const HeadParams p
     const bool plive = pm < p.rows;
     const int ptile = plive ? pm / p.mc_n : 0;
     const int ppass = p.pass0 + (plive ? pm - ptile * p.mc_n : 0);
+    const unsigned pctr = (unsigned)(tile0 + (p.tile_idx ? p.tile_idx[ptile] : (long long)ptile));   // the Philox tile counter of this row
     const float* prow_ptr = p.in + (size_t)(p.in_row_is_tile ? ptile : (plive ? pm : 0)) * p.K;
 
     f32x16 acc1[2][2], acc2[2][2];
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(512) head_dense_pipe_kernel(const HeadParams p
             const int gi = i * 8 + pseg;
             const int g = (k0 >> 2) + gi;
             unsigned rnd[4];
-            philox4x32_10((unsigned)g, (unsigned)p.layer, (unsigned)ppass, (unsigned)(tile0 + ptile), p.seed_lo, p.seed_hi, rnd);
+            philox4x32_10((unsigned)g, (unsigned)p.layer, (unsigned)ppass, pctr, p.seed_lo, p.seed_hi, rnd);
             const float f0 = (plive && rnd[0] >= p.thresh) ? v[i].x * p.dscale : 0.f;
             const float f1 = (plive && rnd[1] >= p.thresh) ? v[i].y * p.dscale : 0.f;
             const float f2 = (plive && rnd[2] >= p.thresh) ? v[i].z * p.dscale : 0.f;
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(512) head_dense_pipe_kernel(const HeadParams p
 // One Dense(1024, relu) layer of the MC head over `rows` = tiles x passes rows.  K = 2048 (layer 0) or 1024 (layer 1).
 int launch_head_dense(const float* in, const void* wh, const void* wl, const float* bias, float* out, int rows, int K,
                       int mc_n, int pass0, int in_row_is_tile, int layer, unsigned seed_lo, unsigned seed_hi, unsigned thresh,
-                      float dscale, long long tile0, const long long* tile0_dev, hipStream_t s, int variant) {
+                      float dscale, long long tile0, const long long* tile0_dev, const long long* tile_idx, hipStream_t s, int variant) {
     if (rows <= 0) return 0;
     if (K % HKC != 0 || !wh || !wl || !bias) return (int)hipErrorInvalidValue;
     HeadParams p;
@@ -317,7 +320,7 @@ int launch_head_dense(const float* in, const void* wh, const void* wl, const flo
     p.bias = bias; p.out = out; p.rows = rows; p.K = K;
     p.mc_n = mc_n; p.pass0 = pass0; p.in_row_is_tile = in_row_is_tile; p.layer = layer;
     p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.thresh = thresh; p.dscale = dscale;
-    p.tile0 = tile0; p.tile0_dev = tile0_dev;
+    p.tile0 = tile0; p.tile0_dev = tile0_dev; p.tile_idx = tile_idx;
     if ((variant == 1 || variant == 2) && K % PKC == 0) {
         constexpr size_t ldsp = 4 * (size_t)PPLANE;
         static BqLdsAttr a1, a2;

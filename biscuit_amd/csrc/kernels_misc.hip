@@ -299,7 +299,8 @@ __global__ void __launch_bounds__(256) gap_kernel(const T* __restrict__ x, int n
 constexpr int kHeadFinalWaves = 8;
 __global__ void __launch_bounds__(64 * kHeadFinalWaves) head_final_kernel(const float* __restrict__ h1, int n, int mc_n,
                                                          int pass0, long long tile0_imm,
-                                                         const long long* __restrict__ tile0_dev, unsigned seed_lo,
+                                                         const long long* __restrict__ tile0_dev,
+                                                         const long long* __restrict__ tile_idx, unsigned seed_lo,
                                                          unsigned seed_hi, unsigned thresh, float dscale,
                                                          const float* __restrict__ w2,
                                                          const float* __restrict__ b2, int init,
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(64 * kHeadFinalWaves) head_final_kernel(const 
     __shared__ float probs[kHeadFinalWaves][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x;
-    const long long tile0 = tile0_imm + (tile0_dev ? *tile0_dev : 0);
+    const unsigned tctr = (unsigned)(tile0_imm + (tile0_dev ? *tile0_dev : 0) + (tile_idx ? tile_idx[tile] : (long long)tile));
     float wa[16], wb[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(64 * kHeadFinalWaves) head_final_kernel(const 
                 const int g = lane + 64 * j;  // Philox group = unit / 4
                 const float4 v = *reinterpret_cast<const float4*>(row + 4 * g);
                 unsigned r[4];
-                philox4x32_10((unsigned)g, 2u, (unsigned)(pass0 + p), (unsigned)(tile0 + tile), seed_lo,
+                philox4x32_10((unsigned)g, 2u, (unsigned)(pass0 + p), tctr, seed_lo,
                               seed_hi, r);
                 const float f0 = r[0] >= thresh ? v.x * dscale : 0.f;
                 const float f1 = r[1] >= thresh ? v.y * dscale : 0.f;
@@ -532,12 +533,12 @@ int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, float m
     return (int)hipGetLastError();
 }
 
-int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, const long long* tile0_dev,
+int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, const long long* tile0_dev, const long long* tile_idx,
                       unsigned seed_lo,
                       unsigned seed_hi, unsigned thresh, float dscale, const float* w2, const float* b2,
                       int init, int finalize, float* state, float* mean2, float* std2, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(head_final_kernel, dim3(n), dim3(64 * kHeadFinalWaves), 0, s, h1, n, mc_n, pass0, tile0, tile0_dev,
+    hipLaunchKernelGGL(head_final_kernel, dim3(n), dim3(64 * kHeadFinalWaves), 0, s, h1, n, mc_n, pass0, tile0, tile0_dev, tile_idx,
                        seed_lo, seed_hi, thresh, dscale, w2, b2, init, finalize, state, mean2, std2);
     return (int)hipGetLastError();
 }

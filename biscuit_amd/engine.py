@@ -257,9 +257,9 @@ class Engine:
                                              self._stream()))
         return feat
 
-    def mc_head(self, feat, mc_n, seed, tile_idx0=0, out=None):
+    def mc_head(self, feat, mc_n, seed, tile_idx0=0, out=None, tile_idx=None):
         """GAP features [n,2048] -> (mean[n,2], std[n,2]) over mc_n dropout passes; the Philox tile counter of row i
-        is tile_idx0 + i.  ``out``: (mean, std) to write into (contiguous [n,2] fp32 views are fine)."""
+        is tile_idx0 + i, or tile_idx0 + tile_idx[i] with ``tile_idx`` (int64 [n], device).  ``out``: (mean, std) to write into (contiguous [n,2] fp32 views are fine)."""
         assert feat.dtype == torch.float32 and feat.is_cuda and feat.is_contiguous()
         n = feat.shape[0]
         ws = self._ws_for(n, mc_n)
@@ -270,9 +270,10 @@ class Engine:
         else:
             mean, std = out
             assert mean.is_contiguous() and std.is_contiguous() and mean.shape == (n, 2) and std.shape == (n, 2)
-        self._check(self._lib.bq_mc_head(self._ctx, _ptr(feat), n, int(tile_idx0), int(mc_n), 0,
-                                         int(seed), 1, 1, _ptr(state), _ptr(mean), _ptr(std), _ptr(ws),
-                                         ws.numel(), self._stream()))
+        with self._tile_index_array(tile_idx, n):
+            self._check(self._lib.bq_mc_head(self._ctx, _ptr(feat), n, int(tile_idx0), int(mc_n), 0,
+                                             int(seed), 1, 1, _ptr(state), _ptr(mean), _ptr(std), _ptr(ws),
+                                             ws.numel(), self._stream()))
         return mean, std
 
     def set_tile_index_ptr(self, idx_tensor):
@@ -283,8 +284,27 @@ class Engine:
             assert idx_tensor.dtype == torch.int64 and idx_tensor.is_cuda and idx_tensor.numel() == 1
         self._check(self._lib.bq_set_tile_index_ptr(self._ctx, _ptr(idx_tensor)))
 
-    def mc_infer(self, tiles_u8, mc_n, seed, tile_idx0=0, mc_mode='head', out=None):
-        """uint8 NHWC tiles (device) -> (mean[n,2], std[n,2]) on device."""
+    def _tile_index_array(self, tile_idx, n):
+        """Context manager: per-tile Philox indices (int64 [n] on this device, or None) for the calls made inside
+        (``bq_set_tile_index_array``; the kernels take the pointer when they are LAUNCHED, the tensor has to outlive them)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            if tile_idx is None:
+                yield
+                return
+            assert tile_idx.dtype == torch.int64 and tile_idx.is_cuda and tile_idx.is_contiguous() and tile_idx.numel() == n
+            self._check(self._lib.bq_set_tile_index_array(self._ctx, _ptr(tile_idx)))
+            try:
+                yield
+            finally:
+                self._lib.bq_set_tile_index_array(self._ctx, None)
+        return scope()
+
+    def mc_infer(self, tiles_u8, mc_n, seed, tile_idx0=0, mc_mode='head', out=None, tile_idx=None):
+        """uint8 NHWC tiles (device) -> (mean[n,2], std[n,2]) on device.  ``tile_idx``: the tiles' Philox indices (int64 [n], device)
+        when they are not ``tile_idx0 + row`` -- a batch across slide boundaries."""
         assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda and tiles_u8.is_contiguous()
         n = tiles_u8.shape[0]
         ws = self._ws_for(n, mc_n)
@@ -294,9 +314,10 @@ class Engine:
         else:
             mean, std = out
         mode = _lib.BQ_MC_HEAD if mc_mode == 'head' else _lib.BQ_MC_FULL
-        self._check(self._lib.bq_mc_infer(self._ctx, _ptr(tiles_u8), n, int(tile_idx0), int(mc_n),
-                                          int(seed), mode, _ptr(mean), _ptr(std), _ptr(ws), ws.numel(),
-                                          self._stream()))
+        with self._tile_index_array(tile_idx, n):
+            self._check(self._lib.bq_mc_infer(self._ctx, _ptr(tiles_u8), n, int(tile_idx0), int(mc_n),
+                                              int(seed), mode, _ptr(mean), _ptr(std), _ptr(ws), ws.numel(),
+                                              self._stream()))
         return mean, std
 
     def mc_infer_part(self, part, tiles_u8, mc_n, seed, tile_idx0=0, out=None):

@@ -496,23 +496,22 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             starts = np.concatenate([[0], brk]); ends = np.concatenate([brk, [take]])
             k = n_batches % len(engines)
 
-            def work(eng, cur=cur):
+            # a batch that spans slides holds tiles whose global indices are not one consecutive run: the backbone does not care,
+            # the head's Philox counter does -- it takes the indices as an array then (bq_set_tile_index_array): ONE launch sequence
+            # per batch whatever its composition (round 4: one head call per run, 4 x the head time with 64-tile slides), and a
+            # tile's result does not depend on batch size, sharding or rank count
+            gdev = None
+            if len(starts) > 1:
+                gdev = torch.from_numpy(np.ascontiguousarray(cg)).to(dev, non_blocking=True) if torch.device(dev).type == 'cuda' \
+                    else torch.from_numpy(np.ascontiguousarray(cg))
+
+            def work(eng, cur=cur, gdev=gdev):
                 if norm_fit is not None:
                     cur = eng.reinhard_fast(cur, norm_fit['target_means'], norm_fit['target_stds'])
-                if len(starts) == 1:
+                if gdev is None:
                     eng.mc_infer(cur, mc_n, seed, tile_idx0=int(cg[0]), mc_mode=mc_mode, out=(mean, std))
-                elif mc_mode == 'head':
-                    # a batch that spans slides: the backbone does not care (one launch sequence for the whole
-                    # batch), only the head's Philox counter does -- one head call per run of consecutive indices.
-                    # bq_backbone_u8 = the kernels mc_infer runs (16-bit: the fused front kernel), so a tile's result
-                    # does not depend on which branch its batch took, i.e. on batch size, sharding or rank count
-                    feat = eng.backbone_u8(cur)
-                    for a, b in zip(starts, ends):
-                        eng.mc_head(feat[a:b], mc_n, seed, tile_idx0=int(cg[a]), out=(mean[a:b], std[a:b]))
                 else:
-                    for a, b in zip(starts, ends):
-                        eng.mc_infer(cur[a:b], mc_n, seed, tile_idx0=int(cg[a]), mc_mode=mc_mode,
-                                     out=(mean[a:b], std[a:b]))
+                    eng.mc_infer(cur, mc_n, seed, tile_idx0=0, mc_mode=mc_mode, out=(mean, std), tile_idx=gdev)
                 acc[k] = eng.slide_reduce(mean, std, cs, max(n_local, 1), tile_uq=tile_uq, acc=acc[k])
             if pool:
                 # these tensors were allocated on the caller's stream and are read on the pool's: tell the
@@ -520,7 +519,7 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 # batch's kernels are still in flight
                 st = getattr(pool, 'streams', None)
                 if st and cur.is_cuda:
-                    for t in (cur, cs, mean, std):
+                    for t in (cur, cs, mean, std) + ((gdev,) if gdev is not None else ()):
                         t.record_stream(st[k])
                 pool.run(n_batches, work, wait_for_current=True)
             else:

@@ -161,6 +161,13 @@ int bq_mc_head(bq_ctx* ctx, const float* d_feat, int n, int64_t tile_idx0, int m
  * loop of results.py:250-258) can then be replayed for tile after tile by updating 8 bytes of device memory. */
 int bq_set_tile_index_ptr(bq_ctx* ctx, const int64_t* d_tile_idx0);
 
+/* Optional per-tile Philox indices for the bq_mc_head / bq_mc_infer calls that follow (NULL: back to consecutive indices; the array
+ * -- int64 [n of the call], device memory -- must stay valid while launches enqueued with it are in flight): the tile counter of
+ * row i becomes tile_idx0 (+ *d_tile_idx0) + d_tile_idx[i] instead of ... + i.  A batch that holds the ends and beginnings of
+ * several slides -- tiles whose global indices are not one consecutive run -- then takes ONE call instead of one head call per run
+ * (biscuit_amd.inference.evaluate; results identical to the per-run calls, tests/test_gpu_parity.py). */
+int bq_set_tile_index_array(bq_ctx* ctx, const int64_t* d_tile_idx);
+
 /* Fused convenience: uint8 tiles -> (mean[n,2], std[n,2]).  mc_mode BQ_MC_HEAD runs
  * the backbone once and the head mc_n times; BQ_MC_FULL re-runs the whole network per
  * pass like the reference loop.  Results are bit-identical between the two. */

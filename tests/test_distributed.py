@@ -22,35 +22,16 @@ class StandInEngine:
         self.device = torch.device('cpu')
         self.calls = []
 
-    def mc_infer(self, tiles, mc_n, seed, tile_idx0=0, mc_mode='head', out=None):
+    def mc_infer(self, tiles, mc_n, seed, tile_idx0=0, mc_mode='head', out=None, tile_idx=None):
         n = tiles.shape[0]
-        g = torch.arange(tile_idx0, tile_idx0 + n, dtype=torch.float64)
+        # (a batch across slide boundaries brings its tiles' global indices as an array: Engine.mc_infer(tile_idx=...))
+        g = torch.arange(tile_idx0, tile_idx0 + n, dtype=torch.float64) if tile_idx is None else tile_idx.double() + tile_idx0
         p1 = tiles.reshape(n, -1).double().mean(1) / 255.0
         unc = ((g * 0.6180339887) % 1.0) * 0.05 + 0.001 * mc_n
         mean, std = out
         mean[:, 1] = p1.float(); mean[:, 0] = 1 - p1.float()
         std[:, 0] = unc.float(); std[:, 1] = unc.float()
-        self.calls.append((int(tile_idx0), n))
-        return mean, std
-
-    # a batch that spans non-adjacent slides runs the backbone once and the head per run of consecutive indices
-    def stage(self, tiles):
-        return tiles
-
-    def backbone(self, staged):
-        return staged.reshape(staged.shape[0], -1).double().mean(1, keepdim=True) / 255.0     # the "features"
-
-    def backbone_u8(self, tiles):        # (Engine.backbone_u8: the kernels mc_infer runs, straight from the bytes)
-        return self.backbone(self.stage(tiles))
-
-    def mc_head(self, feat, mc_n, seed, tile_idx0=0, out=None):
-        n = feat.shape[0]
-        g = torch.arange(tile_idx0, tile_idx0 + n, dtype=torch.float64)
-        unc = ((g * 0.6180339887) % 1.0) * 0.05 + 0.001 * mc_n
-        mean, std = out
-        mean[:, 1] = feat[:, 0].float(); mean[:, 0] = 1 - feat[:, 0].float()
-        std[:, 0] = unc.float(); std[:, 1] = unc.float()
-        self.calls.append((int(tile_idx0), n))
+        self.calls.append([int(x) for x in g.tolist()])           # the global indices this call covered
         return mean, std
 
     def slide_reduce(self, mean2, std2, slide_idx, n_slides, tile_uq=None, acc=None):
@@ -119,8 +100,8 @@ def test_streaming_single_process(batch):
     assert list(res.slide_count) == list(cnt)
     assert len(res.tile_df) == sum(cnt)
     assert list(res.tile_df.columns)[:2] == ['slide', 'cohort-y_true0']
-    # every mc_infer call covered a run of consecutive global indices, all tiles exactly once
-    seen = sorted(sum([list(range(a, a + n)) for a, n in eng.calls], []))
+    # one mc_infer call per batch (a batch across slides brings its indices as an array), all tiles exactly once
+    seen = sorted(sum(eng.calls, []))
     assert seen == list(range(sum(cnt)))
     # slide table in first-appearance order, empty slide dropped
     sf, _ = res.slide_frame()
@@ -233,7 +214,7 @@ def test_eight_rank_gloo_gather(counts, batch):
         # every call covered a run of consecutive GLOBAL tile indices; all of the rank's tiles exactly once
         off = D.global_tile_offsets(counts)
         want = sorted(sum([list(range(int(off[i]), int(off[i]) + counts[i])) for i in loc], []))
-        assert sorted(sum([list(range(a, a + n)) for a, n in calls], [])) == want
+        assert sorted(sum(calls, [])) == want
     assert sorted(covered) == list(range(len(counts)))
     if len(set(counts)) == 1:
         # equal slides: contiguous blocks, so a batch that spans slides is ONE run of indices --

@@ -40,8 +40,8 @@ def _free_port():
 # ------------------------------------------------------------------------------------------------ config 3
 # [9, 4, 0, 7, 5, 3] partitions into contiguous runs of slides; [9, 3, 7, 4, 5] does not (rank 0 gets slides 0 and 3, rank 1
 # slides 1, 2 and 4): rank 0's second batch is tile 8 of slide 0 + the four tiles of slide 3, two runs of Philox tile indices --
-# evaluate()'s multi-run branch (features once through bq_backbone_u8, one head call per run), which in an f16 / bf16 context
-# must run the same fused front kernel as bq_mc_infer does for the single-run batches of the one-rank reference
+# one bq_mc_infer call with the indices as an array (bq_set_tile_index_array; round 4: features once, one head call per run):
+# the same kernels as the single-run batches of the one-rank reference, so the same bits
 @pytest.mark.parametrize('counts,dtype', [([9, 4, 0, 7, 5, 3], 'bf16'), ([9, 3, 7, 4, 5], 'f16'), ([9, 3, 7, 4, 5], 'bf16')])
 def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, counts, dtype):
     from _rank_worker import build_slides

@@ -382,6 +382,28 @@ def test_split_entry_points_equal_mc_infer_bit_for_bit(engines, tiles, dtype):
     assert torch.equal(out[0], m) and torch.equal(out[1], s)
 
 
+@pytest.mark.parametrize('dtype,mode', [('f16', 'head'), ('f32', 'head'), ('f16', 'full')])
+def test_tile_index_array_equals_one_call_per_run(engines, tiles, dtype, mode):
+    """bq_set_tile_index_array: a batch whose Philox tile indices are not consecutive -- the end of one slide, a whole short
+    one, the beginning of a third -- in ONE call, equal bit for bit to one call per run of consecutive indices (what evaluate()
+    did up to round 4) and to the array form of the head alone; the array is dropped again after the call."""
+    eng = engines[dtype]
+    d = dev(tiles)
+    n = d.shape[0]
+    runs = [(0, 2, 1000), (2, 3, 77), (3, n, 5_000_000_000)]           # (from, to, first global index): the last one needs 64 bits
+    idx = torch.cat([torch.arange(g, g + (b - a), dtype=torch.int64) for a, b, g in runs]).cuda()
+    m = torch.empty((n, 2), dtype=torch.float32, device='cuda'); s = torch.empty_like(m)
+    for a, b, g in runs:
+        eng.mc_infer(d[a:b].contiguous(), 5, 31, tile_idx0=g, mc_mode=mode, out=(m[a:b], s[a:b]))
+    m1, s1 = eng.mc_infer(d, 5, 31, mc_mode=mode, tile_idx=idx)
+    assert torch.equal(m1, m) and torch.equal(s1, s)
+    if mode == 'head':
+        m2, s2 = eng.mc_head(eng.backbone_u8(d), 5, 31, tile_idx=idx)
+        assert torch.equal(m2, m) and torch.equal(s2, s)
+    m3, s3 = eng.mc_infer(d[:2].contiguous(), 5, 31, tile_idx0=1000, mc_mode=mode)        # (no array left behind)
+    assert torch.equal(m3, m[:2]) and torch.equal(s3, s[:2])
+
+
 @pytest.mark.parametrize('n', [1, 5])
 def test_ragged_batch_sizes(engines, oracles, n):
     """Batches that do not fill a pixel tile / a row fragment (n = 1: 361 pixels at 19x19) and odd n."""
