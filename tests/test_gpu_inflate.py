@@ -202,3 +202,46 @@ def test_a_damaged_stream_fails_the_run_loudly(tmp_path):
     e = Engine(synthetic_weights(1), dtype='f16', max_batch=8, max_mc=2)
     with pytest.raises(IOError, match='device inflate refused 1 tile'):
         inf.evaluate(e, inf.slides_from_tfrecords([path], {'d': 1}, gpu_decode=True), outcome='cohort', mc_n=2, seed=3, batch=8)
+
+
+def test_mutated_streams_agree_with_zlib_and_terminate(eng):
+    """A seeded fuzz: valid streams of every block kind with 1-3 random byte edits (plus truncations) -- the bytes of a damaged file.
+    Every lane must come back (the launch ends), and the verdict must be zlib's: status 0 with zlib's bytes where ``decompress``
+    returns exactly the expected length, non-zero where it raises or returns another length."""
+    px = 24
+    n_out = px * (1 + 3 * px)
+    rng = np.random.default_rng(2024)
+    base = []
+    for nm, raw in payloads(px, rng).items():
+        for level in (1, 6, 9):
+            base.append(zlib.compress(raw, level))
+        if nm == 'text':                                          # a 512-byte window
+            c = zlib.compressobj(6, zlib.DEFLATED, 9)
+            base.append(c.compress(raw) + c.flush())
+        else:
+            base.append(zlib.compress(raw, 0))                    # stored blocks
+    streams = []
+    for i in range(1536):
+        s = bytearray(base[i % len(base)])
+        for _ in range(int(rng.integers(1, 4))):
+            s[int(rng.integers(0, len(s)))] = int(rng.integers(0, 256))
+        if i % 7 == 0:
+            s = s[:int(rng.integers(1, len(s)))]
+        if len(s) < 2:
+            s = bytearray(b'\x78\x9c')
+        streams.append(bytes(s))
+    got, status = run(eng, streams, px)
+    torch.cuda.synchronize()
+    n_ok = 0
+    for i, s in enumerate(streams):
+        try:
+            d = zlib.decompressobj()
+            ref = d.decompress(s) + d.flush()
+            ok = d.eof and len(ref) == n_out and not d.unused_data
+        except zlib.error:
+            ok = False
+        assert (status[i] == 0) == ok, (i, int(status[i]), ok)
+        if ok:
+            n_ok += 1
+            assert got[i].tobytes() == ref, i
+    assert 0 < n_ok < len(streams)          # the corpus holds both survivors and casualties
