@@ -927,7 +927,7 @@ int bq_png_inflate(bq_ctx* c, const uint8_t* d_z, const uint32_t* d_off, const u
     if (scratch_bytes < inflate_scratch_bytes(n)) return fail(c, BQ_ERR_WORKSPACE, "bq_png_inflate: scratch too small");
     ProfScope ps(c, (hipStream_t)stream, "png_inflate", 0.0, (double)n * row_bytes * 2.0);
     const int e = launch_inflate(d_z, d_off, d_len, n, d_rows, (unsigned)row_bytes, (unsigned)rows_stride, d_scratch, d_status, (hipStream_t)stream,
-                                 c->inflate_variant);
+                                 c->inflate_variant, (unsigned)(1 + 3 * px));
     if (e) return fail(c, BQ_ERR_HIP, std::string("png inflate launch: ") + hipGetErrorString((hipError_t)e));
     return BQ_OK;
 }

@@ -128,7 +128,8 @@ int launch_png_unfilter(const unsigned char* rows, int n, int px, unsigned char*
 // kernels_inflate.hip: n zlib streams (packed, 16-byte aligned starts) -> n x out_len bytes, Adler-32 verified; status 0 = ok
 size_t inflate_scratch_bytes(int n);
 int launch_inflate(const unsigned char* d_z, const unsigned* d_off, const unsigned* d_len, int n, unsigned char* d_out, unsigned out_len,
-                   unsigned out_stride, void* d_scratch, int* d_status, hipStream_t s, int variant = 0);
+                   unsigned out_stride, void* d_scratch, int* d_status, hipStream_t s, int variant = 0, unsigned row_len = 0);
+// (row_len != 0: the outputs are PNG scanlines of that length; a filter-type byte above 4 is flagged too)
 int launch_stem1(const void* in_nchw, int n, const float* w27x32, const float* scale,
                  const float* bias, void* out_nhwc, int dtype, hipStream_t s);
 int launch_pool_add(const void* y, const void* res, void* out, int n, int Hi, int Wi, int C,

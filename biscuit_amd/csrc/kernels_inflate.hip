@@ -36,7 +36,7 @@ constexpr int SCR_LT = 0, SCR_DT = LT_CAP, SCR_LENS = SCR_DT + DT_CAP, SCR_CODES
               SCR_WORDS = SCR_SUB + 128;
 
 enum { INF_OK = 0, INF_BAD_HEADER = 1, INF_BAD_BLOCK = 2, INF_BAD_TABLE = 3, INF_BAD_CODE = 4, INF_BAD_DISTANCE = 5, INF_OVERRUN = 6,
-       INF_LENGTH = 7, INF_TRAILING = 8, INF_ADLER = 9 };
+       INF_LENGTH = 7, INF_TRAILING = 8, INF_ADLER = 9, INF_FILTER = 10 };
 
 __device__ __forceinline__ unsigned entry(unsigned value, unsigned flags, unsigned extra, unsigned nbits) {
     return (value << 16) | flags | (extra << 8) | nbits;
@@ -178,6 +178,7 @@ struct InflateParams {
     unsigned* scratch;             // [n][SCR_WORDS]
     int* status;                   // [n]: INF_*
     int n;
+    unsigned row_len;              // PNG scanline length (1 + 3 px) whose filter-type bytes are checked, or 0
 };
 
 // the bit reader of one lane: 64 bits, refilled a dword at a time; the dword after next is already on its way when one is used
@@ -869,6 +870,13 @@ __global__ void __launch_bounds__(64) adler_kernel(const InflateParams p) {
         const unsigned want = ((unsigned)t[0] << 24) | ((unsigned)t[1] << 16) | ((unsigned)t[2] << 8) | t[3];
         if (((bb << 16) | a) != want) p.status[i] = INF_ADLER;
     }
+    // PNG scanlines (row_len = 1 + 3 px): a filter-type byte above 4 is a damaged file for every PNG decoder -- the host reader
+    // refuses it (tfrecord_reader.cpp: png_finish), the un-filter kernel would read it as "None"
+    if (p.row_len) {
+        bool bad = false;
+        for (unsigned r = lane; r * p.row_len < n; r += 64) bad |= out[(size_t)r * p.row_len] > 4;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0 && p.status[i] == INF_OK) p.status[i] = INF_FILTER;
+    }
 }
 
 }  // namespace
@@ -878,11 +886,11 @@ size_t inflate_scratch_bytes(int n) { return (size_t)(n > 0 ? n : 0) * SCR_WORDS
 // n zlib streams -> n x out_len bytes.  d_z / d_off / d_len: the packed input (see InflateParams); d_out: [n][out_stride] with
 // out_stride >= out_len + 4 and a multiple of 4; d_scratch: inflate_scratch_bytes(n); d_status: [n] (0 = inflated and verified).
 int launch_inflate(const unsigned char* d_z, const unsigned* d_off, const unsigned* d_len, int n, unsigned char* d_out, unsigned out_len,
-                   unsigned out_stride, void* d_scratch, int* d_status, hipStream_t s, int variant) {
+                   unsigned out_stride, void* d_scratch, int* d_status, hipStream_t s, int variant, unsigned row_len) {
     if (n <= 0) return 0;
     if (out_stride < out_len + 4 || (out_stride & 3)) return (int)hipErrorInvalidValue;
     InflateParams p;
-    p.z = d_z; p.off = d_off; p.len = d_len; p.out = d_out; p.out_len = out_len; p.out_stride = out_stride;
+    p.z = d_z; p.off = d_off; p.len = d_len; p.out = d_out; p.out_len = out_len; p.out_stride = out_stride; p.row_len = row_len;
     p.scratch = reinterpret_cast<unsigned*>(d_scratch); p.status = d_status; p.n = n;
     if (variant >= 4 && variant <= 8) {
         // the rounds with the short fast phase: (fast-table bits, fast steps) = 4: (8, 8), 5: (7, 8), 6: (7, 12), 7: (6, 8), 8: (6, 12)

@@ -119,7 +119,8 @@ int bq_png_unfilter(bq_ctx* ctx, const uint8_t* d_rows, int n, int px, uint8_t* 
  * non-interlaced PNG tiles, as libbiscuit_io's bqio_extract_z packs them: stream i = d_z[d_off[i] .. d_off[i] + d_len[i]), every
  * d_off[i] a multiple of 16, 32 readable bytes behind every stream -- are inflated to their px rows of 1 + 3 px bytes at d_rows +
  * i * rows_stride (rows_stride a multiple of 4, >= px (1 + 3 px) + 4), one stream per lane.  d_status[i] = 0 iff stream i is a
- * well-formed zlib stream that inflates to exactly px (1 + 3 px) bytes with a matching Adler-32 (what zlib's uncompress() accepts);
+ * well-formed zlib stream that inflates to exactly px (1 + 3 px) bytes with a matching Adler-32 (what zlib's uncompress() accepts)
+ * and every row's filter-type byte is 0..4 (what a PNG decoder accepts);
  * any other value: the tile's rows are undefined and the caller decodes that record on the host.  d_scratch: table space,
  * bq_png_inflate_scratch_bytes(n).  Follow with bq_png_unfilter_strided.  No reference counterpart (tf.io.decode_png under tf.data). */
 size_t bq_png_inflate_scratch_bytes(int n);

@@ -50,7 +50,12 @@ def payloads(px, rng):
     run1 = b'\x05' * n                                                                    # distance 1 (overlapping copies)
     text = (b'the quick brown fox jumps over the lazy dog. ' * (n // 45 + 1))[:n]
     skew = rng.choice(np.arange(256, dtype=np.uint8), n, p=np.r_[[0.9], np.full(255, 0.1 / 255)]).tobytes()   # one 1-bit code, many 12+ bit codes
-    return {'noise': noise, 'narrow': narrow, 'period7': period, 'run': run1, 'text': text, 'skew': skew}
+
+    def scanlines(raw):          # every row starts with a PNG filter type (0..4): bq_png_inflate flags anything else
+        a = np.frombuffer(raw, np.uint8).copy()
+        a[::1 + 3 * px] %= 5
+        return a.tobytes()
+    return {k: scanlines(v) for k, v in {'noise': noise, 'narrow': narrow, 'period7': period, 'run': run1, 'text': text, 'skew': skew}.items()}
 
 
 @pytest.mark.parametrize('px', [8, 64, 299])
@@ -81,9 +86,13 @@ def test_what_zlib_refuses_is_flagged(eng):
     px = 64
     n = px * (1 + 3 * px)
     rng = np.random.default_rng(1)
-    raw = np.clip(rng.normal(128, 20, n), 0, 255).astype(np.uint8).tobytes()
+    arr = np.clip(rng.normal(128, 20, n), 0, 255).astype(np.uint8)
+    arr[::1 + 3 * px] %= 5                                                               # rows start with a filter type 0..4
+    raw = arr.tobytes()
     good = zlib.compress(raw, 6)
     cases = {'good': good}
+    bad_ft = arr.copy(); bad_ft[17 * (1 + 3 * px)] = 5                                   # a well-formed stream whose row 17 has filter type 5:
+    cases['filter_type'] = zlib.compress(bad_ft.tobytes(), 6)                            # zlib is content, no PNG decoder is
     cases['adler'] = good[:-1] + bytes([good[-1] ^ 1])                                   # trailer off by one bit
     cases['truncated'] = good[: len(good) // 2]
     cases['trailing'] = good + b'\x00\x01'
@@ -104,8 +113,8 @@ def test_what_zlib_refuses_is_flagged(eng):
             ok = len(ref) == n
         except zlib.error:
             ref, ok = None, False
-        if nm in ('trailing',):                                                          # zlib.decompress tolerates trailing bytes;
-            ok = False                                                                   # uncompress()-style strictness here
+        if nm in ('trailing', 'filter_type'):                                            # zlib.decompress tolerates trailing bytes
+            ok = False                                                                   # (uncompress()-style strictness here)
         assert (status[i] == 0) == ok, (nm, int(status[i]), ok)
         if ok:
             assert got[i].tobytes() == ref, nm
@@ -237,7 +246,7 @@ def test_mutated_streams_agree_with_zlib_and_terminate(eng):
         try:
             d = zlib.decompressobj()
             ref = d.decompress(s) + d.flush()
-            ok = d.eof and len(ref) == n_out and not d.unused_data
+            ok = d.eof and len(ref) == n_out and not d.unused_data and max(ref[::1 + 3 * px]) <= 4
         except zlib.error:
             ok = False
         assert (status[i] == 0) == ok, (i, int(status[i]), ok)
