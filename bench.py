@@ -399,6 +399,14 @@ def run(args):
             'bytes_per_tile': BYTES_PER_TILE_BF16, 'flop_per_tile': flop_tile}
 
     solo = world == 1 and rank == 0
+    leg_s = {}                                          # wall seconds of the extra legs (what a default run spends where)
+    t_leg = time.perf_counter()
+
+    def leg_done(name):
+        nonlocal t_leg
+        now = time.perf_counter()
+        leg_s[name] = round(now - t_leg, 1)
+        t_leg = now
     # the other MC structure on the same kernels (N=1 only; a few steps)
     if solo:
         other = 'full' if args.mode == 'head' else 'head'
@@ -410,6 +418,7 @@ def run(args):
         dt3 = timed(args.mode, K, stain=True)
         out['with_reinhard_value'] = K * B / dt3
         out['with_reinhard_ms_per_step'] = dt3 / K * 1e3
+    leg_done('other_mode_and_stain')
 
     # per-kernel roofline: HIP events on the launch stream around every launch
     if not args.no_profile and rank == 0:
@@ -485,6 +494,7 @@ def run(args):
         out['entry_side_floor_ms'] = sum(e.bytes * e.launches for e in entry) / psteps / PEAK_HBM_MEASURED * 1e3
         out['entry_side_kernels'] = sorted(e.name for e in entry)
 
+    leg_done('kernel_profile')
     if solo and not args.no_extras:
         out['b1_latency'] = b1_latency(eng, args.mc)
         pool_e.synchronize()
@@ -501,19 +511,25 @@ def run(args):
             pe2.synchronize()
             pe2.close()
             del pe2
+        leg_done('other_dtypes')
         try:
             out['tfrecords'] = tfrecord_leg(pool_e, args)
         except Exception as e:                                  # an extra leg never takes the headline down
             out['tfrecords'] = {'error': f'{type(e).__name__}: {e}'}
+        leg_done('tfrecords')
         try:
             out['host_tiles'] = host_tiles_leg(pool_e, args)
         except Exception as e:
             out['host_tiles'] = {'error': f'{type(e).__name__}: {e}'}
+        leg_done('host_tiles')
 
     if solo and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(weights, args.mc, seed, args.cpu_tiles, args.cpu_budget)
         out['speedup_vs_cpu_full'] = (out.get('full_mode_value') or value) / out['cpu_baseline']['value']
         out['speedup_headline_vs_cpu_full'] = value / out['cpu_baseline']['value']
+        leg_done('cpu_baseline')
+    if leg_s:
+        out['leg_seconds'] = leg_s
 
     if rank == 0:
         print(json.dumps(out))

@@ -41,7 +41,22 @@ def crc32c(data: bytes) -> int:
     return c ^ 0xFFFFFFFF
 
 
+_NATIVE_CRC = None
+
+
 def masked_crc(data: bytes) -> int:
+    """TFRecord's masked CRC-32C.  Payloads go through libbiscuit_io when it is there (slicing-by-8: a 227 KB PNG record costs
+    0.1 ms instead of the 20 ms of the byte loop above -- writing the benchmark's 16 384 records took three minutes of it)."""
+    global _NATIVE_CRC
+    if len(data) >= 64:
+        if _NATIVE_CRC is None:
+            try:
+                from . import tfrecord_native
+                _NATIVE_CRC = tfrecord_native.lib().bqio_masked_crc32c if tfrecord_native.available() else False
+            except Exception:                                    # noqa: BLE001 -- the pure-Python form below always works
+                _NATIVE_CRC = False
+        if _NATIVE_CRC:
+            return int(_NATIVE_CRC(bytes(data), len(data)))
     c = crc32c(data)
     return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
 
