@@ -205,6 +205,7 @@ CHUNK_TILES = 512        # tiles per pinned buffer: 137 MB at 299 px (a 10^4-til
 RAMP_CHUNKS = (128, 256) # the first chunks of a run are short: the GPU starts after 128 decoded tiles (4 ms of the decoder), not 512
 CHUNK_TILES_Z = 4096     # compressed chunks (gpu_decode): one zlib stream per LANE, so a chunk is what keeps the decode CUs' waves full
 RAMP_CHUNKS_Z = (512, 1024, 2048)
+Z_SLOT_MAX = 1 << 30      # bytes of one pinned slot of the compressed ring at most (three slots are leased)
 Z_FRACTION = 0.9         # pinned bytes per tile of a compressed chunk, as a fraction of the raw scanlines (a nearly incompressible 299-px
                          # PNG: 227 KB of 268 KB = 0.85; a photograph-like one 0.58); a chunk that does not fit is cut in two
 RING_SLOTS = 3
@@ -330,7 +331,7 @@ def _feed_chunks(slides, mine, dev, copy_stream):
                     # chunk runs ACROSS slides (the device inflates one stream per lane: a 1 000-tile slide alone would leave the
                     # decode CUs' waves mostly empty); item = (segments [(li, si, first, count)], cap, 0, tiles, buffer, event, 'z')
                     px = src.tile_px
-                    need = CHUNK_TILES_Z * (8 + int(Z_FRACTION * px * (1 + 3 * px))) + 64
+                    need = min(CHUNK_TILES_Z * (8 + int(Z_FRACTION * px * (1 + 3 * px))) + 64, Z_SLOT_MAX)   # (larger tiles: chunks of fewer)
                     if ring is None or ring.nbytes < need:
                         if not emit_z():
                             return
