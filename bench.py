@@ -75,6 +75,8 @@ def parse_args(argv=None):
     ap.add_argument('--slides', type=int, default=1600, help='cfg3: number of synthetic slides')
     ap.add_argument('--tiles-per-slide', type=int, default=TILES_PER_SLIDE, help='cfg3: tiles per slide')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ragged', action='store_true', help='cfg3: slides of unequal tile counts (T - (7 i mod T/2)): LPT shards are not contiguous')
+    ap.add_argument('--no-table', action='store_true', help='cfg3: skip the second run that also writes the tile table')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the reinhard / f32 / B=1 / TFRecord legs')
     ap.add_argument('--cpu-tiles', type=int, default=128, help='batch of the CPU baseline (hp.py:7: 128)')
@@ -556,7 +558,9 @@ def run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks):
             idx = (torch.arange(count, device=dev) + i * T) % npool
             return allt.index_select(0, idx)
         return load
-    slides = [Slide(f's{i:05d}', tiles_of(i, T), T, y_true=i % 2) for i in range(S)]
+    counts = [T - (7 * i) % max(T // 2, 1) for i in range(S)] if args.ragged else [T] * S
+    slides = [Slide(f's{i:05d}', tiles_of(i, c), c, y_true=i % 2) for i, c in enumerate(counts)]
+    NT = sum(counts)
     wt = min(T, 2 * B)
     warm = [Slide(f'w{i}', tiles_of(i, wt), wt, y_true=0) for i in range(world * max(4, args.warmup))]
     # batches in flight: calibrated like config 2's loop -- the warm-up slides once with two batches on half the chip each,
@@ -578,20 +582,61 @@ def run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks):
                    rank=rank, world=world)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
-    assert int(res.slide_count.sum()) == S * T and np.isfinite(res.slide_pred).all()
-    parts = D.partition_slides([T] * S, world)
-    steps = max(-(-len(p) * T // B) for p in parts)
+    assert int(res.slide_count.sum()) == NT and np.isfinite(res.slide_pred).all()
+    # the same run WITH the path's product: the tile table streamed to disk while the GPU works (every rank its shard, closed before
+    # the all-gather; rank 0 splices them into tile_predictions_eval.csv) -- rows written and the file closed inside the timed region
+    table = None
+    if not args.no_table:
+        import shutil
+        import tempfile
+        # one directory all ranks of this run derive by themselves (no object collective): the rendezvous port names the run
+        tdir = os.path.join(tempfile.gettempdir(), f"bq_table_{os.environ.get('MASTER_PORT', 'p')}_{os.getppid() if world > 1 else os.getpid()}")
+        os.makedirs(tdir, exist_ok=True)
+        try:
+            barrier()
+            t0 = time.perf_counter()
+            rt = evaluate(pool_e, slides, mc_n=args.mc, seed=1234, batch=B, mc_mode=args.mode, keep_tiles=False,
+                          rank=rank, world=world, save_dir=tdir)
+            barrier()
+            dtt = max_over_ranks(time.perf_counter() - t0)
+            assert np.array_equal(rt.slide_pred, res.slide_pred) and np.array_equal(rt.slide_unc, res.slide_unc)
+            if rank == 0:
+                nbytes = os.path.getsize(rt.table_path)
+                with open(rt.table_path, 'rb') as f:
+                    nrows = sum(chunk.count(b'\n') for chunk in iter(lambda: f.read(1 << 24), b'')) - 1
+                assert nrows == NT, (nrows, NT)
+                import hashlib
+                hs = hashlib.sha256()
+                with open(rt.table_path, 'rb') as f:
+                    for chunk in iter(lambda: f.read(1 << 24), b''):
+                        hs.update(chunk)
+                table = {'sha256': hs.hexdigest(), 'with_table_value': NT / dtt, 'seconds': dtt, 'rows': nrows, 'bytes': nbytes,
+                         'ratio_to_value': dt / dtt, 'file': os.path.basename(rt.table_path),
+                         'note': 'evaluate(save_dir=...): rows formatted and written by libbiscuit_io on a host thread while the GPU '
+                                 'works; at N > 1 per-rank shards closed before the all-gather, spliced by rank 0 -- all inside the time'}
+        finally:
+            barrier()
+            if rank == 0:
+                shutil.rmtree(tdir, ignore_errors=True)
+    parts = D.partition_slides(counts, world)
+    steps = max(-(-sum(counts[i] for i in p) // B) for p in parts)
     return {'metric': 'tiles/sec at MC-dropout=30, 299x299x3 (Xception, slide-level pred/sigma reduce)',
-            'value': S * T / dt, 'unit': 'tiles/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup,
+            'value': NT / dt, 'unit': 'tiles/s', 'n_gpus': world, 'steps': steps, 'warmup': args.warmup,
             'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic', 'seconds': dt,
+            'with_table_value': table['with_table_value'] if table else None, 'tile_table': table,
+            # the slide table every rank holds after the gather, as a digest: equal at every world size (Philox counters are global
+            # tile indices, the slide sums order-free fixed point)
+            'slide_table_sha256': __import__('hashlib').sha256(np.ascontiguousarray(res.slide_pred).tobytes()
+                                                               + np.ascontiguousarray(res.slide_unc).tobytes()).hexdigest(),
             'config': {'workload': f'BASELINE.json config 3: {S} synthetic slides x {T} tiles (299x299x3), LPT-sharded over '
                                    f'{world} GPU(s), Xception {args.dtype} + fp32 MC head, MC={args.mc}, batch={B}, through '
                                    f'biscuit_amd.inference.evaluate', 'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B,
-                       'slides_per_rank': [len(p) for p in parts], 'hip_streams': len(pool_e),
+                       'slides_per_rank': [len(p) for p in parts], 'tiles_per_rank': [sum(counts[i] for i in p) for p in parts],
+                       'ragged': bool(args.ragged), 'hip_streams': len(pool_e),
                        'parallelism': f'slide-sharded dp{world}, one all-gather of slide (pred, sigma, n)'},
-            'path_roofline': {'hbm_frac': S * T / dt / world * BYTES_PER_TILE_BF16 / PEAK_HBM if args.dtype in HALF else None,
-                              'mfma_frac': S * T / dt / world * (FLOP_BACKBONE + args.mc * FLOP_HEAD_PASS) /
+            'path_roofline': {'hbm_frac': NT / dt / world * BYTES_PER_TILE_BF16 / PEAK_HBM if args.dtype in HALF else None,
+                              'mfma_frac': NT / dt / world * (FLOP_BACKBONE + args.mc * FLOP_HEAD_PASS) /
                               (PEAK_BF16 if args.dtype in HALF else PEAK_F32)}}
 
 
@@ -741,17 +786,24 @@ def tfrecord_leg(pool_e, args, n_slides=32, tiles_per_slide=1024, n_files=8):
         # first on a box otherwise looks slower (round 3 read +23 % into that once)
         evaluate(pool_e, slides[:2], mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False)
         evaluate(pool_e, gslides[:2], mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False)
-        th, tg = [], []
+        th, tg, tt = [], [], []
         for rep in range(3):
             t0 = time.perf_counter()
-            res = evaluate(pool_e, slides, mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=(rep == 0))
+            res = evaluate(pool_e, slides, mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False)
             th.append(time.perf_counter() - t0)
             assert int(res.slide_count.sum()) == n
             t0 = time.perf_counter()
             evaluate(pool_e, gslides, mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False)
             tg.append(time.perf_counter() - t0)
-        dt, gdt = sorted(th)[1], sorted(tg)[1]
+            # the same run with the path's product: the tile table streamed to disk, file closed inside the time
+            t0 = time.perf_counter()
+            rt = evaluate(pool_e, gslides if auto else slides, mc_n=args.mc, seed=1234, batch=args.batch, keep_tiles=False,
+                          save_dir=os.path.join(d, 'table'))
+            tt.append(time.perf_counter() - t0)
+            assert rt.table_rows == n
+        dt, gdt, tdt = sorted(th)[1], sorted(tg)[1], sorted(tt)[1]
         return {'tiles': n, 'value': n / dt, 'unit': 'tiles/s', 'gpu_unfilter_value': n / gdt,
+                'with_table_value': n / tdt, 'with_table_ratio': (gdt if auto else dt) / tdt, 'runs_with_table': [n / t for t in tt],
                 'decode_only_tiles_per_s': n / min(dec[1:]), 'decode_only_cold_tiles_per_s': n / dec[0],
                 'decode_rows_only_tiles_per_s': n / min(rows_dec),
                 'runs_host_unfilter': [n / t for t in th], 'runs_gpu_unfilter': [n / t for t in tg],

@@ -75,7 +75,7 @@ def main(argv=None):
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
     src = ap.add_mutually_exclusive_group(required=True)
     src.add_argument('--tfrecords', help='directory of Slideflow *.tfrecords (one per slide)')
-    src.add_argument('--synthetic', help='SxT: S synthetic slides of T tiles')
+    src.add_argument('--synthetic', help='SxT: S synthetic slides of T tiles; or a comma list of tile counts (9,3,0,7)')
     ap.add_argument('--labels', help='CSV with slide,label[,patient]')
     ap.add_argument('--weights', help='weights: .npz / .safetensors under Keras variable names, a TensorFlow checkpoint '
                                       'prefix, or a Keras SavedModel directory (default: seeded random init)')
@@ -96,6 +96,11 @@ def main(argv=None):
                     help='decode PNG tiles on the GPU: the host only copies their zlib streams, CUS compute units (16-32) kept out of '
                          'the inference streams inflate them.  For hosts with few free cores per GPU and runs of >= 30 k tiles; '
                          'slower than 16 host threads otherwise (profiles/r05_inflate.txt)')
+    ap.add_argument('--detect', action='store_true',
+                    help='also run threshold.detect on the tile table (Youden thresholds over every tile of the cohort, threshold.py:364-475)')
+    ap.add_argument('--dist-backend', default=None, help='process-group backend for WORLD_SIZE > 1 (default nccl = RCCL; gloo for a rehearsal '
+                                                          'of several ranks on one GPU)')
+    ap.add_argument('--local-device', type=int, default=None, help='HIP device of this rank (default LOCAL_RANK)')
     ap.add_argument('--no-calibrate', action='store_true',
                     help='f16 with external weights: skip the activation-exponent calibration on the first tiles (the headroom check stays)')
     args = ap.parse_args(argv)
@@ -103,11 +108,10 @@ def main(argv=None):
     from . import distributed as D, threshold, weights as W
     from .engine import EnginePool
     from .inference import Slide, evaluate, slides_from_tfrecords
-    from .predictions import rename_cols
     from .synthetic import make_slides
 
-    rank, world, local = D.init_from_env('cuda')
-    D.pin_rank(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)), device_index=local)     # before any thread pool exists
+    rank, world, local = D.init_from_env('cuda', backend=args.dist_backend, local_device=args.local_device)
+    D.pin_rank(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)), device_index=local)     # before any thread pool exists
     model_params = None
     if args.model:
         from .keras_import import load_model_dir
@@ -125,9 +129,15 @@ def main(argv=None):
         paths = sorted(glob.glob(os.path.join(args.tfrecords, '*.tfrecords')))
         slides = slides_from_tfrecords(paths, labels, patients, gpu_decode=args.gpu_decode > 0)
     else:
-        s, t = (int(x) for x in args.synthetic.lower().split('x'))
-        tiles, sidx, y = make_slides(s, t, seed=0)
-        slides = [Slide(f'slide{i:03d}', tiles[sidx == i], t, y_true=int(y[i])) for i in range(s)]
+        if 'x' in args.synthetic.lower():
+            s, t = (int(x) for x in args.synthetic.lower().split('x'))
+            tiles, sidx, y = make_slides(s, t, seed=0)
+            slides = [Slide(f'slide{i:03d}', tiles[sidx == i], t, y_true=int(y[i])) for i in range(s)]
+        else:                                                     # explicit (ragged) tile counts: 9,3,0,7
+            from .synthetic import make_tiles
+            counts = [int(x) for x in args.synthetic.split(',')]
+            slides = [Slide(f'slide{i:03d}', make_tiles(c, seed=500 + i, slide_bias=[(i % 2) * 60.0 - 30.0, 0.0, (i % 3) * 10.0]), c,
+                            y_true=i % 2) for i, c in enumerate(counts)]
     hp, norm_fit = model_hp(model_params)
     if args.params:
         with open(args.params) as f:
@@ -164,19 +174,34 @@ def main(argv=None):
         if hr['headroom'] < 8 and rank == 0:
             print(f'warning: f16 headroom only {hr["headroom"]:.1f}x on the first tiles ({hr["max_abs"]}); '
                   f'consider --dtype bf16', flush=True)
+    # the tile table streams to disk while the GPU works (every rank its shard; rank 0 splices them after the gather): the frame
+    # is not kept in memory, the consumer reads the file -- as biscuit does (experiment.py:688-699)
     res = evaluate(pool, slides, outcome=args.outcome, mc_n=args.mc, seed=args.seed, batch=args.batch,
-                   save_dir=args.out, rank=rank, world=world, norm_fit=norm_fit)
+                   save_dir=args.out, rank=rank, world=world, norm_fit=norm_fit, keep_tiles=False)
     if rank == 0:
+        from .predictions import load_tile_predictions
         sf, _ = res.slide_frame(0.5)
         sf.to_csv(os.path.join(args.out, f'slide_predictions_{args.outcome}_eval.csv'), index=False)
-        summary = {'slides': int((res.slide_count > 0).sum()), 'tiles': int(res.slide_count.sum())}
-        if world == 1:
-            df = res.tile_df.copy()
-            rename_cols(df, args.outcome)
-            metrics, _ = threshold.apply(df, tile_uq=args.tile_uq, slide_uq=args.slide_uq, patients=patients)
-            summary.update({k: (None if v is None or (isinstance(v, float) and np.isnan(v)) else float(v))
-                            for k, v in metrics.items()})
+        summary = {'slides': int((res.slide_count > 0).sum()), 'tiles': int(res.slide_count.sum()), 'world': world,
+                   'tile_table': res.table_path}
+        # the consumer on THE table, at any world size: rank 0 holds every tile of the cohort once the shards are spliced
+        # (threshold.detect takes Youden's J over all of them, threshold.py:417-426)
+        df = load_tile_predictions(res.table_path, args.outcome)
+        if args.detect:
+            try:
+                found, auc = threshold.detect(df.copy(), patients=patients)
+                summary['detected'] = {k: (None if v is None else float(v)) for k, v in found.items()}
+                summary['detect_auc'] = None if auc is None or np.isnan(auc) else float(auc)
+            except ValueError as e:                               # (a cohort whose tiles are all correct / of one class)
+                summary['detected'], summary['detect_error'] = None, str(e)
+        metrics, _ = threshold.apply(df, tile_uq=args.tile_uq, slide_uq=args.slide_uq, patients=patients)
+        summary.update({k: (None if v is None or (isinstance(v, float) and np.isnan(v)) else float(v))
+                        for k, v in metrics.items()})
         print(json.dumps(summary))
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

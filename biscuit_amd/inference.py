@@ -17,7 +17,8 @@ import pandas as pd
 import torch
 
 from . import distributed as D
-from .predictions import save_tile_predictions, tile_frame, EVAL_NAME
+from .predictions import (EVAL_NAME, TableWriter, assemble_shards, save_tile_predictions, shard_name, tile_frame,
+                          write_shard_index)
 
 
 @dataclass
@@ -191,6 +192,8 @@ class EvalResult:
     slide_count: np.ndarray
     slide_y_true: np.ndarray
     local_slides: List[int] = field(default_factory=list)
+    table_path: Optional[str] = None         # the tile table on disk: THE table (world 1; rank 0 after the splice) or this rank's shard
+    table_rows: int = 0                      # rows this rank wrote
 
     def slide_frame(self, pred_thresh=0.5, level='slide'):
         """Group table in ``process_group_predictions`` form from the device-reduced means."""
@@ -447,13 +450,120 @@ def _to_device(t, device):
     return torch.from_numpy(np.ascontiguousarray(t)).to(device, non_blocking=True)
 
 
+class _TableStream:
+    """The tile table written WHILE the GPU works (round 6; Slideflow -- and rounds 1-5 here -- wrote it with one
+    ``DataFrame.to_csv`` after the last batch: 1.75 s per 200 000 rows, serial, behind 6 s of GPU time).  ``submit`` takes a
+    batch's results as they were enqueued -- one device tensor [2, n, 2] (mean | std), the event behind the batch's last kernel,
+    and the runs of tiles per slide it holds --; a host thread waits for the event on a side stream, copies the 4 KB to pinned
+    memory there and appends the rows through ``TableWriter`` (libbiscuit_io; the GIL is released while it formats and writes).
+    Batches are written in submission order, so the rows are in dataset order however many batches are in flight.  For a shard
+    of a multi-rank run it also notes every slide's byte range (``write_shard_index``)."""
+
+    def __init__(self, path, outcome, with_loc, dev, max_batch, shard=None):
+        import queue
+        import threading
+        self.writer = TableWriter(path, outcome, with_loc)
+        self.path, self.outcome, self.with_loc, self.shard = path, outcome, with_loc, shard
+        self.dev = torch.device(dev)
+        self.cuda = self.dev.type == 'cuda'
+        self.side = torch.cuda.Stream(device=self.dev) if self.cuda else None
+        self.host = torch.empty((2 * max_batch * 2,), dtype=torch.float32, pin_memory=self.cuda)
+        self.q = queue.Queue(maxsize=64)
+        self.error = None
+        self.index = []                      # [global slide index, name, rows, offset, length]
+        self.rows = 0
+        self.th = threading.Thread(target=self._work, name='bq-table-writer', daemon=True)
+        self.th.start()
+
+    def _work(self):
+        try:
+            while True:
+                item = self.q.get()
+                if item is None:
+                    return
+                if self.error is not None:
+                    continue                 # (drain: the producer must never block on a dead writer)
+                out2, ev, segs = item
+                n = out2.shape[1]
+                if self.cuda:
+                    host = self.host[:4 * n].view(2, n, 2)
+                    with torch.cuda.stream(self.side):
+                        if ev is not None:
+                            self.side.wait_event(ev)
+                        host.copy_(out2, non_blocking=True)
+                    self.side.synchronize()
+                    arr = host.numpy()
+                else:
+                    arr = out2.numpy()
+                at = 0
+                for si, name, y_true, loc, count in segs:
+                    t0 = self.writer.tell()
+                    self.writer.rows(name, y_true, arr[0, at:at + count], arr[1, at:at + count], loc)
+                    t1 = self.writer.tell()
+                    if self.index and self.index[-1][0] == si:
+                        self.index[-1][2] += count
+                        self.index[-1][4] += t1 - t0
+                    else:
+                        self.index.append([si, name, count, t0, t1 - t0])
+                    at += count
+                    self.rows += count
+                del out2, item
+        except BaseException as e:           # noqa: BLE001 -- re-raised by the producer
+            self.error = e
+            while self.q.get() is not None:  # keep draining until the producer says stop
+                pass
+
+    def submit(self, out2, ev, segs):
+        if self.error is not None:
+            self.finish()
+        if self.cuda:
+            out2.record_stream(self.side)
+        self.q.put((out2, ev, segs))
+
+    def abort(self):
+        """The run failed elsewhere: stop the thread and close the file (what is on disk stays, without an index)."""
+        if self.th is not None:
+            self.q.put(None)
+            self.th.join()
+            self.th = None
+        self.error = None
+        try:
+            self.writer.close()
+        except IOError:
+            pass
+
+    def finish(self):
+        """Everything submitted is on disk and the file is closed when this returns; raises what the writer thread met."""
+        if self.th is not None:
+            self.q.put(None)
+            self.th.join()
+            self.th = None
+        err, self.error = self.error, None
+        if err is not None:
+            try:
+                self.writer.close()
+            finally:
+                raise err
+        rows, _ = self.writer.close()
+        if self.shard is not None:
+            write_shard_index(self.path, self.shard[0], self.shard[1], self.outcome, self.with_loc, self.index)
+        return rows
+
+
 def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=None, batch=256,
-             mc_mode='head', tile_uq=None, save_dir=None, keep_tiles=True, rank=0, world=1, norm_fit=None):
+             mc_mode='head', tile_uq=None, save_dir=None, keep_tiles=True, rank=0, world=1, norm_fit=None,
+             table_name=EVAL_NAME, table_writer='native'):
     """Run MC-dropout inference over ``slides`` and return tile- and slide-level results.
 
     Every rank passes the SAME slide list; rank r processes ``partition_slides(...)[r]``.
-    The slide-level arrays are all-gathered (one collective); tile rows stay rank-local and
-    are written as ``{save_dir}/tile_predictions_eval[.rankR].csv`` when requested.
+    The slide-level arrays are all-gathered (one collective).
+
+    ``save_dir``: the tile table -- the product ``biscuit.threshold`` reads (experiment.py:688-699) -- is written there as
+    ``table_name`` WHILE the GPU works (``_TableStream``; ``keep_tiles`` is not needed for it).  With ``world`` > 1 every rank
+    streams its shard ``tile_predictions_eval.rankR.csv`` (+ a byte index of its slides) and closes it BEFORE the all-gather, so
+    the gather doubles as "all shards complete"; rank 0 then splices them into the ONE table in dataset order -- byte for byte
+    the file a single-rank run writes.  ``table_writer='pandas'`` (or a ``.parquet.gzip`` name) writes with pandas after the run
+    instead: the checker of the native writer, and the parquet form.
 
     ``norm_fit`` (``{'target_means': [3], 'target_stds': [3]}``, the block of that name in the model's
     params.json) switches on the `reinhard_fast` stain normaliser of hp.py:19 in front of the staging
@@ -473,6 +583,18 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     acc = [None] * len(engines)
     n_batches = 0
     rows_mean, rows_std, rows_slide, rows_true, rows_loc = [], [], [], [], []
+    with_loc = bool(slides) and all(s.loc is not None for s in slides if s.n_tiles)
+    native = save_dir is not None and table_writer == 'native' and table_name.endswith('.csv')
+    if table_writer not in ('native', 'pandas'):
+        raise ValueError(f"table_writer must be 'native' or 'pandas', not {table_writer!r}")
+    if save_dir is not None and not native and not keep_tiles:
+        raise ValueError('the pandas writer needs keep_tiles=True (it writes the frame after the run)')
+    table = None
+    if native:
+        import os
+        tpath = os.path.join(save_dir, table_name if world == 1 else shard_name(table_name, rank))
+        table = _TableStream(tpath, outcome, with_loc, dev, batch, shard=None if world == 1 else (rank, world))
+    pend_segs = []                           # (slide index, name, y_true, loc rows or None, count) of the pending tiles, in order
 
     # stream tiles of this rank's slides in batches that may span slides
     pend_tiles, pend_sidx, pend_gidx = [], [], []
@@ -491,8 +613,8 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             cur, cs = cur.contiguous(), cs.contiguous()
             # global tile indices inside a batch are contiguous per slide but not across
             # slides: run one bq_mc_infer per contiguous run so the Philox counter is exact
-            mean = torch.empty((take, 2), dtype=torch.float32, device=dev)
-            std = torch.empty((take, 2), dtype=torch.float32, device=dev)
+            out2 = torch.empty((2, take, 2), dtype=torch.float32, device=dev)       # mean | std: ONE device-to-host copy per batch
+            mean, std = out2[0], out2[1]
             brk = np.flatnonzero(np.diff(cg) != 1) + 1
             starts = np.concatenate([[0], brk]); ends = np.concatenate([brk, [take]])
             k = n_batches % len(engines)
@@ -520,11 +642,27 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 # batch's kernels are still in flight
                 st = getattr(pool, 'streams', None)
                 if st and cur.is_cuda:
-                    for t in (cur, cs, mean, std) + ((gdev,) if gdev is not None else ()):
+                    for t in (cur, cs, out2) + ((gdev,) if gdev is not None else ()):
                         t.record_stream(st[k])
                 pool.run(n_batches, work, wait_for_current=True)
             else:
                 work(engine)
+            if table is not None:
+                ev = None
+                if out2.is_cuda:
+                    ev = torch.cuda.Event()
+                    st = getattr(pool, 'streams', None) if pool else None
+                    ev.record(st[k] if st else torch.cuda.current_stream(dev))
+                segs, left = [], take
+                while left:
+                    si, name, yt, loc, c = pend_segs[0]
+                    if c <= left:
+                        segs.append(pend_segs.pop(0)); left -= c
+                    else:
+                        segs.append((si, name, yt, None if loc is None else loc[:left], left))
+                        pend_segs[0] = (si, name, yt, None if loc is None else loc[left:], c - left)
+                        left = 0
+                table.submit(out2, ev, segs)
             n_batches += 1
             if keep_tiles:          # device tensors; copied to the host once everything has been enqueued
                 rows_mean.append(mean); rows_std.append(std)
@@ -594,6 +732,8 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             pend_sidx.append(torch.full((count,), li, dtype=torch.int32, device=dev))
             pend_gidx.append(offsets[si] + first + np.arange(count, dtype=np.int64))
             pend_n += count
+            if table is not None:
+                pend_segs.append((si, s.name, int(s.y_true), np.asarray(s.loc)[first:first + count] if with_loc else None, count))
             if keep_tiles:
                 rows_slide += [s.name] * count
                 rows_true += [s.y_true] * count
@@ -622,8 +762,13 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             flush()
         flush(final=True)
 
-    with (torch.cuda.stream(prep) if prep is not None else contextlib.nullcontext()):
-        stream_slides()
+    try:
+        with (torch.cuda.stream(prep) if prep is not None else contextlib.nullcontext()):
+            stream_slides()
+    except BaseException:
+        if table is not None:
+            table.abort()
+        raise
     if prep is not None:
         torch.cuda.current_stream(dev).wait_stream(prep)
 
@@ -647,17 +792,30 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
         mp, mu, cnt = mp.cpu().numpy(), mu.cpu().numpy(), cnt.cpu().numpy()
     else:
         mp = mu = np.zeros(0); cnt = np.zeros(0, dtype=np.int64)
+    # this rank's rows are on disk and its file closed BEFORE the collective: whoever leaves the gather knows every shard is complete
+    table_path, table_rows = None, 0
+    if table is not None:
+        table_rows = table.finish()
+        table_path = table.path
     cap = max(len(p) for p in parts) if parts else 0
     g_pred, g_unc, g_cnt = D.gather_slide_results(mine, mp[:n_local], mu[:n_local], cnt[:n_local],
                                                   len(slides), cap)
+    if table is not None and world > 1 and rank == 0:
+        table_path = assemble_shards(save_dir, table_name)
     tile_df = None
     if keep_tiles:
         mean = torch.cat(rows_mean).cpu().numpy() if rows_mean else np.zeros((0, 2), np.float32)
         std = torch.cat(rows_std).cpu().numpy() if rows_std else np.zeros((0, 2), np.float32)
         loc = np.concatenate(rows_loc) if rows_loc and sum(len(x) for x in rows_loc) == len(rows_slide) else None
-        tile_df = tile_frame(outcome, rows_slide, rows_true, mean, std, loc)
-        if save_dir is not None:
-            name = EVAL_NAME if world == 1 else EVAL_NAME.replace('.csv', f'.rank{rank}.csv')
-            save_tile_predictions(tile_df, save_dir, name)
+        tile_df = tile_frame(outcome, rows_slide, rows_true, mean, std, loc if (with_loc or table is None) else None)
+        if save_dir is not None and table is None:
+            table_path = save_tile_predictions(tile_df, save_dir, table_name if world == 1 else shard_name(table_name, rank))
+            table_rows = len(tile_df)
+            if world > 1:                        # (pandas shards carry the same index, without byte ranges: row counts order them)
+                order, at = [], 0
+                for si in mine:
+                    if slides[si].n_tiles:
+                        order.append([si, slides[si].name, slides[si].n_tiles, 0, 0])
+                write_shard_index(table_path, rank, world, outcome, 'loc_x' in tile_df.columns, order)
     return EvalResult(tile_df, [s.name for s in slides], g_pred, g_unc, g_cnt,
-                      np.array([s.y_true for s in slides]), list(mine))
+                      np.array([s.y_true for s in slides]), list(mine), table_path, table_rows)

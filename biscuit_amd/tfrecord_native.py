@@ -37,6 +37,14 @@ ABI = {
                           C.POINTER(_i), C.POINTER(_i)]),
     'bqio_inflate_fallbacks': (_i64, []),
     'bqio_decode_jpeg': (_i, [C.c_char_p, C.c_size_t, _i, _vp]),
+    # the output side: the tile-prediction table (biscuit_amd/predictions.py)
+    'bqio_table_open': (_vp, [C.c_char_p, C.c_char_p, _i, _i]),
+    'bqio_table_last_error': (C.c_char_p, [_vp]),
+    'bqio_table_rows': (_i, [_vp, C.c_char_p, _i64, _vp, _vp, _vp, _i64]),
+    'bqio_table_tell': (_i64, [_vp]),
+    'bqio_table_append_file': (_i, [_vp, C.c_char_p, _i64, _i64]),
+    'bqio_table_close': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    'bqio_format_f64': (_i, [C.c_double, C.c_char_p, _i]),
 }
 
 

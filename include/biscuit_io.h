@@ -26,7 +26,7 @@ extern "C" {
 typedef struct bqio_reader bqio_reader;
 
 enum { BQIO_OK = 0, BQIO_ERR_ARG = -1, BQIO_ERR_IO = -2, BQIO_ERR_FORMAT = -3, BQIO_ERR_CORRUPT = -4,
-       BQIO_ERR_UNSUPPORTED = -5 };
+       BQIO_ERR_UNSUPPORTED = -5, BQIO_ERR_NAN = -6 };
 enum { BQIO_VERIFY_NONE = 0, BQIO_VERIFY_LENGTH = 1, BQIO_VERIFY_FULL = 2 };
 enum { BQIO_IMG_UNKNOWN = 0, BQIO_IMG_PNG = 1, BQIO_IMG_JPEG = 2 };
 
@@ -101,6 +101,41 @@ int bqio_inflate2(const uint8_t* za, size_t na, uint8_t* out_a, size_t len_a, co
 /* How many PNG streams bqio_decode handed to zlib after the decompressor above refused them and zlib accepted them
  * (process-wide).  Always 0 unless that decompressor has a bug; the tests assert it. */
 int64_t bqio_inflate_fallbacks(void);
+
+/* ---- The output side: the tile-prediction table -------------------------------------------------------------------------
+ * Replaces the `DataFrame.to_csv(index=False)` with which Slideflow's `Project.evaluate(..., save_predictions=True)`
+ * (experiment.py:917-922) leaves `tile_predictions_eval.csv`, the file biscuit reads back with
+ * `pd.read_csv(path, dtype={'slide': str})` (experiment.py:688-699; validation: `tile_predictions_val_epoch1.csv`,
+ * experiment.py:982-988, utils.py:216) and renames by the column contract of utils.py:19-53.  Rows are appended while the GPU
+ * works (one call per run of tiles of one slide), in the bytes pandas would write: float64 cells as the shortest string that
+ * reads back to the same double, laid out as Python's repr(float); NaN = empty cell; slide names quoted only when they must be. */
+typedef struct bqio_table bqio_table;
+
+/* Create (append = 0: truncate and write the header line
+ *     slide[,loc_x,loc_y],{outcome}-y_true0,{outcome}-y_pred0,{outcome}-y_pred1,{outcome}-uncertainty0,{outcome}-uncertainty1)
+ * or extend (append = 1: no header) the table at `path`.  NULL on failure; bqio_table_last_error(NULL) says why. */
+bqio_table* bqio_table_open(const char* path, const char* outcome, int with_loc, int append);
+const char* bqio_table_last_error(bqio_table* t);
+
+/* Append `count` rows of ONE slide: mean2 / std2 = float32 [count][2] (the MC mean and population std of the two class
+ * probabilities, widened to float64 exactly as the in-memory table holds them), loc = int64 [count][2] (loc_x, loc_y) exactly
+ * when the table was opened with_loc.  A NaN in mean2 returns BQIO_ERR_NAN and writes nothing of this call (threshold.py:141-142
+ * refuses such a table: the Python wrapper raises PredsContainNaNError). */
+int bqio_table_rows(bqio_table* t, const char* slide, int64_t y_true, const int64_t* loc, const float* mean2, const float* std2,
+                    int64_t count);
+
+/* Bytes of the table so far (written or buffered): a rank notes it per slide, so that the per-rank shards of a multi-rank run
+ * can be spliced into ONE table in dataset order without parsing them. */
+int64_t bqio_table_tell(bqio_table* t);
+
+/* Append bytes [offset, offset + length) of the file at src_path (a slide's rows in another rank's shard). */
+int bqio_table_append_file(bqio_table* t, const char* src_path, int64_t offset, int64_t length);
+
+/* Flush and close; *rows / *bytes (may be NULL) = what bqio_table_rows wrote / the file's size increase.  Frees t. */
+int bqio_table_close(bqio_table* t, int64_t* rows, int64_t* bytes);
+
+/* repr(float) of one double into out (NUL-terminated), exported for tests.  Returns its length or BQIO_ERR_ARG. */
+int bqio_format_f64(double v, char* out, int cap);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,9 @@ def main():
     group1 = len(sys.argv) > 8 and sys.argv[8] == 'group1'
     rank, world, local = D.init_from_env('cuda', backend=backend, local_device=local_device, single_rank_group=group1)
     eng = Engine(synthetic_weights(1), dtype=dtype, max_batch=batch, max_mc=mc_n, device=local)
-    res = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch, rank=rank, world=world)
+    # BQ_TEST_SAVE_DIR: also stream the tile table (this rank's shard; rank 0 splices the shards after the gather)
+    res = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch, rank=rank, world=world,
+                   save_dir=os.environ.get('BQ_TEST_SAVE_DIR'))
     np.savez(f'{out}.rank{rank}.npz', slide_pred=res.slide_pred, slide_unc=res.slide_unc, slide_count=res.slide_count,
              local=np.array(res.local_slides), tile_slide=np.array(res.tile_df['slide'], dtype=str),
              tile_pred=res.tile_df['cohort-y_pred1'].to_numpy(), tile_unc=res.tile_df['cohort-uncertainty1'].to_numpy())

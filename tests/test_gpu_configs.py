@@ -57,12 +57,23 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path, counts, dtype):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), BQ_TEST_SAVE_DIR=str(tmp_path / 'multi'))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_rank_worker.py'), out, dtype,
                                        str(mc_n), str(batch), ','.join(map(str, counts)), '0', 'gloo'], env=env, cwd=ROOT))
     assert [p.wait(timeout=600) for p in procs] == [0, 0]
     eng = Engine(synthetic_weights(1), dtype=dtype, max_batch=batch, max_mc=mc_n)
-    single = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch)
+    single = evaluate(eng, build_slides(counts), mc_n=mc_n, seed=77, batch=batch, save_dir=str(tmp_path / 'single'))
+    # THE product of the path (experiment.py:688-699 reads ONE tile_predictions_eval.csv): each rank streamed its shard while its
+    # GPU worked and closed it before the gather, rank 0 spliced them -- the single-rank file byte for byte, which is also
+    # to_csv of the frame; the consumer finds the same thresholds on it (threshold.detect: Youden over every tile, threshold.py:417-426)
+    from biscuit_amd import predictions as P, threshold
+    whole = os.path.join(str(tmp_path / 'multi'), P.EVAL_NAME)
+    assert open(whole, 'rb').read() == open(single.table_path, 'rb').read()
+    assert open(P.save_tile_predictions(single.tile_df, str(tmp_path / 'pandas')), 'rb').read() == open(whole, 'rb').read()
+    assert len(P.find_shards(str(tmp_path / 'multi'))) == 2
+    df_m, df_s = P.load_tile_predictions(str(tmp_path / 'multi'), 'cohort'), P.load_tile_predictions(single.table_path, 'cohort')
+    assert df_m.equals(df_s) and len(df_s) == sum(counts)
+    assert threshold.detect(df_m.copy())[0] == threshold.detect(df_s.copy())[0]
     r0, r1 = (np.load(f'{out}.rank{r}.npz') for r in range(2))
     # both ranks hold the whole gathered slide table, equal to the single-rank one bit for bit
     for r in (r0, r1):
@@ -133,6 +144,53 @@ def test_bench_starts_its_own_ranks():
                          env=dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0'), cwd=ROOT, capture_output=True, text=True,
                          timeout=600)
     assert bad.returncode != 0 and 'WORLD_SIZE' in bad.stderr
+
+
+def _json_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{')][-1])
+
+
+def test_eight_rank_rehearsal_on_one_gpu(tmp_path):
+    """What the driver runs at N = 8, end to end with real engines on the ONE GPU of this box (eight HIP contexts on device 0, a
+    gloo group: RCCL refuses several ranks on one device): ``bench.py --gpus 8`` on config 2 and on a ragged config 3 with the tile
+    table, and the CLI at world 8 with the shards spliced and the consumer run by rank 0 -- rank 0's results equal to the
+    single-rank run bit for bit (digests of the slide table and of tile_predictions_eval.csv, the printed metrics)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'LOCAL_WORLD_SIZE')}
+    common = ['--local-device', '0', '--dist-backend', 'gloo', '--batch', '16', '--mc', '5', '--streams', '1', '--no-extras',
+              '--no-cpu-baseline', '--no-profile']
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *a, *common], env=env, cwd=ROOT,     # noqa: E731
+                                    capture_output=True, text=True, timeout=1500)
+    w8 = _json_line(run('--gpus', '8', '--steps', '2', '--warmup', '1'))
+    assert w8['n_gpus'] == 8 and w8['scaling'] == 'weak' and w8['value'] > 0
+    assert w8['collective'] == {'backend': 'gloo', 'ranks_seen': 8, 'rccl_ranks': 0}
+    assert w8['host_cores_of_rank0'] >= 1                       # pin_rank against this box's sysfs: a share, never empty
+    cfg3 = ['--workload', 'cfg3', '--slides', '19', '--tiles-per-slide', '24', '--ragged']
+    s8, s1 = _json_line(run('--gpus', '8', *cfg3)), _json_line(run('--gpus', '1', *cfg3))
+    assert s8['n_gpus'] == 8 and s8['config']['ragged'] and sum(s8['config']['slides_per_rank']) == 19
+    assert s8['slide_table_sha256'] == s1['slide_table_sha256']
+    assert s8['tile_table']['sha256'] == s1['tile_table']['sha256'] and s8['tile_table']['rows'] == s1['tile_table']['rows'] > 0
+    # the CLI: eight ranks, shards spliced by rank 0, threshold.detect / apply on THE table
+    counts = '9,3,7,4,5,0,11,6,2,8,1,10'
+    cli = [sys.executable, '-m', 'biscuit_amd', '--synthetic', counts, '--batch', '8', '--mc', '5', '--detect', '--local-device', '0',
+           '--dist-backend', 'gloo']
+    port = _free_port()
+    procs = []
+    for r in range(8):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='8', LOCAL_WORLD_SIZE='8', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(cli + ['--out', str(tmp_path / 'w8')], env=e, cwd=ROOT, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE if r == 0 else None))
+    out0, err0 = procs[0].communicate(timeout=900)
+    assert [p.wait(timeout=300) for p in procs] == [0] * 8, err0[-3000:]
+    one = subprocess.run(cli + ['--out', str(tmp_path / 'w1')], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    a = json.loads([ln for ln in out0.splitlines() if ln.startswith('{')][-1])
+    b = _json_line(one)
+    assert a.pop('world') == 8 and b.pop('world') == 1
+    ta, tb = a.pop('tile_table'), b.pop('tile_table')
+    assert a == b and a['tiles'] == 66 and 'auc' in a and 'detected' in a, (a, b)
+    assert open(ta, 'rb').read() == open(tb, 'rb').read()
+    name = 'slide_predictions_cohort_eval.csv'
+    assert open(tmp_path / 'w8' / name, 'rb').read() == open(tmp_path / 'w1' / name, 'rb').read()
 
 
 def test_config3_one_ranks_share_at_real_size():
