@@ -262,7 +262,8 @@ def run(args):
     seed = 1234
 
     # synthetic tiles, generated on the device: 4 batches resident, cycled
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    # (config 3 is ONE dataset sharded over the ranks: every rank generates the same tiles; config 2 is per-rank work)
+    g = torch.Generator(device=dev).manual_seed(100 + (rank if args.workload == 'cfg2' else 0))
     pool = [torch.randint(0, 256, (B, 299, 299, 3), dtype=torch.uint8, device=dev, generator=g)
             for _ in range(4)]
     scratch = [torch.empty_like(pool[0]) for _ in range(NS)]      # stain-normalised copy, one per stream
