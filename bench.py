@@ -83,16 +83,12 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-budget', type=float, default=25.0, help='seconds of CPU work in the baseline sample')
     ap.add_argument('--dist-backend', default=None, help='process-group backend (default: nccl = RCCL); tests: gloo')
     ap.add_argument('--local-device', type=int, default=None, help='GPU index of this rank (default: LOCAL_RANK)')
-    ap.add_argument('--schedule', default='free', choices=['free', 'antiphase', 'pipeline'],
-                    help='free: batches alternate over free-running streams (EnginePool); antiphase / pipeline: every batch cut into '
-                         'its entry part and the rest, the two parts of two batches scheduled against each other (PhasedPool)')
-    ap.add_argument('--cus-entry', type=int, default=None, help='pipeline: compute units of the stream that runs the entry parts')
     ap.add_argument('--size-grids', action='store_true',
-                    help='free schedule: persistent grids sized for the CUs of each stream (default: for the whole chip)')
+                    help='persistent grids sized for the CUs of each stream (default: for the whole chip)')
     ap.add_argument('--selftest-exit', default=None, metavar='R:CODE',
                     help='(tests, no GPU) rank R exits with CODE before the rendezvous ("none": nobody does), the other ranks run a '
                          'gloo rendezvous and a barrier: exercises the launcher of --gpus N')
-    ap.add_argument('--fixed-streams', action='store_true', help='free schedule: exactly --streams batches in flight, no calibration')
+    ap.add_argument('--fixed-streams', action='store_true', help='exactly --streams batches in flight, no calibration')
     ap.add_argument('--streams', type=int, default=4,
                     help='batches in flight: independent contexts on HIP streams that own disjoint groups of XCDs (2 or 4)')
     return ap.parse_args(argv)
@@ -251,11 +247,6 @@ def run(args):
     weights = synthetic_weights(1)
     pool_e = EnginePool(weights, n_streams=args.streams, dtype=args.dtype, max_batch=args.batch, max_mc=args.mc,
                         device=local, size_grids=args.size_grids)
-    phased = None
-    if args.schedule != 'free':
-        from biscuit_amd.engine import PhasedPool
-        phased = PhasedPool(weights, schedule=args.schedule, cus_entry=args.cus_entry, dtype=args.dtype, max_batch=args.batch,
-                            max_mc=args.mc, device=local)
     eng = pool_e.engines[0]
     NS = len(pool_e)
     B, K, Wm = args.batch, args.steps, args.warmup
@@ -307,11 +298,6 @@ def run(args):
                  torch.zeros(n_slides_local, dtype=torch.int32, device=dev)) for _ in range(n)]
 
     def step(pe, i, acc, mode, stain=False):
-        if pe is phased and phased is not None:
-            k = i % len(pe.engines)
-            pe.step(i, pool[i % 4], args.mc, seed, tile_base + i * B, (mean[k], std[k]),
-                    after=lambda e: e.slide_reduce(mean[k], std[k], slide_of[i], n_slides_local, acc=acc[k]))
-            return
         k = i % len(pe)               # batches in flight (set by the calibration below)
 
         def work(e):
@@ -364,11 +350,7 @@ def run(args):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         pool_e.set_in_flight(cands[int(torch.argmin(tt).item())])
     streams_used = len(pool_e)
-    if phased is not None and args.mode == 'head':
-        timed(args.mode, min(K, 16), pe=phased)          # warm-up of the second set of contexts
-        dt = timed(args.mode, K, pe=phased)
-    else:
-        dt = timed(args.mode, K)
+    dt = timed(args.mode, K)
     value = world * K * B / dt
 
     out = {
@@ -382,10 +364,8 @@ def run(args):
                                + ('; f16 is the 16-bit mode that holds the 1e-3 tile/slide tolerance on O(1)-logit weights '
                                   '(bf16, the type config 2 names, runs 5-6 % slower and misses it: bf16_value)'
                                   if args.dtype == 'f16' else ''),
-                   'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B, 'hip_streams': streams_used if phased is None else 2,
-                   'schedule': args.schedule if phased is not None else 'free',
-                   'cus': list(phased.cus) if phased is not None else None,
-                   'grids_sized_for_mask': bool(args.size_grids) if phased is None else True,
+                   'mc_mode': args.mode, 'mc_n': args.mc, 'batch': B, 'hip_streams': streams_used,
+                   'grids_sized_for_mask': bool(args.size_grids),
                    'parallelism': f'slide-sharded dp{world}, one all-gather of slide (pred, sigma, n)'},
         'rccl_ranks': coll['rccl_ranks'], 'collective': coll, 'host_cores_of_rank0': len(rank_cpus),
     }

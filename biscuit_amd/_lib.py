@@ -12,7 +12,6 @@ LIB_PATH = os.path.join(_HERE, 'libbiscuit_hip.so')
 
 BQ_DTYPE_F32, BQ_DTYPE_BF16, BQ_DTYPE_F16 = 0, 1, 2
 BQ_MC_HEAD, BQ_MC_FULL = 0, 1
-BQ_PART_ENTRY, BQ_PART_REST, BQ_PART_ALL = 1, 2, 3
 BQ_PROF_MAX = 64
 
 
@@ -53,7 +52,6 @@ ABI = {
     'bq_set_tile_index_ptr': (_i, [_vp, _vp]),
     'bq_set_tile_index_array': (_i, [_vp, _vp]),
     'bq_mc_infer': (_i, [_vp, _vp, _i, _i64, _i, _u64, _i, _vp, _vp, _vp, _sz, _vp]),
-    'bq_mc_infer_part': (_i, [_vp, _vp, _i, _i64, _i, _u64, _i, _vp, _vp, _vp, _sz, _vp]),
     'bq_slide_reduce': (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'bq_roc_workspace_bytes': (_sz, [_i64]),
     'bq_roc_youden': (_i, [_vp, _vp, _vp, _i64, _vp, _sz, _vp, _vp]),

@@ -55,10 +55,8 @@ struct bq_ctx {
     float* d_srgb_lut = nullptr;   // tables of the Reinhard normaliser
     const long long* d_tile0 = nullptr;   // bq_set_tile_index_ptr
     const long long* d_tile_idx = nullptr;   // bq_set_tile_index_array
-    int head_variant = 2;          // bq_set_option("head_variant"): 0 = stages in lock step, 1 / 2 = producer and matrix stage overlapped (2: the
-                                   // waves that share a SIMD in opposite stages; bit-identical, 1-7 % faster: tools/ab_head.py)
-    int inflate_variant = 5;       // bq_set_option("inflate_variant"): 0 = tables in global memory, 1 = direct tables mirrored in LDS, 2-8 = rounds of a
-                                   // literal-only fast phase + general phase (kernels_inflate.hip); 5 measured fastest (profiles/r05_inflate.txt)
+    int inflate_variant = 5;       // bq_set_option("inflate_variant"): 5 = rounds of a literal-only fast phase + a general phase (LDS), 0 = the
+                                   // kernel without LDS, tables in global memory (kernels_inflate.hip; profiles/r05_inflate.txt)
     float feat_mul = 1.f;          // "act/feat_mul" of the blob: 2^k of the pooled tensor's activation exponent (weights.py: pack_blob)
     double* d_stage_stats = nullptr;   // 2 x 64-bit integer sums per tile for the staging kernel pair
     // profiling
@@ -535,7 +533,7 @@ int entry_flow(bq_ctx* c, const void* in_nchw, int n, void* out4, void* A, void*
 }
 
 // part: bit 0 = stem + entry flow (blocks 1-4; its output stays in the workspace), bit 1 = middle + exit flow (reads it there):
-// bq_mc_infer_part lets a caller schedule the two halves of two batches against each other
+// (experiments build: bq_mc_infer_part lets a scheduler run the two halves of two batches against each other)
 int backbone_impl(bq_ctx* c, const void* in_nchw, int n, float* feat, unsigned char* ws, hipStream_t s,
                   Tap* tap, const uint8_t* u8 = nullptr, int part = 3) {
     const WsLayout L = ws_layout(c, n, 1);
@@ -634,7 +632,7 @@ int head_impl(bq_ctx* c, const float* feat, int n, int64_t tile0, int mc_n, int 
                      4.0 * ((layer == 0 ? (double)n : (double)rows) * K + (double)rows * 1024 + (double)K * 1024));
         const int e = launch_head_dense(layer == 0 ? feat : h0, G.wh, G.wl, G.bias, layer == 0 ? h0 : h1, rows, K, mc_n, pass0,
                                         layer == 0 ? 1 : 0, layer, (unsigned)(seed & 0xffffffffu), (unsigned)(seed >> 32), thresh,
-                                        dscale, tile0, c->d_tile0, c->d_tile_idx, s, c->head_variant);
+                                        dscale, tile0, c->d_tile0, c->d_tile_idx, s);
         if (e) return fail(c, BQ_ERR_HIP, std::string("head dense launch: ") + hipGetErrorString((hipError_t)e));
     }
     {
@@ -950,8 +948,7 @@ int bq_stream_create_masked(bq_ctx* c, const uint32_t* cu_mask, int mask_words, 
 
 int bq_set_option(bq_ctx* c, const char* name, int value) {
     if (!c || !name) return fail(c, BQ_ERR_ARG, "bq_set_option: bad argument");
-    if (strcmp(name, "inflate_variant") == 0 && value >= 0 && value <= 8) { c->inflate_variant = value; return BQ_OK; }
-    if (strcmp(name, "head_variant") == 0 && value >= 0 && value <= 2) { c->head_variant = value; return BQ_OK; }
+    if (strcmp(name, "inflate_variant") == 0 && (value == 0 || value == 5)) { c->inflate_variant = value; return BQ_OK; }
     return fail(c, BQ_ERR_ARG, std::string("bq_set_option: unknown option or value: ") + name);
 }
 
@@ -1051,8 +1048,14 @@ int bq_mc_infer(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int
     return BQ_OK;
 }
 
-int bq_mc_infer_part(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int mc_n, uint64_t seed, int part,
-                     float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes, bq_stream_t stream) {
+#ifdef BQ_EXPERIMENTS
+// bq_mc_infer (BQ_MC_HEAD) in two parts, for a scheduler that runs the entry parts and the rests of two batches against each other
+// (tools/phased_pool.py): ENTRY = staging, stem and entry flow, whose output stays in the workspace; REST = middle and exit flow + the
+// MC head.  Round 5 measured every such schedule equal to or slower than free-running streams (profiles/r05_schedules_steps.log), so
+// the entry point is not part of the product library: `make EXPERIMENTS=1` builds it.
+enum { BQ_PART_ENTRY = 1, BQ_PART_REST = 2, BQ_PART_ALL = 3 };
+extern "C" int bq_mc_infer_part(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0, int mc_n, uint64_t seed, int part,
+                                float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes, bq_stream_t stream) {
     if (!c || !d_tiles || !d_mean2 || !d_std2 || !d_ws || n <= 0 || mc_n <= 0 || n > c->cfg.max_batch ||
         mc_n > c->cfg.max_mc || (part != BQ_PART_ENTRY && part != BQ_PART_REST && part != BQ_PART_ALL))
         return fail(c, BQ_ERR_ARG, "bq_mc_infer_part: bad argument");
@@ -1065,6 +1068,7 @@ int bq_mc_infer_part(bq_ctx* c, const uint8_t* d_tiles, int n, int64_t tile_idx0
     if (!(part & BQ_PART_REST)) return BQ_OK;
     return head_impl(c, feat, n, tile_idx0, mc_n, 0, seed, 1, 1, (float*)(ws + L.state), d_mean2, d_std2, ws, (hipStream_t)stream);
 }
+#endif
 
 int bq_backbone_u8(bq_ctx* c, const uint8_t* d_tiles, int n, float* d_feat, void* d_ws, size_t ws_bytes, bq_stream_t stream) {
     if (!c || !d_tiles || !d_feat || !d_ws || n <= 0 || n > c->cfg.max_batch) return fail(c, BQ_ERR_ARG, "bq_backbone_u8: bad argument");

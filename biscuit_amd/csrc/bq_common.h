@@ -139,7 +139,7 @@ int launch_respool(int dtype, const void* x, const void* wp32, const float* scal
 int launch_gap(const void* x, int n, int HW, int C, int ld, float* feat, float mul, int dtype, hipStream_t s);
 int launch_head_dense(const float* in, const void* wh, const void* wl, const float* bias, float* out, int rows, int K,
                       int mc_n, int pass0, int in_row_is_tile, int layer, unsigned seed_lo, unsigned seed_hi, unsigned thresh,
-                      float dscale, long long tile0, const long long* tile0_dev, const long long* tile_idx, hipStream_t s, int variant = 0);
+                      float dscale, long long tile0, const long long* tile0_dev, const long long* tile_idx, hipStream_t s);
 int launch_head_final(const float* h1, int n, int mc_n, int pass0, long long tile0, const long long* tile0_dev, const long long* tile_idx,
                       unsigned seed_lo, unsigned seed_hi, unsigned thresh, float dscale,
                       const float* w2, const float* b2, int init, int finalize, float* state,

@@ -23,9 +23,6 @@ namespace {
 using namespace bqk;
 
 constexpr int HM = 64, HN = 512;            // rows, columns per workgroup
-constexpr int HKC = 512;                    // k per chunk
-constexpr int HSTR = HKC * 2 + 16;          // A plane row stride: an odd number of 16-byte slots
-constexpr int HPLANE = HM * HSTR;
 constexpr float HSCALE = 2048.f, HINV = 1.f / 2048.f;
 
 struct HeadParams {
@@ -49,138 +46,15 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = H16<f16_t>::pack2(ra, rb);
 }
 
-__global__ void __launch_bounds__(512) head_dense_kernel(const HeadParams p) {
-    bq_f16_saturate();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // A planes: hi | lo
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r32 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * HM;
-    const int nf0 = blockIdx.y * (HN / 32) + wave * 2;          // this wave's two 32-column fragments
-    const int KB = p.K / 16;
-    const long long tile0 = p.tile0 + (p.tile0_dev ? *p.tile0_dev : 0);
-
-    // producer role: row tid >> 3 of the tile, Philox groups (of 4 k) i * 8 + (tid & 7), i = 0 .. 15, of the chunk
-    const int prow = tid >> 3, pseg = tid & 7;
-    const int pm = m0 + prow;
-    const bool plive = pm < p.rows;
-    const int ptile = plive ? pm / p.mc_n : 0;
-    const int ppass = p.pass0 + (plive ? pm - ptile * p.mc_n : 0);
-    const unsigned pctr = (unsigned)(tile0 + (p.tile_idx ? p.tile_idx[ptile] : (long long)ptile));   // the Philox tile counter of this row
-    const float* prow_ptr = p.in + (size_t)(p.in_row_is_tile ? ptile : (plive ? pm : 0)) * p.K;
-
-    f32x16 acc1[2][2], acc2[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
-
-    const uint4* bh0 = p.wh + (size_t)nf0 * KB * 64 + lane;
-    const uint4* bl0 = p.wl + (size_t)nf0 * KB * 64 + lane;
-    constexpr int PF = 2;                                       // k-blocks of weight fragments in flight
-    uint4 bh[PF][2], bl[PF][2];
-#pragma unroll
-    for (int d = 0; d < PF; ++d)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            bh[d][j] = bh0[((size_t)j * KB + d) * 64];
-            bl[d][j] = bl0[((size_t)j * KB + d) * 64];
-        }
-
-    for (int k0 = 0; k0 < p.K; k0 += HKC) {
-        if (k0) __syncthreads();                                // the previous chunk's fragments are all read
-        {   // ---- producer: dropout + split -> LDS
-            // two batches of eight 16-byte loads in flight (the accumulators leave no room for sixteen)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float4 v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(prow_ptr + k0 + ((half * 8 + i) * 8 + pseg) * 4);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int gi = (half * 8 + i) * 8 + pseg;
-                    const int g = (k0 >> 2) + gi;               // Philox group = unit / 4
-                    unsigned rnd[4];
-                    philox4x32_10((unsigned)g, (unsigned)p.layer, (unsigned)ppass, pctr, p.seed_lo, p.seed_hi, rnd);
-                    const float f0 = (plive && rnd[0] >= p.thresh) ? v[i].x * p.dscale : 0.f;
-                    const float f1 = (plive && rnd[1] >= p.thresh) ? v[i].y * p.dscale : 0.f;
-                    const float f2 = (plive && rnd[2] >= p.thresh) ? v[i].z * p.dscale : 0.f;
-                    const float f3 = (plive && rnd[3] >= p.thresh) ? v[i].w * p.dscale : 0.f;
-                    uint2 hi, lo;
-                    split2(f0, f1, hi.x, lo.x);
-                    split2(f2, f3, hi.y, lo.y);
-                    const int off = prow * HSTR + gi * 8;
-                    *reinterpret_cast<uint2*>(smem + off) = hi;
-                    *reinterpret_cast<uint2*>(smem + HPLANE + off) = lo;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- matrix stage: 32 k-blocks of 16
-        const unsigned char* a_hi = smem + r32 * HSTR + h * 16;
-        const unsigned char* a_lo = a_hi + HPLANE;
-        const int kb0 = k0 / 16;
-#pragma unroll 2
-        for (int kl = 0; kl < HKC / 16; ++kl) {
-            const int d = kl & (PF - 1);
-            uint4 ah[2], al[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const uint4*>(a_hi + i * 32 * HSTR + kl * 32);
-                al[i] = *reinterpret_cast<const uint4*>(a_lo + i * 32 * HSTR + kl * 32);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    mma<f16_t>(acc1[i][j], bh[d][j], ah[i]);
-                    mma<f16_t>(acc2[i][j], bh[d][j], al[i]);
-                    mma<f16_t>(acc2[i][j], bl[d][j], ah[i]);
-                }
-            const int nx = kb0 + kl + PF;
-            const int idx = nx < KB ? nx : KB - 1;              // past the end: a valid, unused block
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bh[d][j] = bh0[((size_t)j * KB + idx) * 64];
-                bl[d][j] = bl0[((size_t)j * KB + idx) * 64];
-            }
-        }
-    }
-    // ---- epilogue: combine the two accumulator sets, bias, ReLU; lane = row r32 of a fragment, four consecutive columns
-    // per register quad (D[column][row] = W^T-fragment x A-fragment, as everywhere in this library)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n0 = (nf0 + j) * 32 + g * 8 + h * 4;
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = m0 + i * 32 + r32;
-                if (m < p.rows) {
-                    float4 o;
-                    o.x = fmaxf(fmaf(acc2[i][j][g * 4 + 0], HINV, acc1[i][j][g * 4 + 0]) + b.x, 0.f);
-                    o.y = fmaxf(fmaf(acc2[i][j][g * 4 + 1], HINV, acc1[i][j][g * 4 + 1]) + b.y, 0.f);
-                    o.z = fmaxf(fmaf(acc2[i][j][g * 4 + 2], HINV, acc1[i][j][g * 4 + 2]) + b.z, 0.f);
-                    o.w = fmaxf(fmaf(acc2[i][j][g * 4 + 3], HINV, acc1[i][j][g * 4 + 3]) + b.w, 0.f);
-                    *reinterpret_cast<float4*>(p.out + (size_t)m * 1024 + n0) = o;
-                }
-            }
-        }
-}
-
-// ---- round 5: producer and matrix stage overlapped ------------------------------------------------------------------------
-// head_dense_kernel above runs its two stages in lock step -- barrier, every wave draws Philox masks and splits (vector ALU, ~9 us
-// per 512-deep chunk), barrier, every wave multiplies (matrix pipe, ~12 us) -- so each pipe idles while the other works.  Here the
-// A planes are double-buffered (chunks of 256: 2 x 2 x 33 KB of LDS) and a chunk step is "produce chunk c + 1, multiply chunk c"
-// for the even waves and "multiply chunk c, produce chunk c + 1" for the odd ones: the two waves of a SIMD are in opposite stages,
-// one barrier per chunk.  Same products, same accumulation order per output: bit-identical results.
+// Producer and matrix stage overlapped (round 5; rounds 3-4 ran them in lock step -- barrier, every wave draws Philox masks and
+// splits (vector ALU, ~9 us per 512-deep chunk), barrier, every wave multiplies (matrix pipe, ~12 us) -- so each pipe idled while the
+// other worked: 0.155 ms for layer 0 where this takes 0.123).  The A planes are double-buffered (chunks of 256: 2 x 2 x 33 KB of
+// LDS) and a chunk step is "produce chunk c + 1, multiply chunk c" for waves 0-3 and "multiply chunk c, produce chunk c + 1" for
+// waves 4-7: waves w and w + 4 of a workgroup share a SIMD, so the two waves of a SIMD are in opposite stages; one barrier per chunk.
 constexpr int PKC = 256;
 constexpr int PSTR = PKC * 2 + 16;          // 33 slots of 16 B
 constexpr int PPLANE = HM * PSTR;
 
-template <int SPLIT>    // which waves produce first: 0 = even waves, 1 = waves 0-3 (waves w and w + 4 of a workgroup share a SIMD)
 __global__ void __launch_bounds__(512) head_dense_pipe_kernel(const HeadParams p) {
     bq_f16_saturate();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [buffer][hi | lo] planes
@@ -274,7 +148,7 @@ __global__ void __launch_bounds__(512) head_dense_pipe_kernel(const HeadParams p
     const int NC = p.K / PKC;
     produce(0, 0);
     __syncthreads();
-    const bool first_produce = SPLIT == 0 ? (wave & 1) == 0 : (wave >> 2) == 0;      // (wave-uniform)
+    const bool first_produce = (wave >> 2) == 0;      // (wave-uniform)
     for (int c = 0; c < NC; ++c) {
         const bool more = c + 1 < NC;
         if (first_produce) {
@@ -312,30 +186,18 @@ __global__ void __launch_bounds__(512) head_dense_pipe_kernel(const HeadParams p
 // One Dense(1024, relu) layer of the MC head over `rows` = tiles x passes rows.  K = 2048 (layer 0) or 1024 (layer 1).
 int launch_head_dense(const float* in, const void* wh, const void* wl, const float* bias, float* out, int rows, int K,
                       int mc_n, int pass0, int in_row_is_tile, int layer, unsigned seed_lo, unsigned seed_hi, unsigned thresh,
-                      float dscale, long long tile0, const long long* tile0_dev, const long long* tile_idx, hipStream_t s, int variant) {
+                      float dscale, long long tile0, const long long* tile0_dev, const long long* tile_idx, hipStream_t s) {
     if (rows <= 0) return 0;
-    if (K % HKC != 0 || !wh || !wl || !bias) return (int)hipErrorInvalidValue;
+    if (K % PKC != 0 || !wh || !wl || !bias) return (int)hipErrorInvalidValue;
     HeadParams p;
     p.in = in; p.wh = reinterpret_cast<const uint4*>(wh); p.wl = reinterpret_cast<const uint4*>(wl);
     p.bias = bias; p.out = out; p.rows = rows; p.K = K;
     p.mc_n = mc_n; p.pass0 = pass0; p.in_row_is_tile = in_row_is_tile; p.layer = layer;
     p.seed_lo = seed_lo; p.seed_hi = seed_hi; p.thresh = thresh; p.dscale = dscale;
     p.tile0 = tile0; p.tile0_dev = tile0_dev; p.tile_idx = tile_idx;
-    if ((variant == 1 || variant == 2) && K % PKC == 0) {
-        constexpr size_t ldsp = 4 * (size_t)PPLANE;
-        static BqLdsAttr a1, a2;
-        if (variant == 1) {
-            if (const int e = a1.ensure(reinterpret_cast<const void*>(head_dense_pipe_kernel<0>), ldsp)) return e;
-            hipLaunchKernelGGL(head_dense_pipe_kernel<0>, dim3((rows + HM - 1) / HM, 1024 / HN), dim3(512), ldsp, s, p);
-        } else {
-            if (const int e = a2.ensure(reinterpret_cast<const void*>(head_dense_pipe_kernel<1>), ldsp)) return e;
-            hipLaunchKernelGGL(head_dense_pipe_kernel<1>, dim3((rows + HM - 1) / HM, 1024 / HN), dim3(512), ldsp, s, p);
-        }
-        return (int)hipGetLastError();
-    }
-    constexpr size_t lds = 2 * (size_t)HPLANE;
+    constexpr size_t ldsp = 4 * (size_t)PPLANE;
     static BqLdsAttr attr;
-    if (const int e = attr.ensure(reinterpret_cast<const void*>(head_dense_kernel), lds)) return e;
-    hipLaunchKernelGGL(head_dense_kernel, dim3((rows + HM - 1) / HM, 1024 / HN), dim3(512), lds, s, p);
+    if (const int e = attr.ensure(reinterpret_cast<const void*>(head_dense_pipe_kernel), ldsp)) return e;
+    hipLaunchKernelGGL(head_dense_pipe_kernel, dim3((rows + HM - 1) / HM, 1024 / HN), dim3(512), ldsp, s, p);
     return (int)hipGetLastError();
 }

@@ -12,10 +12,9 @@
 //    csrc/inflate_fast.h).  A stream's tables live in its 8 KB slice of a caller-provided scratch buffer; zlib's deflate closes a
 //    block every 16 383 symbols whatever the data, so the lanes of a wave reach their block headers -- and rebuild their tables --
 //    together;
-//  * the DIRECT halves of a wave's tables are mirrored in LDS as 16-bit entries (64 lanes x (512 + 64) x 2 B = 72 KB per wave, two
-//    waves per CU): the symbol loop's table load is a ds_read_u16, ~100 cycles, not a trip to L2 (~1 200 cycles per symbol with
-//    the tables in global memory: profiles/r05_inflate.txt); a code longer than the direct width follows a link into the
-//    stream's sub-tables in the scratch buffer.  Length / distance bases are computed from the symbol, not looked up;
+//  * the symbol loop runs in ROUNDS (the round kernel below): a literal-only fast phase out of a small per-lane table in LDS and a
+//    general phase through the global tables that only the stalled lanes enter -- a trip to L2 costs ~1 200 cycles, and with 64
+//    streams in lock step the plain loop pays it per symbol (profiles/r05_inflate.txt);
 //  * the next input dword is loaded one refill ahead of its use;
 //  * output: literals are collected into a dword per lane and stored when it is full; a match copies from the lane's own output.
 // Results are zlib's: a stream is accepted iff it is well-formed and inflates to exactly the expected number of bytes; the Adler-32
@@ -62,35 +61,11 @@ __device__ __forceinline__ unsigned sym_entry(int kind, int sym) {
     return entry(kDistBase[sym], 0, kDistExtra[sym], 0);
 }
 
-// 16-bit form of a direct entry (LDS): type in bits 14-15 -- 0 literal (value in bits 0-7), 1 length / distance SYMBOL (index in
-// bits 0-4), 3 special (bit 0: 0 = end of block, 1 = invalid) --, the code length in bits 8-11; 2 = link to a sub-table of the
-// global table: its first word in bits 0-9, its width (1 .. 9) in bits 10-13.
-__device__ __forceinline__ unsigned short root16_entry(int kind, int sym, int l) {
-    if (kind == 1) {
-        if (sym < 256) return (unsigned short)((unsigned)sym | ((unsigned)l << 8));
-        if (sym == 256) return (unsigned short)(0xC000u | ((unsigned)l << 8));
-        if (sym > 285) return (unsigned short)(0xC001u | ((unsigned)l << 8));
-        return (unsigned short)(0x4000u | (unsigned)(sym - 257) | ((unsigned)l << 8));
-    }
-    if (sym > 29) return (unsigned short)(0xC001u | ((unsigned)l << 8));
-    return (unsigned short)(0x4000u | (unsigned)sym | ((unsigned)l << 8));
-}
-// base value and extra bits of length symbol si = 0 .. 28 / distance symbol di = 0 .. 29 (RFC 1951 3.2.5), computed
-__device__ __forceinline__ void len_base_extra(unsigned si, unsigned& base, unsigned& extra) {
-    extra = (si < 4 || si == 28) ? 0u : (si >> 2) - 1u;
-    base = si < 4 ? 3u + si : (si == 28 ? 258u : 3u + ((4u + (si & 3u)) << extra));
-}
-__device__ __forceinline__ void dist_base_extra(unsigned di, unsigned& base, unsigned& extra) {
-    extra = di < 4 ? 0u : (di >> 1) - 1u;
-    base = di < 4 ? 1u + di : 1u + ((2u + (di & 1u)) << extra);
-}
-
 // Canonical Huffman decode table from code lengths (RFC 1951 3.2.2), two levels.  False for an over-subscribed set of lengths, for
 // one that does not fit the table, and -- as zlib -- for an incomplete set unless it is empty or a single code of length 1 in a
 // literal/length or distance table (unused codes decode as invalid).  The arithmetic of csrc/inflate_fast.h: build_table.
-// root16 (may be null): the 16-bit mirror of the direct entries (root16_entry).
 __device__ __noinline__ bool build_table(const unsigned char* lens, int nsym, unsigned* table, int table_bits, int table_cap, int kind,
-                                         unsigned short* codes, unsigned char* sub_bits, unsigned short* root16) {
+                                         unsigned short* codes, unsigned char* sub_bits) {
     int count[16];
 #pragma unroll
     for (int l = 0; l < 16; ++l) count[l] = 0;
@@ -119,8 +94,6 @@ __device__ __noinline__ bool build_table(const unsigned char* lens, int nsym, un
     const unsigned invalid = entry(1, F_SPECIAL, 0, 1);
     const int primary = 1 << table_bits;
     for (int i = 0; i < primary; ++i) table[i] = invalid;
-    if (root16)
-        for (int i = 0; i < primary; ++i) root16[i] = (unsigned short)0xC101u;        // invalid, one bit
     bool any_long = false;
     for (int l = table_bits + 1; l <= 15; ++l) any_long |= count[l] != 0;
     if (any_long)
@@ -143,7 +116,6 @@ __device__ __noinline__ bool build_table(const unsigned char* lens, int nsym, un
             const int size = 1 << sb;
             if (used + size > table_cap) return false;
             table[pfx] = entry((unsigned)used, F_SUB, (unsigned)sb, (unsigned)table_bits);
-            if (root16) root16[pfx] = (unsigned short)(0x8000u | (unsigned)used | ((unsigned)sb << 10));
             for (int i = 0; i < size; ++i) table[used + i] = invalid;
             used += size;
         }
@@ -155,10 +127,6 @@ __device__ __noinline__ bool build_table(const unsigned char* lens, int nsym, un
         const unsigned e = sym_entry(kind, s) | (unsigned)l;
         if (l <= table_bits) {
             for (unsigned i = rev; i < (unsigned)primary; i += 1u << l) table[i] = e;
-            if (root16) {
-                const unsigned short e16 = root16_entry(kind, s, l);
-                for (unsigned i = rev; i < (unsigned)primary; i += 1u << l) root16[i] = e16;
-            }
         } else {
             const unsigned pe = table[rev & (unsigned)(primary - 1)];
             const unsigned base = pe >> 16, sb = (pe >> 8) & 0x1F;
@@ -203,18 +171,14 @@ struct Bits {
     }
 };
 
-constexpr int ROOT16 = (1 << LT_BITS) + (1 << DT_BITS);      // 16-bit entries per lane in LDS: 576 = 1 152 bytes
-constexpr int INF_NT = 64;                                    // one wave per workgroup: 72 KB of LDS, two workgroups per CU
+constexpr int INF_NT = 64;                                    // one wave per workgroup
 
-// LDSROOT: the direct halves of the tables mirrored in LDS (two waves per CU); otherwise everything from the scratch buffer in
-// global memory (L2) and as many waves per CU as the registers allow -- throughput then comes from occupancy, not latency.
-template <bool LDSROOT>
+// The kernel WITHOUT LDS (option inflate_variant = 0): every table access goes to the stream's scratch slice in global memory (L2) and
+// as many waves per CU as the registers allow -- throughput comes from occupancy, not latency.  It is the fallback for a device
+// whose LDS the round kernel below cannot have (hipFuncSetAttribute refused), and the simplest statement of the algorithm.
 __global__ void __launch_bounds__(INF_NT) inflate_kernel(const InflateParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short root16[];      // [lane][ROOT16]
     const int i = blockIdx.x * INF_NT + threadIdx.x;
     if (i >= p.n) return;
-    unsigned short* const lt16 = LDSROOT ? root16 + threadIdx.x * ROOT16 : nullptr;
-    unsigned short* const dt16 = LDSROOT ? lt16 + (1 << LT_BITS) : nullptr;
     unsigned* const scr = p.scratch + (size_t)i * SCR_WORDS;
     unsigned* const lt = scr + SCR_LT;
     unsigned* const dt = scr + SCR_DT;
@@ -284,7 +248,7 @@ __global__ void __launch_bounds__(INF_NT) inflate_kernel(const InflateParams p) 
                 b.need();
                 cl_mem[kClOrder[k]] = (unsigned char)b.take(3);
             }
-            if (!build_table(cl_mem, 19, dt, 7, 128, 0, codes, sub_bits, nullptr)) { status = INF_BAD_TABLE; break; }
+            if (!build_table(cl_mem, 19, dt, 7, 128, 0, codes, sub_bits)) { status = INF_BAD_TABLE; break; }
             int k = 0;
             const int total = hlit + hdist;
             bool bad = false;
@@ -308,8 +272,8 @@ __global__ void __launch_bounds__(INF_NT) inflate_kernel(const InflateParams p) 
             }
             if (bad || lens[256] == 0) { status = INF_BAD_TABLE; break; }
         }
-        if (!build_table(lens, hlit, lt, LT_BITS, LT_CAP, 1, codes, sub_bits, lt16) ||
-            !build_table(lens + hlit, hdist, dt, DT_BITS, DT_CAP, 2, codes, sub_bits, dt16)) { status = INF_BAD_TABLE; break; }
+        if (!build_table(lens, hlit, lt, LT_BITS, LT_CAP, 1, codes, sub_bits) ||
+            !build_table(lens + hlit, hdist, dt, DT_BITS, DT_CAP, 2, codes, sub_bits)) { status = INF_BAD_TABLE; break; }
         // ---- the symbols of the block
         for (;;) {
             if (b.p > p_limit) { status = INF_OVERRUN; break; }
@@ -317,28 +281,14 @@ __global__ void __launch_bounds__(INF_NT) inflate_kernel(const InflateParams p) 
             // literal / length symbol: the 16-bit direct entry from LDS, a longer code through its link into the global sub-table
             // -- or both levels from the global table
             unsigned kind, nb, val, lbase = 0, lextra = 0;
-            if constexpr (LDSROOT) {
-                const unsigned e16 = lt16[(unsigned)b.buf & ((1u << LT_BITS) - 1u)];
-                kind = e16 >> 14; nb = (e16 >> 8) & 15u; val = e16 & 0xFFu;
-                if (kind == 2u) {
-                    const unsigned e = lt[(e16 & 1023u) + (((unsigned)(b.buf >> LT_BITS)) & ((1u << ((e16 >> 10) & 15u)) - 1u))];
-                    nb = e & 0xFFu;
-                    val = e >> 16;
-                    if (e & F_LITERAL) kind = 0u;
-                    else if (e & F_SPECIAL) kind = 3u;
-                    else { kind = 1u; lbase = val; lextra = (e >> 8) & 0x1Fu; }
-                } else if (kind == 1u) {
-                    len_base_extra(val & 31u, lbase, lextra);
-                }
-            } else {
-                unsigned e = lt[(unsigned)b.buf & ((1u << LT_BITS) - 1u)];
-                if (e & F_SUB) e = lt[(e >> 16) + (((unsigned)(b.buf >> LT_BITS)) & ((1u << ((e >> 8) & 0x1F)) - 1u))];
-                nb = e & 0xFFu;
-                val = e >> 16;
-                if (e & F_LITERAL) kind = 0u;
-                else if (e & F_SPECIAL) kind = 3u;
-                else { kind = 1u; lbase = val; lextra = (e >> 8) & 0x1Fu; }
-            }
+            unsigned e = lt[(unsigned)b.buf & ((1u << LT_BITS) - 1u)];
+            if (e & F_SUB) e = lt[(e >> 16) + (((unsigned)(b.buf >> LT_BITS)) & ((1u << ((e >> 8) & 0x1F)) - 1u))];
+            nb = e & 0xFFu;
+            val = e >> 16;
+            if (e & F_LITERAL) kind = 0u;
+            else if (e & F_SPECIAL) kind = 3u;
+            else { kind = 1u; lbase = val; lextra = (e >> 8) & 0x1Fu; }
+        
             if (kind == 0u) {
                 b.drop((int)nb);
                 if (op >= out_len) { status = INF_LENGTH; break; }
@@ -356,24 +306,11 @@ __global__ void __launch_bounds__(INF_NT) inflate_kernel(const InflateParams p) 
             const unsigned len = lbase + b.take((int)lextra);
             b.need();
             unsigned dnb, dbase, dextra;
-            if constexpr (LDSROOT) {
-                const unsigned d16 = dt16[(unsigned)b.buf & ((1u << DT_BITS) - 1u)];
-                const unsigned dkind = d16 >> 14;
-                dnb = (d16 >> 8) & 15u;
-                if (dkind == 2u) {
-                    const unsigned d = dt[(d16 & 1023u) + (((unsigned)(b.buf >> DT_BITS)) & ((1u << ((d16 >> 10) & 15u)) - 1u))];
-                    if (d & F_SPECIAL) { status = INF_BAD_CODE; break; }
-                    dnb = d & 0xFFu; dbase = d >> 16; dextra = (d >> 8) & 0x1Fu;
-                } else {
-                    if (dkind != 1u) { status = INF_BAD_CODE; break; }
-                    dist_base_extra(d16 & 31u, dbase, dextra);
-                }
-            } else {
-                unsigned d = dt[(unsigned)b.buf & ((1u << DT_BITS) - 1u)];
-                if (d & F_SUB) d = dt[(d >> 16) + (((unsigned)(b.buf >> DT_BITS)) & ((1u << ((d >> 8) & 0x1F)) - 1u))];
-                if (d & F_SPECIAL) { status = INF_BAD_CODE; break; }
-                dnb = d & 0xFFu; dbase = d >> 16; dextra = (d >> 8) & 0x1Fu;
-            }
+            unsigned d = dt[(unsigned)b.buf & ((1u << DT_BITS) - 1u)];
+            if (d & F_SUB) d = dt[(d >> 16) + (((unsigned)(b.buf >> DT_BITS)) & ((1u << ((d >> 8) & 0x1F)) - 1u))];
+            if (d & F_SPECIAL) { status = INF_BAD_CODE; break; }
+            dnb = d & 0xFFu; dbase = d >> 16; dextra = (d >> 8) & 0x1Fu;
+        
             b.drop((int)dnb);
             const unsigned dist = dbase + b.take((int)dextra);
             if (dist > op) { status = INF_BAD_DISTANCE; break; }
@@ -401,234 +338,19 @@ __global__ void __launch_bounds__(INF_NT) inflate_kernel(const InflateParams p) 
     p.status[i] = status;
 }
 
-// ---- variant 2: the wave alternates between a FAST phase and a SLOW phase -------------------------------------------------------------
-// Lanes of a wave share one program counter: in the kernels above a symbol that needs the slow path in ANY of the 64 streams -- a code
+// ---- the round kernel (option inflate_variant = 5, the default) -------------------------------------------------------------------------
+// Lanes of a wave share one program counter: in the kernel above a symbol that needs the slow path in ANY of the 64 streams -- a code
 // longer than the direct table, a match, a refill from memory -- costs all 64 a trip to L2 (~1 000 cycles), and with 64 streams that
 // is every symbol.  Here the two kinds of work are separated in time:
-//   fast phase   up to FAST symbols per lane with NO memory access but one ds_read_u16 each: a per-lane table of 2^L0 16-bit entries
-//                in LDS answers "is the next code a literal of at most L0 bits" (93 % of the symbols of a nearly incompressible tile at
-//                L0 = 8, 99 % of a photo-like one); the literal goes into a 16-byte pending register, the bits come out of the 64-bit
-//                buffer, which the slow phase left with more than 32 bits.  A lane whose next symbol is anything else -- or whose
-//                buffer has run low -- idles until the phase ends;
-//   slow phase   once per round, for all lanes: completed output dwords are stored, the bit buffer is refilled from memory, and a lane
-//                that stopped on a non-literal decodes ONE symbol the general way (two-level tables in the scratch buffer, matches,
+//   fast phase   up to FAST symbols per lane with NO memory access but LDS: a per-lane table of 2^L0 16-bit entries answers "is the
+//                next code a literal of at most L0 bits" (93 % of the symbols of a nearly incompressible tile, 99 % of a photo-like
+//                one); the literal goes to a 32-byte ring in LDS with one ds_write_b8, the bits come out of the 64-bit buffer; the
+//                fast step is a table read, a compare and a shift.  A lane whose next symbol is anything else idles until the phase ends;
+//   slow phase   once per round: the ring's complete dwords are stored, the bit buffer is refilled from memory, and ONLY the lanes
+//                that stopped on a non-literal decode one symbol the general way (two-level tables in the scratch buffer, matches,
 //                end of block, block headers and table construction).
-// The trip to L2 is paid once per round of ~5-7 symbols instead of once per symbol, and by the lanes that need it only.
-template <int L0, int FAST>
-__global__ void __launch_bounds__(INF_NT) inflate_rounds_kernel(const InflateParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short l0_all[];      // [lane][1 << L0]
-    const int i = blockIdx.x * INF_NT + threadIdx.x;
-    const bool mine = i < p.n;
-    const int ii = mine ? i : 0;
-    unsigned short* const l0 = l0_all + threadIdx.x * (1 << L0);
-    unsigned* const scr = p.scratch + (size_t)ii * SCR_WORDS;
-    unsigned* const lt = scr + SCR_LT;
-    unsigned* const dt = scr + SCR_DT;
-    unsigned char* const lens = reinterpret_cast<unsigned char*>(scr + SCR_LENS);
-    unsigned short* const codes = reinterpret_cast<unsigned short*>(scr + SCR_CODES);
-    unsigned char* const sub_bits = reinterpret_cast<unsigned char*>(scr + SCR_SUB);
-    const unsigned char* const zin = p.z + p.off[ii];
-    const unsigned zlen = p.len[ii];
-    unsigned char* const out0 = p.out + (size_t)ii * p.out_stride;
-    const unsigned out_len = p.out_len;
-    int status = INF_OK;
-
-    Bits b;
-    b.open(reinterpret_cast<const unsigned*>(zin));
-    const unsigned* const p_limit = reinterpret_cast<const unsigned*>(zin) + (zlen + 3) / 4 + 4;
-    {
-        const unsigned cmf = b.take(8), flg = b.take(8);
-        if (zlen < 6 || (cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) status = INF_BAD_HEADER;
-    }
-    unsigned op = 0;                            // bytes produced
-    unsigned long long pend_lo = 0, pend_hi = 0;   // the bytes from output position (op - npend) on that are not in memory yet
-    unsigned npend = 0;                         // (op - npend) is a multiple of 4
-    bool final_block = false;
-    enum { ST_HEADER = 0, ST_SYMBOLS = 1, ST_DONE = 2 };
-    int state = mine ? ST_HEADER : ST_DONE;
-    if (status != INF_OK) state = ST_DONE;
-    // pending bytes -> memory, whole dwords only (all == true: the partial dword too, as a dword: positions behind op get zeros that
-    // later bytes overwrite; the output stride leaves room for the last one)
-    auto flush = [&](bool all) {
-        const unsigned base = op - npend;
-        const unsigned nd = all ? (npend + 3) >> 2 : npend >> 2;
-        if (nd > 0) *reinterpret_cast<unsigned*>(out0 + base) = (unsigned)pend_lo;
-        if (nd > 1) *reinterpret_cast<unsigned*>(out0 + base + 4) = (unsigned)(pend_lo >> 32);
-        if (nd > 2) *reinterpret_cast<unsigned*>(out0 + base + 8) = (unsigned)pend_hi;
-        if (nd > 3) *reinterpret_cast<unsigned*>(out0 + base + 12) = (unsigned)(pend_hi >> 32);
-        if (all) { npend = 0; pend_lo = pend_hi = 0; return; }
-        // keep the partial dword
-        const unsigned keep = npend & 3u;
-        unsigned last = nd == 0 ? (unsigned)pend_lo : nd == 1 ? (unsigned)(pend_lo >> 32) : nd == 2 ? (unsigned)pend_hi : (unsigned)(pend_hi >> 32);
-        if (nd >= 4) last = 0;
-        pend_lo = last; pend_hi = 0; npend = keep;
-    };
-    auto put = [&](unsigned byte) {             // one literal into the pending register (npend < 16)
-        if (npend < 8) pend_lo |= (unsigned long long)byte << (8 * npend);
-        else pend_hi |= (unsigned long long)byte << (8 * (npend - 8));
-        ++npend; ++op;
-    };
-
-    while (__builtin_amdgcn_ballot_w64(state != ST_DONE) != 0ull) {
-        // ---- fast phase
-        if (state == ST_SYMBOLS) {
-            bool go = true;
-#pragma unroll
-            for (int f = 0; f < FAST; ++f) {
-                const unsigned e = l0[(unsigned)b.buf & ((1u << L0) - 1u)];
-                const int nb = (int)((e >> 8) & 15u);
-                go = go && (e & 0x8000u) && b.cnt >= nb && op < out_len && npend < 16;
-                if (go) { put(e & 0xFFu); b.drop(nb); }
-            }
-        }
-        // ---- slow phase
-        if (state != ST_DONE) {
-            flush(false);
-            if (b.p > p_limit) { status = INF_OVERRUN; state = ST_DONE; }
-            else { b.need(); b.need(); }                  // (two dwords at most: afterwards more than 32 bits)
-        }
-        if (state == ST_SYMBOLS) {
-            // one symbol the general way -- unless the lane only ran out of bits, in which case this decodes its next literal
-            unsigned e = lt[(unsigned)b.buf & ((1u << LT_BITS) - 1u)];
-            if (e & F_SUB) e = lt[(e >> 16) + (((unsigned)(b.buf >> LT_BITS)) & ((1u << ((e >> 8) & 0x1F)) - 1u))];
-            if (e & F_LITERAL) {
-                if (op >= out_len) { status = INF_LENGTH; state = ST_DONE; }
-                else { b.drop((int)(e & 0xFF)); put(e >> 16); }
-            } else if (e & F_SPECIAL) {
-                if (e >> 16) { status = INF_BAD_CODE; state = ST_DONE; }
-                else { b.drop((int)(e & 0xFF)); state = final_block ? ST_DONE : ST_HEADER; }
-            } else {
-                b.drop((int)(e & 0xFF));
-                const unsigned len = (e >> 16) + b.take((int)((e >> 8) & 0x1F));
-                b.need();
-                unsigned d = dt[(unsigned)b.buf & ((1u << DT_BITS) - 1u)];
-                if (d & F_SUB) d = dt[(d >> 16) + (((unsigned)(b.buf >> DT_BITS)) & ((1u << ((d >> 8) & 0x1F)) - 1u))];
-                if (d & F_SPECIAL) { status = INF_BAD_CODE; state = ST_DONE; }
-                else {
-                    b.drop((int)(d & 0xFF));
-                    const unsigned dist = (d >> 16) + b.take((int)((d >> 8) & 0x1F));
-                    if (dist > op) { status = INF_BAD_DISTANCE; state = ST_DONE; }
-                    else if (len > out_len - op) { status = INF_LENGTH; state = ST_DONE; }
-                    else {
-                        flush(true);                        // the copy reads this lane's own output
-                        unsigned k = 0;
-                        if (dist >= 4) {
-                            for (; k + 4 <= len; k += 4) {  // four loads, then four stores
-                                const unsigned b0 = out0[op - dist], b1 = out0[op - dist + 1], b2 = out0[op - dist + 2], b3 = out0[op - dist + 3];
-                                out0[op] = (unsigned char)b0; out0[op + 1] = (unsigned char)b1; out0[op + 2] = (unsigned char)b2; out0[op + 3] = (unsigned char)b3;
-                                op += 4;
-                            }
-                        }
-                        for (; k < len; ++k) { out0[op] = out0[op - dist]; ++op; }
-                        // the partial dword at the new position comes back into the pending register
-                        npend = op & 3u;
-                        pend_lo = npend ? (*reinterpret_cast<const unsigned*>(out0 + (op & ~3u)) & ((1u << (8 * npend)) - 1u)) : 0u;
-                        pend_hi = 0;
-                    }
-                }
-            }
-        } else if (state == ST_HEADER) {
-            final_block = b.take(1) != 0;
-            const unsigned type = b.take(2);
-            if (type == 0) {
-                b.drop(b.cnt & 7);
-                b.need();
-                const unsigned len = b.take(16);
-                b.need();
-                const unsigned nlen = b.take(16);
-                if ((len ^ nlen) != 0xFFFFu) { status = INF_BAD_BLOCK; state = ST_DONE; }
-                else if (len > out_len - op) { status = INF_LENGTH; state = ST_DONE; }
-                else {
-                    for (unsigned k = 0; k < len && status == INF_OK; ++k) {
-                        b.need();
-                        put(b.take(8));
-                        if (npend >= 12) flush(false);
-                        if (b.p > p_limit) status = INF_OVERRUN;
-                    }
-                    if (status != INF_OK) state = ST_DONE;
-                    else if (final_block) state = ST_DONE;      // (otherwise the next header, next round)
-                }
-            } else if (type == 3) { status = INF_BAD_BLOCK; state = ST_DONE; }
-            else {
-                int hlit = 288, hdist = 32;
-                bool bad = false;
-                if (type == 1) {
-                    for (int k = 0; k < 144; ++k) lens[k] = 8;
-                    for (int k = 144; k < 256; ++k) lens[k] = 9;
-                    for (int k = 256; k < 280; ++k) lens[k] = 7;
-                    for (int k = 280; k < 288; ++k) lens[k] = 8;
-                    for (int k = 0; k < 32; ++k) lens[288 + k] = 5;
-                } else {
-                    b.need();
-                    hlit = (int)b.take(5) + 257; hdist = (int)b.take(5) + 1;
-                    const int hclen = (int)b.take(4) + 4;
-                    if (hlit > 286 || hdist > 30) bad = true;
-                    else {
-                        unsigned char* const cl_mem = sub_bits + 256;
-                        for (int k = 0; k < 19; ++k) cl_mem[k] = 0;
-                        for (int k = 0; k < hclen; ++k) {
-                            b.need();
-                            cl_mem[kClOrder[k]] = (unsigned char)b.take(3);
-                        }
-                        if (!build_table(cl_mem, 19, dt, 7, 128, 0, codes, sub_bits, nullptr)) bad = true;
-                        int k = 0;
-                        const int total = hlit + hdist;
-                        while (!bad && k < total) {
-                            if (b.p > p_limit) { bad = true; break; }
-                            b.need();
-                            const unsigned e = dt[b.peek(7)];
-                            if (e & F_SPECIAL) { bad = true; break; }
-                            b.drop((int)(e & 0xFF));
-                            const unsigned sym = e >> 16;
-                            if (sym < 16) { lens[k++] = (unsigned char)sym; continue; }
-                            unsigned rep, val = 0;
-                            if (sym == 16) {
-                                if (k == 0) { bad = true; break; }
-                                val = lens[k - 1]; rep = 3 + b.take(2);
-                            } else if (sym == 17) rep = 3 + b.take(3);
-                            else rep = 11 + b.take(7);
-                            if (k + (int)rep > total) { bad = true; break; }
-                            for (unsigned r = 0; r < rep; ++r) lens[k + r] = (unsigned char)val;
-                            k += (int)rep;
-                        }
-                        if (!bad && lens[256] == 0) bad = true;
-                    }
-                }
-                if (!bad && (!build_table(lens, hlit, lt, LT_BITS, LT_CAP, 1, codes, sub_bits, nullptr) ||
-                             !build_table(lens + hlit, hdist, dt, DT_BITS, DT_CAP, 2, codes, sub_bits, nullptr))) bad = true;
-                if (bad) { status = status == INF_OK ? INF_BAD_TABLE : status; state = ST_DONE; }
-                else {
-                    // the fast table: the literals whose codes fit L0 bits (their entries repeat over the upper index bits of the
-                    // 9-bit direct table, so entry i of that table answers for index i of this one)
-                    for (int k = 0; k < (1 << L0); ++k) {
-                        const unsigned e = lt[k];
-                        const unsigned nb = e & 0xFFu;
-                        l0[k] = ((e & F_LITERAL) && !(e & F_SUB) && nb <= (unsigned)L0) ? (unsigned short)(0x8000u | (nb << 8) | ((e >> 16) & 0xFFu))
-                                                                                         : (unsigned short)0;
-                    }
-                    state = ST_SYMBOLS;
-                }
-            }
-        }
-    }
-    if (mine) {
-        if (status == INF_OK) {
-            flush(true);
-            if (op != out_len) status = INF_LENGTH;
-            else {
-                b.drop(b.cnt & 7);
-                if (b.consumed(zin) != (long long)zlen - 4) status = INF_TRAILING;
-            }
-        }
-        p.status[i] = status;
-    }
-}
-
-// ---- variants 4 / 5: the rounds again, with a fast phase that is memory-free AND short ------------------------------------------
-// What variants 2 / 3 lost to: ~30 instructions per fast step (a 128-bit pending register with variable shifts) and a slow phase in
-// which EVERY lane decoded a symbol through the global tables.  Here a literal of the fast phase goes to a 32-byte ring in LDS with
-// one ds_write_b8 (the slow phase stores the ring's complete dwords), the fast step is a table read, a compare and a shift, and only
-// the lanes that stopped on a non-literal take the general path.
+// (Rounds 5's other forms -- direct tables mirrored in LDS, a 128-bit pending register, other table widths and phase lengths -- were
+// measured slower and are gone: profiles/r05_inflate.txt has their figures.)
 template <int L0, int FAST>
 __global__ void __launch_bounds__(INF_NT) inflate_rounds2_kernel(const InflateParams p) {
     constexpr int RING = 32;                                   // bytes of output ring per lane
@@ -785,7 +507,7 @@ __global__ void __launch_bounds__(INF_NT) inflate_rounds2_kernel(const InflatePa
                             b.need();
                             cl_mem[kClOrder[k]] = (unsigned char)b.take(3);
                         }
-                        if (!build_table(cl_mem, 19, dt, 7, 128, 0, codes, sub_bits, nullptr)) bad = true;
+                        if (!build_table(cl_mem, 19, dt, 7, 128, 0, codes, sub_bits)) bad = true;
                         int k = 0;
                         const int total = hlit + hdist;
                         while (!bad && k < total) {
@@ -809,8 +531,8 @@ __global__ void __launch_bounds__(INF_NT) inflate_rounds2_kernel(const InflatePa
                         if (!bad && lens[256] == 0) bad = true;
                     }
                 }
-                if (!bad && (!build_table(lens, hlit, lt, LT_BITS, LT_CAP, 1, codes, sub_bits, nullptr) ||
-                             !build_table(lens + hlit, hdist, dt, DT_BITS, DT_CAP, 2, codes, sub_bits, nullptr))) bad = true;
+                if (!bad && (!build_table(lens, hlit, lt, LT_BITS, LT_CAP, 1, codes, sub_bits) ||
+                             !build_table(lens + hlit, hdist, dt, DT_BITS, DT_CAP, 2, codes, sub_bits))) bad = true;
                 if (bad) { status = status == INF_OK ? INF_BAD_TABLE : status; state = ST_DONE; }
                 else {
                     // the fast table: (code length << 8) | value for the literals whose codes fit L0 bits, 0 for everything else
@@ -892,41 +614,15 @@ int launch_inflate(const unsigned char* d_z, const unsigned* d_off, const unsign
     InflateParams p;
     p.z = d_z; p.off = d_off; p.len = d_len; p.out = d_out; p.out_len = out_len; p.out_stride = out_stride; p.row_len = row_len;
     p.scratch = reinterpret_cast<unsigned*>(d_scratch); p.status = d_status; p.n = n;
-    if (variant >= 4 && variant <= 8) {
-        // the rounds with the short fast phase: (fast-table bits, fast steps) = 4: (8, 8), 5: (7, 8), 6: (7, 12), 7: (6, 8), 8: (6, 12)
-        const int l0 = variant == 4 ? 8 : (variant <= 6 ? 7 : 6);
-        const size_t lds = (size_t)INF_NT * ((1u << l0) * 2 + 32);
-        static BqLdsAttr at[5];
-        const void* kern = variant == 4 ? reinterpret_cast<const void*>(inflate_rounds2_kernel<8, 8>)
-                         : variant == 5 ? reinterpret_cast<const void*>(inflate_rounds2_kernel<7, 8>)
-                         : variant == 6 ? reinterpret_cast<const void*>(inflate_rounds2_kernel<7, 12>)
-                         : variant == 7 ? reinterpret_cast<const void*>(inflate_rounds2_kernel<6, 8>)
-                                        : reinterpret_cast<const void*>(inflate_rounds2_kernel<6, 12>);
-        if (const int e = at[variant - 4].ensure(kern, lds)) return e;
-        const dim3 grid((n + INF_NT - 1) / INF_NT), block(INF_NT);
-        if (variant == 4) hipLaunchKernelGGL((inflate_rounds2_kernel<8, 8>), grid, block, lds, s, p);
-        else if (variant == 5) hipLaunchKernelGGL((inflate_rounds2_kernel<7, 8>), grid, block, lds, s, p);
-        else if (variant == 6) hipLaunchKernelGGL((inflate_rounds2_kernel<7, 12>), grid, block, lds, s, p);
-        else if (variant == 7) hipLaunchKernelGGL((inflate_rounds2_kernel<6, 8>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((inflate_rounds2_kernel<6, 12>), grid, block, lds, s, p);
-    } else if (variant == 2 || variant == 3) {
-        // rounds of a fast and a slow phase; 2: an 8-bit fast table (32 KB of LDS per wave, 4-5 waves per CU), 3: 7 bits (16 KB, 8-10)
-        const size_t lds = (size_t)INF_NT * (variant == 2 ? 256 : 128) * 2;
-        static BqLdsAttr a2, a3;
-        if (variant == 2) {
-            if (const int e = a2.ensure(reinterpret_cast<const void*>(inflate_rounds_kernel<8, 8>), lds)) return e;
-            hipLaunchKernelGGL((inflate_rounds_kernel<8, 8>), dim3((n + INF_NT - 1) / INF_NT), dim3(INF_NT), lds, s, p);
-        } else {
-            if (const int e = a3.ensure(reinterpret_cast<const void*>(inflate_rounds_kernel<7, 8>), lds)) return e;
-            hipLaunchKernelGGL((inflate_rounds_kernel<7, 8>), dim3((n + INF_NT - 1) / INF_NT), dim3(INF_NT), lds, s, p);
-        }
-    } else if (variant == 1) {
-        constexpr size_t lds = (size_t)INF_NT * ROOT16 * 2;
-        static BqLdsAttr attr;
-        if (const int e = attr.ensure(reinterpret_cast<const void*>(inflate_kernel<true>), lds)) return e;
-        hipLaunchKernelGGL(inflate_kernel<true>, dim3((n + INF_NT - 1) / INF_NT), dim3(INF_NT), lds, s, p);
+    if (variant != 0) {
+        // option inflate_variant = 5 (default): rounds of a literal-only fast phase (7-bit table + a 32-byte output ring per lane in
+        // LDS, 8 fast steps) and a general phase only stalled lanes enter
+        constexpr size_t lds = (size_t)INF_NT * ((1u << 7) * 2 + 32);
+        static BqLdsAttr at;
+        if (const int e = at.ensure(reinterpret_cast<const void*>(inflate_rounds2_kernel<7, 8>), lds)) return e;
+        hipLaunchKernelGGL((inflate_rounds2_kernel<7, 8>), dim3((n + INF_NT - 1) / INF_NT), dim3(INF_NT), lds, s, p);
     } else {
-        hipLaunchKernelGGL(inflate_kernel<false>, dim3((n + INF_NT - 1) / INF_NT), dim3(INF_NT), 0, s, p);
+        hipLaunchKernelGGL(inflate_kernel, dim3((n + INF_NT - 1) / INF_NT), dim3(INF_NT), 0, s, p);
     }
     hipLaunchKernelGGL(adler_kernel, dim3(n), dim3(64), 0, s, p);
     return (int)hipGetLastError();

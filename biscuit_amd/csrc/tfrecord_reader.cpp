@@ -324,6 +324,7 @@ struct bqio_reader {
     size_t size = 0;
     std::vector<Span> records;
     std::string err;
+    int verify = 0;                          // BQIO_VERIFY_*: FULL also checks the PNG chunk CRCs where a caller takes raw streams
 };
 
 extern "C" {
@@ -339,6 +340,7 @@ bqio_reader* bqio_open(const char* path, int verify) {
     crc_init();
     if (!path) { g_open_error = "path is null"; return nullptr; }
     bqio_reader* r = new (std::nothrow) bqio_reader();
+    if (r) r->verify = verify;
     if (!r) { g_open_error = "out of memory"; return nullptr; }
     auto fail = [&](const std::string& m) { g_open_error = std::string(path) + ": " + m; bqio_close(r); return nullptr; };
     r->fd = open(path, O_RDONLY);
@@ -586,22 +588,37 @@ int bqio_extract_z(bqio_reader* r, int64_t first, int64_t count, int tile_px, ui
             const uint8_t* p = ex.image.p + 8;
             const uint8_t* end = ex.image.p + ex.image.n;
             bool ihdr = false, seen_end = false;
+            int idat = 0;                                      // 0: none yet, 1: inside the run of IDAT chunks, 2: behind it
             uint64_t total = 0;
-            while (end - p >= 12 && !seen_end && e == BQIO_OK) {
+            // stricter than the host decoder (round-5 advisory): the stream goes to the device as it is, so what a PNG reader
+            // is entitled to refuse is refused HERE and the slide takes the host path -- IHDR first, compression and filter
+            // method 0, IDAT chunks consecutive, chunk CRCs when the reader was opened with BQIO_VERIFY_FULL
+            for (int nchunk = 0; end - p >= 12 && !seen_end && e == BQIO_OK; ++nchunk) {
                 const uint32_t n = be32(p);
                 if ((uint64_t)n + 12 > (uint64_t)(end - p)) { e = BQIO_ERR_CORRUPT; break; }
                 const uint8_t* type = p + 4;
                 const uint8_t* data = p + 8;
-                if (!memcmp(type, "IHDR", 4)) {
-                    if (n < 13) { e = BQIO_ERR_CORRUPT; break; }
+                if (r->verify == BQIO_VERIFY_FULL && (uint32_t)crc32(0L, type, (uInt)(n + 4)) != be32(data + n)) {
+                    e = BQIO_ERR_CORRUPT; break;
+                }
+                const bool is_ihdr = !memcmp(type, "IHDR", 4);
+                if ((nchunk == 0) != is_ihdr) { e = BQIO_ERR_CORRUPT; break; }            // IHDR first, and once
+                if (is_ihdr) {
+                    if (n != 13) { e = BQIO_ERR_CORRUPT; break; }
                     const uint32_t w = be32(data), h = be32(data + 4);
-                    if (data[8] != 8 || data[9] != 2 || data[12] != 0) e = BQIO_ERR_UNSUPPORTED;      // 8-bit RGB, not interlaced
+                    if (data[10] != 0 || data[11] != 0) e = BQIO_ERR_CORRUPT;                // compression / filter method
+                    else if (data[8] != 8 || data[9] != 2 || data[12] != 0) e = BQIO_ERR_UNSUPPORTED;   // 8-bit RGB, not interlaced
                     else if ((int)w != tile_px || (int)h != tile_px) e = BQIO_ERR_FORMAT;
                     ihdr = true;
                 } else if (!memcmp(type, "IDAT", 4)) {
+                    if (idat == 2) { e = BQIO_ERR_CORRUPT; break; }                          // IDAT chunks must be consecutive
+                    idat = 1;
                     if (n) pieces[(size_t)i].push_back(Piece{data, n});
                     total += n;
-                } else if (!memcmp(type, "IEND", 4)) seen_end = true;
+                } else {
+                    if (idat == 1) idat = 2;
+                    if (!memcmp(type, "IEND", 4)) seen_end = true;
+                }
                 p += (size_t)n + 12;
             }
             if (e == BQIO_OK && (!ihdr || total == 0 || total > 0x7fffffffull)) e = BQIO_ERR_CORRUPT;

@@ -60,11 +60,13 @@ class TFRecordSource:
         self.z = bool(z)
         self._reader = None
         self._fallback = None
+        self._probed = False                    # the once-per-slide decoder decision (``read``) has been taken
 
     def z_ok(self):
         """True when the whole slide can go the compressed way (every record an 8-bit RGB, non-interlaced PNG of the tile size)."""
         from . import tfrecord_native as tn
-        if not (self.z and tn.available() and self.n_tiles):
+        # (larger tiles: the un-filter kernel takes rows of up to 1 024 bytes = 341 px; those slides stay on the host decoder)
+        if not (self.z and tn.available() and self.n_tiles and self.tile_px <= 341):
             return False
         if self._reader is None:
             self._reader = tn.NativeReader(self.path)
@@ -93,9 +95,12 @@ class TFRecordSource:
         if self._fallback is None and tn.available():
             if self._reader is None:
                 self._reader = tn.NativeReader(self.path)
+            if not self._probed:
                 # ONE decoder per slide, decided before its first chunk: a record the native decoders refuse (a progressive
                 # JPEG, ...) sends the WHOLE slide to Pillow -- as the whole-slide loader does (Slide.load) -- instead of the chunks
-                # from that record on: the native islow IDCT and Pillow's libjpeg-turbo are not bound to agree to the last bit
+                # from that record on: the native islow IDCT and Pillow's libjpeg-turbo are not bound to agree to the last bit.
+                # (Its own flag: ``z_ok`` may have opened the reader already -- round 5 skipped the probe then.)
+                self._probed = True
                 if self._reader.probe(self.tile_px) is not None:
                     self._reader.close()
                     self._reader = None
@@ -117,6 +122,7 @@ class TFRecordSource:
             self._reader.close()
             self._reader = None
         self._fallback = None
+        self._probed = False
 
 
 def pick_unfilter_mode(path, tile_px=299, sample=48):

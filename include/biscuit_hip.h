@@ -88,12 +88,10 @@ int bq_stream_destroy(bq_ctx* ctx, bq_stream_t stream);
  * that).  A context whose launches go to a CU-masked stream sets it to the CUs of the mask: a grid sized for the whole chip runs
  * there as two rounds of workgroups, each with its own prologue.  Results do not depend on it. */
 int bq_set_num_cus(bq_ctx* ctx, int n);
-/* Tuning knobs that change no result.  "inflate_variant": 0 = bq_png_inflate keeps its decode tables in the scratch buffer (global
- * memory / L2; throughput from many waves per CU), 1 = the direct halves of the tables mirrored in LDS (two waves per CU), 2 / 3 =
- * rounds of a literal-only fast phase (small LDS table) and a general slow phase, 4-8 = the same with the literals going to a
- * 32-byte LDS ring per lane and only stalled lanes taking the general path; 5 (7-bit table, 8 waves per CU) is the default:
- * 27.6 k incompressible / 38.8 k photograph-like tiles a second on 16 CUs (profiles/r05_inflate.txt).  "head_variant": the MC head's
- * dense layers with their Philox / split stage and their matrix stage in lock step (0) or overlapped (1, 2 = default). */
+/* Tuning knobs that change no result.  "inflate_variant": 5 (default) = bq_png_inflate decodes in rounds of a literal-only fast
+ * phase (a 7-bit table and a 32-byte output ring per lane in LDS, 8 waves per CU) and a general phase only stalled lanes enter:
+ * 27.6 k incompressible / 38.8 k photograph-like tiles a second on 16 CUs; 0 = the kernel without LDS, decode tables in the scratch
+ * buffer (global memory / L2): the fallback, 2-3 x slower (profiles/r05_inflate.txt).  Anything else: BQ_ERR_ARG. */
 int bq_set_option(bq_ctx* ctx, const char* name, int value);
 
 /* K0, optional front half: the `reinhard_fast` stain normaliser hp.py:19 selects, applied to the
@@ -175,14 +173,6 @@ int bq_set_tile_index_array(bq_ctx* ctx, const int64_t* d_tile_idx);
 int bq_mc_infer(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, int64_t tile_idx0,
                 int mc_n, uint64_t seed, int mc_mode, float* d_mean2, float* d_std2,
                 void* d_ws, size_t ws_bytes, bq_stream_t stream);
-
-/* bq_mc_infer (BQ_MC_HEAD) in two parts, for a caller that schedules two batches in flight against each other: ENTRY = staging,
- * stem and entry flow (blocks 1-4; vector-ALU / HBM-bound kernels), whose output stays in the workspace; REST = middle and
- * exit flow + the MC head (matrix-core bound).  ENTRY then REST on one workspace = bq_mc_infer, bit for bit; d_tiles is not
- * read by REST, d_mean2 / d_std2 not written by ENTRY.  No reference counterpart (scheduling only). */
-enum { BQ_PART_ENTRY = 1, BQ_PART_REST = 2, BQ_PART_ALL = 3 };
-int bq_mc_infer_part(bq_ctx* ctx, const uint8_t* d_tiles_nhwc, int n, int64_t tile_idx0, int mc_n, uint64_t seed, int part,
-                     float* d_mean2, float* d_std2, void* d_ws, size_t ws_bytes, bq_stream_t stream);
 
 /* K7: per-slide sums of y_pred (= mean of P(class 1)) and uncertainty (= std of
  * P(class 1)) plus tile counts, restricted to tiles with uncertainty < tile_uq when

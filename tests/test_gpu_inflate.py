@@ -17,7 +17,7 @@ from biscuit_amd.weights import synthetic_weights
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=[0, 1, 2, 3, 4, 5], ids=['tables_in_l2', 'direct_tables_in_lds', 'rounds_l0_8bit', 'rounds_l0_7bit', 'rounds2_8bit', 'rounds2_7bit'])
+@pytest.fixture(scope='module', params=[0, 5], ids=['tables_in_l2', 'rounds_7bit'])
 def eng(request):
     from biscuit_amd.engine import Engine
     e = Engine(synthetic_weights(1), dtype='f16', max_batch=8, max_mc=2)

@@ -151,22 +151,21 @@ def test_mc_head_against_oracle(engines, oracles):
     assert torch.equal(mb, mf) and torch.equal(sb, sf)
 
 
-def test_head_variants_bit_identical(engines):
-    """The MC head's dense kernels with the dropout / split stage and the matrix stage in lock step (0) or overlapped (1, 2: the
-    default): the same products in the same order, for a full batch, a ragged row count and the one-tile call."""
+def test_head_shapes_against_oracle(engines, oracles):
+    """The MC head's dense kernels (Philox / split stage overlapped with the matrix stage) for a full batch at MC = 30, a ragged row
+    count and the one-tile call, against the oracle's head on the same features; the knobs that round 5 carried are gone."""
+    from biscuit_amd.engine import BiscuitHipError
     eng = engines['f16']
     rng = np.random.default_rng(5)
-    try:
-        for n, mc in ((256, 30), (37, 7), (1, 30)):
-            feat = dev(np.abs(rng.normal(0.8, 0.5, (n, 2048))).astype(np.float32))
-            outs = []
-            for v in (0, 1, 2):
-                eng.set_option('head_variant', v)
-                m, s = eng.mc_head(feat, mc, 99, tile_idx0=1000)
-                outs.append((m.clone(), s.clone()))
-            assert all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) for o in outs), (n, mc)
-    finally:
-        eng.set_option('head_variant', 2)
+    for n, mc in ((256, 30), (37, 7), (1, 30)):
+        feat = np.abs(rng.normal(0.8, 0.5, (n, 2048))).astype(np.float32)
+        m, s = eng.mc_head(dev(feat), mc, 99, tile_idx0=1000)
+        rm, rs = oracles['f32'].mc_from_features(feat, mc, 99, tile_index0=1000)
+        assert np.abs(m.cpu().numpy() - rm).max() < 2e-6 and np.abs(s.cpu().numpy() - rs).max() < 2e-6, (n, mc)
+    with pytest.raises(BiscuitHipError):
+        eng.set_option('head_variant', 2)                        # removed in round 6 (one head kernel)
+    with pytest.raises(BiscuitHipError):
+        eng.set_option('inflate_variant', 3)                     # removed in round 6 (0 and 5 are left)
 
 
 def test_end_to_end_fp32(engines, oracles, tiles):
@@ -363,23 +362,12 @@ def test_full_mode_batching_and_determinism_bit_exact(engines, tiles, dtype):
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_split_entry_points_equal_mc_infer_bit_for_bit(engines, tiles, dtype):
-    """bq_backbone_u8 + bq_mc_head, and bq_mc_infer_part ENTRY then REST, are bq_mc_infer cut in two: the same kernels on the same
-    workspace, so the same bits -- evaluate()'s multi-run batches and a phase-staggered schedule rest on that."""
+    """bq_backbone_u8 + bq_mc_head are bq_mc_infer cut in two: the same kernels on the same workspace, so the same bits."""
     eng = engines[dtype]
     d = dev(tiles)
     m, s = eng.mc_infer(d, 5, 31, tile_idx0=40)
     m2, s2 = eng.mc_head(eng.backbone_u8(d), 5, 31, tile_idx0=40)
     assert torch.equal(m2, m) and torch.equal(s2, s)
-    out = (torch.full_like(m, -1), torch.full_like(s, -1))
-    eng.mc_infer_part('entry', d, 5, 31, tile_idx0=40, out=out)
-    torch.cuda.synchronize()
-    assert float(out[0].max()) == -1.0                            # ENTRY writes no result
-    junk = torch.zeros_like(d)                                    # REST does not read the tiles
-    eng.mc_infer_part('rest', junk, 5, 31, tile_idx0=40, out=out)
-    assert torch.equal(out[0], m) and torch.equal(out[1], s)
-    out = (torch.empty_like(m), torch.empty_like(s))
-    eng.mc_infer_part('all', d, 5, 31, tile_idx0=40, out=out)
-    assert torch.equal(out[0], m) and torch.equal(out[1], s)
 
 
 @pytest.mark.parametrize('dtype,mode', [('f16', 'head'), ('f32', 'head'), ('f16', 'full')])
@@ -653,24 +641,6 @@ def test_engine_pool_two_streams_bit_identical(weights):
     pool2 = EnginePool(weights, n_streams=2, dtype='bf16', max_batch=8, max_mc=8, size_grids=True)
     got = evaluate(pool2, slides, mc_n=4, seed=3, batch=4)
     assert single.tile_df.equals(got.tile_df)
-
-
-@pytest.mark.parametrize('schedule,cus_entry', [('antiphase', None), ('pipeline', 96), ('pipeline', 128)])
-def test_phased_pool_equals_mc_infer_bit_for_bit(weights, engines, schedule, cus_entry):
-    """Every batch cut into ENTRY and REST and the parts of consecutive batches scheduled against each other on CU-masked streams
-    (PhasedPool): the schedule, the split of the chip and the grid sizes change nothing in the results."""
-    from biscuit_amd.engine import PhasedPool
-    pp = PhasedPool(weights, schedule=schedule, cus_entry=cus_entry, dtype='f16', max_batch=6, max_mc=8)
-    batches = [dev(make_tiles(6, seed=300 + i)) for i in range(5)]
-    outs = [(torch.empty((6, 2), device='cuda'), torch.empty((6, 2), device='cuda')) for _ in batches]
-    torch.cuda.synchronize()
-    for i, t in enumerate(batches):
-        pp.step(i, t, 8, 17, 6 * i, outs[i])
-    pp.synchronize()
-    for i, t in enumerate(batches):
-        m, s = engines['f16'].mc_infer(t, 8, 17, tile_idx0=6 * i)
-        assert torch.equal(outs[i][0], m) and torch.equal(outs[i][1], s), (schedule, i)
-    pp.close()
 
 
 @pytest.mark.gpu

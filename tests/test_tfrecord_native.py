@@ -321,3 +321,76 @@ def test_two_streams_in_one_loop():
     except zlib.error:
         ref = None
     assert ref is None or ref != data
+
+
+def test_chunk_source_probes_once_per_slide_whoever_opened_the_reader(tmp_path):
+    """Round-5 advisory: ``TFRecordSource.z_ok()`` (the gpu_decode pre-check) opens the native reader; ``read()`` used to run the
+    once-per-slide probe only when IT opened the reader, so a slide with a progressive JPEG beyond the first chunk -- which sends
+    the WHOLE slide to Pillow -- raised UnsupportedImage mid-run under gpu_decode=True.  The probe has its own flag now."""
+    from PIL import Image
+    from biscuit_amd.inference import TFRecordSource
+    from biscuit_amd.synthetic import make_tiles
+    t = make_tiles(5, seed=12)
+    b = io.BytesIO()
+    Image.fromarray(t[3]).save(b, format='JPEG', quality=90, progressive=True)
+    path = str(tmp_path / 'mixed.tfrecords')
+    tfr.write_slide(path, 'mixed', [tfr.encode_image(t[0]), tfr.encode_image(t[1]), tfr.encode_image(t[2]), b.getvalue(),
+                                    tfr.encode_image(t[4])])
+    want = tfr.read_slide(path, 299)[1]
+    for z in (True, False):
+        src = TFRecordSource(path, 5, 299, rows=False, z=z)
+        assert src.z_ok() is False                      # a JPEG record: never the compressed way
+        out = np.zeros((5, 299, 299, 3), np.uint8)
+        src.read(0, 2, out[:2])                         # first chunk: PNG records only
+        src.read(2, 3, out[2:])                         # the progressive JPEG sits in the second chunk
+        assert src._fallback is not None and np.array_equal(out, want)
+        src.close()
+    big = TFRecordSource(path, 5, 512, z=True)          # tiles the device un-filter cannot take (rows > 1 024 bytes): host decoder
+    assert big.z_ok() is False
+
+
+def test_extract_z_refuses_what_a_png_reader_may_refuse(tmp_path):
+    """``bqio_extract_z`` hands a tile's zlib stream to the DEVICE as it is, so it checks more than the host decoder (round-5
+    advisory): IHDR first and 13 bytes, compression / filter method 0, IDAT chunks consecutive, and -- for a reader opened with
+    verify='full' -- the PNG chunk CRCs.  What it refuses goes to the host decoder (``TFRecordSource.z_ok`` is False)."""
+    import zlib
+
+    def chunk(tag, data, crc=None):
+        c = zlib.crc32(tag + data) & 0xFFFFFFFF if crc is None else crc
+        return struct.pack('>I', len(data)) + tag + data + struct.pack('>I', c)
+    px = 8
+    img = np.random.default_rng(1).integers(0, 256, (px, px, 3), dtype=np.uint8)
+    raw = b''.join(b'\x00' + img[y].tobytes() for y in range(px))
+    z = zlib.compress(raw)
+    sig = b'\x89PNG\r\n\x1a\n'
+    ihdr = struct.pack('>IIBBBBB', px, px, 8, 2, 0, 0, 0)
+    good = sig + chunk(b'IHDR', ihdr) + chunk(b'IDAT', z[:10]) + chunk(b'IDAT', z[10:]) + chunk(b'tEXt', b'k\0v') + chunk(b'IEND', b'')
+    cases = {
+        'good': (good, None),
+        'split': (sig + chunk(b'IHDR', ihdr) + chunk(b'IDAT', z[:10]) + chunk(b'tEXt', b'k\0v') + chunk(b'IDAT', z[10:]) + chunk(b'IEND', b''), IOError),
+        'late_ihdr': (sig + chunk(b'tEXt', b'k\0v') + chunk(b'IHDR', ihdr) + chunk(b'IDAT', z) + chunk(b'IEND', b''), IOError),
+        'compression1': (sig + chunk(b'IHDR', struct.pack('>IIBBBBB', px, px, 8, 2, 1, 0, 0)) + chunk(b'IDAT', z) + chunk(b'IEND', b''), IOError),
+        'filter1': (sig + chunk(b'IHDR', struct.pack('>IIBBBBB', px, px, 8, 2, 0, 1, 0)) + chunk(b'IDAT', z) + chunk(b'IEND', b''), IOError),
+        'two_ihdr': (sig + chunk(b'IHDR', ihdr) + chunk(b'IHDR', ihdr) + chunk(b'IDAT', z) + chunk(b'IEND', b''), IOError),
+    }
+    for name, (png, err) in cases.items():
+        path = str(tmp_path / f'{name}.tfrecords')
+        tfr.write_slide(path, name, [png])
+        with tn.NativeReader(path) as r:
+            buf, off, ln = np.zeros(4096, np.uint8), np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+            if err is None:
+                used, _ = r.extract_z(0, 1, px, buf, off, ln)
+                assert bytes(buf[off[0]:off[0] + ln[0]]) == z and used >= len(z) + 32
+            else:
+                with pytest.raises(err):
+                    r.extract_z(0, 1, px, buf, off, ln)
+    # a chunk CRC that does not match: caught when the reader verifies fully, Adler-32's business otherwise
+    bad = sig + chunk(b'IHDR', ihdr) + chunk(b'IDAT', z, crc=0x12345678) + chunk(b'IEND', b'')
+    path = str(tmp_path / 'badcrc.tfrecords')
+    tfr.write_slide(path, 'badcrc', [bad])
+    buf, off, ln = np.zeros(4096, np.uint8), np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    with tn.NativeReader(path, verify='full') as r:
+        with pytest.raises(IOError):
+            r.extract_z(0, 1, px, buf, off, ln)
+    with tn.NativeReader(path, verify='length') as r:
+        assert r.extract_z(0, 1, px, buf, off, ln)[0] > 0

@@ -13,7 +13,7 @@ from biscuit_amd.weights import synthetic_weights
 ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, nargs='+', default=[1024, 4096, 8192])
 ap.add_argument('--cus', type=int, nargs='+', default=[256, 32, 16])
-ap.add_argument('--variant', type=int, nargs='+', default=[0, 1])
+ap.add_argument('--variant', type=int, nargs='+', default=[0, 5])
 ap.add_argument('--beside', action='store_true', help='also with a two-stream inference loop running on the rest of the chip')
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
