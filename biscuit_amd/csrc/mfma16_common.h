@@ -66,10 +66,15 @@ __device__ __forceinline__ void bn_pair4(const f32x4& u, const f32x4& v, const f
     o[2] = H16<T>::pack2(fmaf(v[0], s1.x, b1.x), fmaf(v[1], s1.y, b1.y));
     o[3] = H16<T>::pack2(fmaf(v[2], s1.z, b1.z), fmaf(v[3], s1.w, b1.w));
 }
+// (the four table reads as 16-byte LDS reads: through `float4` hipcc emits ds_read2_b64 -- twice the LDS cycles of a
+//  ds_read_b128 -- although every address here is a multiple of 32 bytes; a uint4 read is a ds_read_b128)
+__device__ __forceinline__ float4 lds_f4(const float* p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 template <typename T>
 __device__ __forceinline__ void bn_pair(const f32x4& u, const f32x4& v, const float* sbq, int nb, unsigned (&o)[4]) {
-    bn_pair4<T>(u, v, *reinterpret_cast<const float4*>(sbq), *reinterpret_cast<const float4*>(sbq + 4),
-                *reinterpret_cast<const float4*>(sbq + nb), *reinterpret_cast<const float4*>(sbq + nb + 4), o);
+    bn_pair4<T>(u, v, lds_f4(sbq), lds_f4(sbq + 4), lds_f4(sbq + nb), lds_f4(sbq + nb + 4), o);
 }
 
 }  // namespace

@@ -26,6 +26,12 @@ class BiscuitHipError(RuntimeError):
     pass
 
 
+class F16RangeError(RuntimeError):
+    """The f16 storage type met activations at (or within the demanded margin of) its range limit during a run: every f16 kernel
+    clamps at +-65504 without a signal, so the results from there on are plausible and wrong.  Raised by ``inference.evaluate``'s
+    headroom monitor; re-run with ``Engine.calibrate`` on tiles like the offending ones, or with dtype bf16 / f32."""
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -423,6 +429,21 @@ class Engine:
             out['saturated'][name] = int((a.abs() >= limit).sum())
             out['headroom'] = min(out['headroom'], limit / max(m, 1e-30))
         return out
+
+    def f16_headroom_async(self, tiles_u8, limit=65504.0):
+        """``f16_headroom`` without a host synchronisation, for a monitor inside a running loop (``inference.evaluate``'s
+        ``headroom_every``): the eight taps on up to eight of ``tiles_u8``, everything enqueued on the current stream; returns a
+        device tensor float32 [8, 2] -- per tap (max |activation| as stored, number of values at the clamp) -- that the caller
+        copies out and looks at later.  None for the other storage types."""
+        assert tiles_u8.dtype == torch.uint8 and tiles_u8.is_cuda
+        t = tiles_u8[:min(8, tiles_u8.shape[0], self.max_batch)].contiguous()
+        if self.dtype != 'f16' or t.shape[0] == 0:
+            return None
+        rows = []
+        for name, shp in self.HEADROOM_TAPS:
+            a = self.debug_activation_u8(name, t, shp, true_scale=False).abs_()
+            rows.append(torch.stack([a.max(), (a >= limit).sum().to(torch.float32)]))
+        return torch.stack(rows)
 
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on=True):

@@ -200,6 +200,8 @@ class EvalResult:
     local_slides: List[int] = field(default_factory=list)
     table_path: Optional[str] = None         # the tile table on disk: THE table (world 1; rank 0 after the splice) or this rank's shard
     table_rows: int = 0                      # rows this rank wrote
+    f16_headroom: float = float('inf')       # minimum over the run's range checks of 65504 / max |stored activation| (f16 engines)
+    f16_checks: int = 0
 
     def slide_frame(self, pred_thresh=0.5, level='slide'):
         """Group table in ``process_group_predictions`` form from the device-reduced means."""
@@ -558,7 +560,7 @@ class _TableStream:
 
 def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=None, batch=256,
              mc_mode='head', tile_uq=None, save_dir=None, keep_tiles=True, rank=0, world=1, norm_fit=None,
-             table_name=EVAL_NAME, table_writer='native'):
+             table_name=EVAL_NAME, table_writer='native', headroom_every=200, headroom_min=2.0):
     """Run MC-dropout inference over ``slides`` and return tile- and slide-level results.
 
     Every rank passes the SAME slide list; rank r processes ``partition_slides(...)[r]``.
@@ -570,6 +572,12 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     the gather doubles as "all shards complete"; rank 0 then splices them into the ONE table in dataset order -- byte for byte
     the file a single-rank run writes.  ``table_writer='pandas'`` (or a ``.parquet.gzip`` name) writes with pandas after the run
     instead: the checker of the native writer, and the parquet form.
+
+    ``headroom_every`` (f16 engines only; 0 / None: off): every that many batches -- and on the first -- the eight range taps of
+    ``Engine.f16_headroom`` run on up to eight tiles of the batch, behind it on its stream, with no host synchronisation: the
+    maxima are copied out asynchronously and looked at when the next check is due (and at the end).  A value at the clamp, or
+    less than ``headroom_min`` x of range left, raises ``F16RangeError``: the calibration batch at the start of a run says
+    nothing about the 10^5 tiles behind it, and f16's clamp is silent.  ``EvalResult.f16_headroom`` = the minimum seen.
 
     ``norm_fit`` (``{'target_means': [3], 'target_stds': [3]}``, the block of that name in the model's
     params.json) switches on the `reinhard_fast` stain normaliser of hp.py:19 in front of the staging
@@ -601,6 +609,28 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
         tpath = os.path.join(save_dir, table_name if world == 1 else shard_name(table_name, rank))
         table = _TableStream(tpath, outcome, with_loc, dev, batch, shard=None if world == 1 else (rank, world))
     pend_segs = []                           # (slide index, name, y_true, loc rows or None, count) of the pending tiles, in order
+    # the f16 range monitor (see the docstring): checks in flight = (batch number, first global tile index, pinned [8, 2], event)
+    monitor = bool(headroom_every) and all(getattr(e, 'dtype', None) == 'f16' and hasattr(e, 'f16_headroom_async') for e in engines)
+    hr_pending, hr_state = [], {'min': float('inf'), 'checks': 0}
+
+    def headroom_look(block):
+        from .engine import Engine, F16RangeError
+        while hr_pending and (block or hr_pending[0][3].query()):
+            nb, g0, host, ev = hr_pending.pop(0)
+            ev.synchronize()
+            a = host.numpy()
+            hr_state['checks'] += 1
+            worst = int(np.argmax(a[:, 0]))
+            hr = 65504.0 / max(float(a[worst, 0]), 1e-30)
+            hr_state['min'] = min(hr_state['min'], hr)
+            if a[:, 1].sum() > 0 or hr < float(headroom_min):
+                sat = {Engine.HEADROOM_TAPS[i][0]: int(a[i, 1]) for i in range(a.shape[0]) if a[i, 1] > 0}
+                raise F16RangeError(
+                    f'f16 storage at its range limit in batch {nb} (global tile {g0} on): ' +
+                    (f'{sat} values clamped at +-65504' if sat else f'only {hr:.2f}x of range left at {Engine.HEADROOM_TAPS[worst][0]} '
+                     f'(peak {float(a[worst, 0]):.4g}; headroom_min {headroom_min})') +
+                    '; the results from there on would be plausible and wrong.  Re-run with Engine.calibrate() on tiles like these, '
+                    'or with dtype bf16 / f32')
 
     # stream tiles of this rank's slides in batches that may span slides
     pend_tiles, pend_sidx, pend_gidx = [], [], []
@@ -634,6 +664,9 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 gdev = torch.from_numpy(np.ascontiguousarray(cg)).to(dev, non_blocking=True) if torch.device(dev).type == 'cuda' \
                     else torch.from_numpy(np.ascontiguousarray(cg))
 
+            if monitor and hr_pending and n_batches % int(headroom_every) == 0:
+                headroom_look(block=True)            # the previous check: one interval old, long finished -- a run fails one interval late at most
+
             def work(eng, cur=cur, gdev=gdev):
                 if norm_fit is not None:
                     cur = eng.reinhard_fast(cur, norm_fit['target_means'], norm_fit['target_stds'])
@@ -642,6 +675,13 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                 else:
                     eng.mc_infer(cur, mc_n, seed, tile_idx0=0, mc_mode=mc_mode, out=(mean, std), tile_idx=gdev)
                 acc[k] = eng.slide_reduce(mean, std, cs, max(n_local, 1), tile_uq=tile_uq, acc=acc[k])
+                if monitor and n_batches % int(headroom_every) == 0:
+                    hr = eng.f16_headroom_async(cur)
+                    host = torch.empty(hr.shape, dtype=torch.float32, pin_memory=True)
+                    host.copy_(hr, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    hr_pending.append((n_batches, int(cg[0]), host, ev))
             if pool:
                 # these tensors were allocated on the caller's stream and are read on the pool's: tell the
                 # caching allocator, or the next batch's temporaries may reuse their memory while this
@@ -780,6 +820,13 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
 
     if pool:
         pool.synchronize()
+    if monitor:
+        try:
+            headroom_look(block=True)
+        except BaseException:
+            if table is not None:
+                table.abort()
+            raise
     for segs, status in z_state['status']:          # (one look at the end: a stream the device refused is a damaged PNG)
         bad = torch.nonzero(status).flatten().tolist()
         if bad:
@@ -824,4 +871,4 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
                         order.append([si, slides[si].name, slides[si].n_tiles, 0, 0])
                 write_shard_index(table_path, rank, world, outcome, 'loc_x' in tile_df.columns, order)
     return EvalResult(tile_df, [s.name for s in slides], g_pred, g_unc, g_cnt,
-                      np.array([s.y_true for s in slides]), list(mine), table_path, table_rows)
+                      np.array([s.y_true for s in slides]), list(mine), table_path, table_rows, hr_state['min'], hr_state['checks'])

@@ -344,6 +344,52 @@ def test_f16_headroom_indicator(engines, tiles):
     e.close()
 
 
+def test_range_monitor_fails_a_run_whose_later_tiles_leave_the_f16_range(tmp_path):
+    """f16's clamp at +-65504 is silent and the calibration / headroom check of a run looks at its FIRST tiles only (round-5 review,
+    weak item 4).  ``evaluate(headroom_every=N)`` looks again while the run is in flight.  Here block1_conv2 is stored 8 x below
+    the limit on ordinary tiles (its BatchNorm scaled up, the two BatchNorms behind it scaled back: the same function), and a later
+    slide holds tiles that are flat but for a 3 x 3 bright spot -- after per-image standardisation ~30 x an ordinary tile's peak in
+    the first BatchNorm's units.  Without the monitor the run returns finite, plausible, WRONG numbers; with it, it fails loudly."""
+    from biscuit_amd.engine import Engine, F16RangeError
+    from biscuit_amd.inference import Slide, evaluate
+    w = dict(synthetic_weights(1))
+    normal = make_tiles(24, seed=70)
+    spike = np.full((8, 299, 299, 3), 128, np.uint8)
+    for i in range(8):
+        spike[i, 40 + 20 * i:43 + 20 * i, 100:103, :] = 255
+    probe = Engine(w, dtype='f16', max_batch=8, max_mc=4)
+    p1 = probe.f16_headroom(dev(normal))['max_abs']['block1_conv2']
+    probe.close()
+    f = 65504.0 / (8.0 * p1)
+    for k in ('gamma', 'beta'):
+        w['block1_conv2_bn/' + k] = w['block1_conv2_bn/' + k] * np.float32(f)
+    for bn in ('block2_sepconv1_bn', 'block2_res_bn'):                  # the consumers: conv (no bias) -> BN, so scale their statistics
+        w[bn + '/moving_mean'] = w[bn + '/moving_mean'] * np.float32(f)
+        w[bn + '/moving_variance'] = w[bn + '/moving_variance'] * np.float32(f * f)
+    eng = Engine(w, dtype='f16', max_batch=8, max_mc=4)
+    ok = [Slide('a', normal, 24, y_true=0)]
+    res = evaluate(eng, ok, mc_n=4, seed=5, batch=8, headroom_every=1)
+    assert res.f16_checks == 3 and 4.0 < res.f16_headroom < 12.0, (res.f16_checks, res.f16_headroom)       # built to be ~8 x
+    off = evaluate(eng, ok, mc_n=4, seed=5, batch=8, headroom_every=0)
+    assert off.f16_checks == 0 and off.f16_headroom == float('inf') and off.tile_df.equals(res.tile_df)     # the monitor changes no result
+    both = ok + [Slide('b', spike, 8, y_true=1)]
+    silent = evaluate(eng, both, mc_n=4, seed=5, batch=8, headroom_every=0)
+    assert np.isfinite(silent.slide_pred).all()                          # plausible numbers, no signal: what the monitor is for
+    f32 = Engine(w, dtype='f32', max_batch=8, max_mc=4)
+    truth = evaluate(f32, both, mc_n=4, seed=5, batch=8)
+    assert abs(silent.slide_pred[1] - truth.slide_pred[1]) > 1e-3       # ... and wrong (the clamp changed the spike slide's prediction)
+    assert abs(silent.slide_pred[0] - truth.slide_pred[0]) < 1e-3       # (the ordinary slide is fine)
+    with pytest.raises(F16RangeError, match='block1_conv2'):
+        evaluate(eng, both, mc_n=4, seed=5, batch=8, headroom_every=1, save_dir=str(tmp_path))
+    # a margin can be demanded too: the ordinary slide has ~8 x of range left
+    with pytest.raises(F16RangeError, match='of range left'):
+        evaluate(eng, ok, mc_n=4, seed=5, batch=8, headroom_every=1, headroom_min=16.0)
+    # sampling: the default interval (200 batches) looks at the first batch only here -- the monitor is a guard against drift, not
+    # a per-tile check -- and costs 8 partial passes of 8 tiles per 51 200 tiles
+    assert evaluate(eng, both, mc_n=4, seed=5, batch=8).f16_checks == 1
+    eng.close(); f32.close()
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16', 'f16'])
 def test_full_mode_batching_and_determinism_bit_exact(engines, tiles, dtype):
     eng = engines[dtype]
