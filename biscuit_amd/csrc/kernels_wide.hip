@@ -640,6 +640,9 @@ __global__ void __launch_bounds__(64 * WN) sepconv_wide_kernel(const WideParams 
             if constexpr (DMODE == 1) dw_ops<T, RELU, PW, KP, NSTEP, dw_before<NSLOTQ, NDW>(Q), dw_before<NSLOTQ, NDW>(Q + 1)>(st, smem, raw_addr, tap_addr, awn);
             if constexpr (DMODE == 2) dw_ops<T, RELU, PW, KP, NSTEP, dw_before<NSLOTQ, NDW>(2 * Q), dw_before<NSLOTQ, NDW>(2 * Q + 2)>(st, smem, raw_addr, tap_addr, awn);
 #endif
+#if defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 96)           // 32 = no MFMA on the last m-fragment, 64 = none on n-fragments 4, 5 of six:
+            if constexpr (!(((WIDE_ABLATE & 32) && I == MF - 1 && MF == 5) || ((WIDE_ABLATE & 64) && RN == 6 && J >= 4)))   // what the padding costs
+#endif
 #if !(defined(BQ_EXPERIMENTS) && (WIDE_ABLATE & 4))          // 4 = no MFMA
             if constexpr (BPRE) mfma16_ab<T, FIRST && D == 0>(acc[I][J], bb[CUR][D][J], a[I]);
             else if constexpr (FIRST && D == 0) mfma16_first<T>(acc[I][J], bq[J], a[I]);
