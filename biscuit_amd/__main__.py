@@ -95,7 +95,8 @@ def main(argv=None):
     ap.add_argument('--gpu-decode', type=int, default=0, metavar='CUS',
                     help='decode PNG tiles on the GPU: the host only copies their zlib streams, CUS compute units (16-32) kept out of '
                          'the inference streams inflate them.  For hosts with few free cores per GPU and runs of >= 30 k tiles; '
-                         'slower than 16 host threads otherwise (profiles/r05_inflate.txt)')
+                         'slower than 16 host threads otherwise (profiles/r05_inflate.txt).  Pins 3 x up to 1 GiB of host memory per rank for the '
+                         'compressed ring (4 096-tile chunks) and allocates ~3 GB on the device per chunk in flight')
     ap.add_argument('--detect', action='store_true',
                     help='also run threshold.detect on the tile table (Youden thresholds over every tile of the cohort, threshold.py:364-475)')
     ap.add_argument('--dist-backend', default=None, help='process-group backend for WORLD_SIZE > 1 (default nccl = RCCL; gloo for a rehearsal '

@@ -738,8 +738,22 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
 
     # gpu_decode: compressed chunks are inflated on the pool's decode streams (CU-masked: the compute units it keeps out of the
     # inference streams; without a pool, the current stream), round-robin, each with its own table scratch; the status words are
-    # looked at once, at the end
+    # looked at one chunk late (check_z)
     z_state = {'k': 0, 'scratch': {}, 'status': []}
+
+    def check_z(block):
+        while z_state['status'] and (block or z_state['status'][0][2].query()):
+            segs, status, ev2 = z_state['status'].pop(0)
+            ev2.synchronize()
+            bad = np.flatnonzero(status.numpy()).tolist()
+            if bad:
+                at, where = 0, None
+                for (_, si, first, c) in segs:
+                    if at <= bad[0] < at + c:
+                        where = f'{slides[si].name}, tile {first + bad[0] - at}'
+                    at += c
+                raise IOError(f'the device inflate refused {len(bad)} tile(s) (first: {where}, status {int(status[bad[0]])}): damaged PNG '
+                              f'data; decode on the host (gpu_decode=False) to see the decoder\'s own error')
 
     def decode_z(buf, cap, count, ev, px, segs):
         eng0 = engines[0]
@@ -761,7 +775,15 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             done.record(dec)
         main.wait_event(done)
         rows.record_stream(main)
-        z_state['status'].append((segs, status))
+        # the status words leave the device behind the inflate (a few KB, pinned, on the decode stream) and are looked at when the NEXT
+        # chunk arrives -- one chunk late, without stalling anything: a damaged stream stops the run there instead of after it
+        host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+        with torch.cuda.stream(dec):
+            host.copy_(status, non_blocking=True)
+            ev2 = torch.cuda.Event()
+            ev2.record(dec)
+        check_z(block=False)
+        z_state['status'].append((segs, host, ev2))
         return eng0.png_unfilter_strided(rows, px=px)
 
     def stream_slides():
@@ -827,16 +849,12 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
             if table is not None:
                 table.abort()
             raise
-    for segs, status in z_state['status']:          # (one look at the end: a stream the device refused is a damaged PNG)
-        bad = torch.nonzero(status).flatten().tolist()
-        if bad:
-            at, where = 0, None
-            for (_, si, first, c) in segs:
-                if at <= bad[0] < at + c:
-                    where = f'{slides[si].name}, tile {first + bad[0] - at}'
-                at += c
-            raise IOError(f'the device inflate refused {len(bad)} tile(s) (first: {where}, status {int(status[bad[0]])}): damaged PNG '
-                          f'data; decode on the host (gpu_decode=False) to see the decoder\'s own error')
+    try:
+        check_z(block=True)                         # what is left: the last chunks
+    except BaseException:
+        if table is not None:
+            table.abort()
+        raise
     live = [a for a in acc if a is not None]
     if live:
         # per-stream fixed-point accumulators are integers: their sum is exact and order-free

@@ -122,8 +122,8 @@ class UnsupportedImage(ValueError):
 
 def default_threads():
     """Decoder threads of one process: the cores it may use (its affinity mask, which ``distributed.pin_rank`` narrows to the
-    rank's share of the node, capped by the cgroup's CPU quota) -- no fixed ceiling: a 64-core share decodes on 64 threads, and
-    eight ranks on one node do not start 8 x 16 threads on the same cores."""
+    rank's share of the node, capped by the cgroup's CPU quota), at most 64: a 64-core share decodes on 64 threads -- twice what
+    one GPU consumes --, and eight ranks on one node do not start 8 x 16 threads on the same cores."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -134,7 +134,7 @@ def default_threads():
             n = min(n, max(1, int(float(quota) / float(period))))
     except (OSError, ValueError):
         pass
-    return max(1, n)
+    return max(1, min(n, 64))
 
 
 class NativeReader:
