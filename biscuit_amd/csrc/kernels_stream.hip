@@ -34,6 +34,13 @@
 #ifndef STREAM_NW
 #define STREAM_NW 12
 #endif
+// The depthwise stage of f16 instances in PACKED HALF arithmetic (v_pk_fma_f16 on the dwords as they arrive: taps rounded to f16,
+// nine roundings per output instead of one; no conversions, half the registers of the running sums): bit 0 = the fused block
+// tails (block2_sepconv2, block3_sepconv2), bit 1 = the plain streaming layers (block2_sepconv1, block3_sepconv1).  Measured in
+// round 6 (experiments/r06.md).
+#ifndef STREAM_DW_F16
+#define STREAM_DW_F16 0
+#endif
 #ifndef TAIL_NW
 #define TAIL_NW 8
 #endif
@@ -89,6 +96,50 @@ struct DwSums {
         }
     }
 };
+
+// The same running sums in packed half arithmetic (STREAM_DW_F16, f16 instances only): the window is the packed dwords themselves.
+typedef _Float16 h16x2p __attribute__((ext_vector_type(2)));
+template <int NCOL>
+struct DwSumsH {
+    h16x2p sa[NCOL], sb[NCOL];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int x = 0; x < NCOL; ++x) { sa[x] = (h16x2p){0, 0}; sb[x] = (h16x2p){0, 0}; }
+    }
+    template <bool OUT>
+    __device__ __forceinline__ void push(const h16x2p (&tap)[9], const unsigned (&row)[NCOL + 2], unsigned char* a_lane, int ast) {
+        h16x2p v[NCOL + 2];
+#pragma unroll
+        for (int j = 0; j < NCOL + 2; ++j) v[j] = __builtin_bit_cast(h16x2p, row[j]);
+#pragma unroll
+        for (int x = 0; x < NCOL; ++x) {
+            if constexpr (OUT) {
+                h16x2p o = sa[x];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) o = __builtin_elementwise_fma(tap[6 + dx], v[x + dx], o);
+                *reinterpret_cast<unsigned*>(a_lane + x * ast) = __builtin_bit_cast(unsigned, o);
+            }
+            h16x2p a = sb[x];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) a = __builtin_elementwise_fma(tap[3 + dx], v[x + dx], a);
+            sa[x] = a;
+            h16x2p b = {0, 0};
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) b = __builtin_elementwise_fma(tap[dx], v[x + dx], b);
+            sb[x] = b;
+        }
+    }
+};
+// the depthwise state of an instance: packed half for f16 when STREAM_DW_F16, fp32 pairs otherwise
+template <typename T, int NCOL, bool WANT> struct DwSel { typedef DwSums<T, NCOL> sums; typedef f32x2s tap_t; };
+template <int NCOL> struct DwSel<f16_t, NCOL, true> { typedef DwSumsH<NCOL> sums; typedef h16x2p tap_t; };
+constexpr bool DW_HALF_TAIL = (STREAM_DW_F16 & 1) != 0, DW_HALF_PLAIN = (STREAM_DW_F16 & 2) != 0;
+template <typename TAP>
+__device__ __forceinline__ TAP load_tap(const float* p) {
+    const f32x2s t = *reinterpret_cast<const f32x2s*>(p);
+    if constexpr (sizeof(TAP) == 4) return (TAP){(_Float16)t.x, (_Float16)t.y};
+    else return t;
+}
 
 // ---- pointwise: D[cout][pixel] = W[cout][k] * A[pixel][k] from the wave's A tile (LDS operations of a wave complete in order)
 template <typename T, int KS, int NF>
@@ -164,9 +215,10 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
     }
     const int cpair = HALVES == 1 ? lane : (lane & 31);
     const int chalf = HALVES == 1 ? 0 : (lane >> 5);
-    f32x2s tap[9];
+    typedef DwSel<T, NCOL, DW_HALF_PLAIN> DW;
+    typename DW::tap_t tap[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) tap[t] = *reinterpret_cast<const f32x2s*>(p.dw + t * CIN + 2 * cpair);
+    for (int t = 0; t < 9; ++t) tap[t] = load_tap<typename DW::tap_t>(p.dw + t * CIN + 2 * cpair);
     __syncthreads();                            // the only workgroup barrier of the kernel
 
     unsigned char* const At = smem + A_OFF + wave * A_BYTES;
@@ -220,7 +272,7 @@ __global__ void __launch_bounds__(NW * 64) sepconv_stream_kernel(const StreamPar
 #pragma unroll
             for (int j = 0; j < NWIN; ++j) row[j] = ((m >> j) & 1u) ? row[j] : 0u;
         };
-        DwSums<T, NCOL> dws;
+        typename DW::sums dws;
         dws.clear();
         load_row(y0 - 1); take_row(y0 - 1);
         load_row(y0);
@@ -332,9 +384,10 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
         float* sbw = reinterpret_cast<float*>(smem + SB_OFF);
         sbw[i] = p.scale[i]; sbw[COUT + i] = p.bias[i]; sbw[2 * COUT + i] = p.rscale[i]; sbw[3 * COUT + i] = p.rbias[i];
     }
-    f32x2s tap[9];
+    typedef DwSel<T, NCOL, DW_HALF_TAIL> DW;
+    typename DW::tap_t tap[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) tap[t] = *reinterpret_cast<const f32x2s*>(p.dw + t * CIN + 2 * lane);
+    for (int t = 0; t < 9; ++t) tap[t] = load_tap<typename DW::tap_t>(p.dw + t * CIN + 2 * lane);
     __syncthreads();
 
     unsigned char* const At = smem + A_OFF + wave * A_BYTES;
@@ -397,7 +450,7 @@ __global__ void __launch_bounds__(NW * 64) block_tail_stream_kernel(const TailPa
 #pragma unroll
             for (int j = 0; j < NWIN; ++j) row[j] = ((m >> j) & 1u) ? row[j] : 0u;
         };
-        DwSums<T, NCOL> dws;
+        typename DW::sums dws;
         dws.clear();
         load_row(ys - 1); take_row(ys - 1);
         load_row(ys);
@@ -564,9 +617,10 @@ __global__ void __launch_bounds__(C * 2, WGS) block_tail_coop_kernel(const CoopP
 #pragma unroll
         for (int i = 0; i < 2; ++i) wrq[ks][i] = p.wr16[((size_t)ks * NFR + 2 * wave + i) * 64 + lane];
     const int pair = lane & 15, cg = lane >> 4;                      // depthwise role: channels 32 w + 2 pair (+1), columns 4 cg .. 4 cg + 3
-    f32x2s tap[9];
+    typedef DwSel<T, NCOL, DW_HALF_TAIL> DW;
+    typename DW::tap_t tap[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) tap[t] = *reinterpret_cast<const f32x2s*>(p.dw + t * CIN + 32 * wave + 2 * pair);
+    for (int t = 0; t < 9; ++t) tap[t] = load_tap<typename DW::tap_t>(p.dw + t * CIN + 32 * wave + 2 * pair);
     __syncthreads();
 
     const int px = lane & 15, g = lane >> 4;                         // matrix role: pixel slot, channel group
@@ -623,7 +677,7 @@ __global__ void __launch_bounds__(C * 2, WGS) block_tail_coop_kernel(const CoopP
 #pragma unroll
             for (int j = 0; j < NWIN; ++j) row[j] = ((m >> j) & 1u) ? row[j] : 0u;
         };
-        DwSums<T, NCOL> dws;
+        typename DW::sums dws;
         dws.clear();
         unsigned char* a_lane0 = smem + (NCOL * cg) * AST + (32 * wave + 2 * pair) * 2;      // buffer 0; buffer 1 at + A_BYTES
         // Software pipeline: a step pushes row y + 2 -- the depthwise output of row y + 1 goes to the OTHER A buffer -- and
