@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy a round's evidence from gpurun_out/ (scratch) into profiles/ (tracked) and refresh the summaries: bash tools/collect.sh r05
-T=${1:-r05}
+T=${1:-r06}
 set -e
 python tools/summarize_prof.py gpurun_out/prof_${T} profiles/${T}_rocprof.md f16 > /dev/null
 cp "$(ls -t gpurun_out/prof_${T}/trace/runc/*_kernel_stats.csv | head -1)" profiles/${T}_kernel_stats.csv      # (gpurun_out accumulates: the newest run's)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# A round's evidence run on the GPU box (bash tools/gpu_round.sh r05): tests, the default bench, config 3's per-GPU share, the MC
+# A round's evidence run on the GPU box (bash tools/gpu_round.sh r06): tests, the default bench, config 3's per-GPU share, the MC
 # sweep, rocprofv3 passes (tools/profile.sh), SQ counters (tools/pmc_sq.sh); tools/collect.sh copies the results into profiles/.
-T=${1:-r05}
+T=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd $R
