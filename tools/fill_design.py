@@ -1,7 +1,8 @@
-"""DESIGN.md and README.md from their templates (tools/templates/*.in: the text, with R05_* placeholders where a measured number goes) and
-profiles/<tag>_bench.json: python tools/fill_design.py r05 <cpu tests> <gpu tests>.  Edit the TEMPLATES, then run this."""
+"""DESIGN.md and README.md from their templates (tools/templates/*.in: the text, with RND_* placeholders where a measured number goes),
+profiles/<tag>_bench.json and profiles/<tag>_bench_cfg3_share.json: python tools/fill_design.py r06 <cpu tests> <gpu tests>.
+Edit the TEMPLATES, then run this."""
 import json, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 d = json.load(open(f'profiles/{tag}_bench.json'))
 ks = d['kernels']
 rows = ['| kernel (profiling class) | file | launches | ms per launch | frac of its roofline |', '|---|---|---:|---:|---:|']
@@ -17,18 +18,25 @@ where = {'sepconv_k728_n728_19x19': 'kernels_wide.hip', 'sepconv_k728_n728_37x37
 for k in ks:
     rows.append(f"| `{k['name']}` | {where.get(k['name'], '')} | {k['launches_per_step']:.0f} | {k['ms_per_launch']:.4f} | {k['frac_of_bound']:.2f} |")
 t = d['tfrecords']
+c3 = json.load(open(f'profiles/{tag}_bench_cfg3_share.json'))
+wide = next(k for k in ks if k['name'] == d['roofline']['kernel'])
 rep = {
-    'R05_VALUE': f"{d['value']:,.0f}", 'R05_MS': f"{d['ms_per_step']:.2f}",
-    'R05_HBM': f"{100 * d['path_roofline']['hbm_frac']:.1f}", 'R05_MFMA': f"{100 * d['path_roofline']['mfma_frac']:.1f}",
-    'R05_CPU_TESTS': sys.argv[2] if len(sys.argv) > 2 else '?', 'R05_GPU_TESTS': sys.argv[3] if len(sys.argv) > 3 else '?',
-    'R05_CPU': f"{d['cpu_baseline']['value']:.2f}",
-    'R05_WIDE_MS': f"{d['roofline']['avg_launch_ms']:.4f}", 'R05_WIDE_FRAC': f"{100 * d['roofline']['frac']:.1f} %",
-    'R05_ENTRY': f"{d['entry_side_ms']:.2f}",
-    'R05_KERNEL_TABLE': '\n'.join(rows),
-    'R05_TFR_FRAC': f"{100 * max(t['value'], t['gpu_unfilter_value']) / d['value']:.0f} %",
-    'R05_TFR': f"{t['value'] / 1e3:.1f} k tiles/s with the filters on the host, {t['gpu_unfilter_value'] / 1e3:.1f} k with them on the GPU (photo-like tiles: {t['photo']['value'] / 1e3:.1f} k / {t['photo']['gpu_unfilter_value'] / 1e3:.1f} k)",
-    'R05_DEC': f"{t['decode_only_tiles_per_s'] / 1e3:.1f} k tiles/s ({t['decode_rows_only_tiles_per_s'] / 1e3:.1f} k stopping at the scanlines)",
-    'R05_HOST': f"{d['host_tiles']['value'] / 1e3:.1f} k tiles/s",
+    'RND_TAG': tag, 'RND_CORES': str(d['cpu_baseline']['cores']),
+    'RND_CFG3_TABLE': f"{c3['with_table_value']:,.0f}", 'RND_CFG3_RATIO': f"{c3['tile_table']['ratio_to_value']:.3f}", 'RND_CFG3': f"{c3['value']:,.0f}",
+    'RND_TFR_TABLE': f"{t['with_table_value'] / 1e3:.1f} k",
+    'RND_WIDE_SHARE': f"{100 * d['roofline']['share_of_step']:.0f}",
+    'RND_TRAFFIC': (f"{d['roofline']['traffic'] / 1e6:.0f}" if d['roofline'].get('traffic') else 'n/a'),
+    'RND_VALUE': f"{d['value']:,.0f}", 'RND_MS': f"{d['ms_per_step']:.2f}",
+    'RND_HBM': f"{100 * d['path_roofline']['hbm_frac']:.1f}", 'RND_MFMA': f"{100 * d['path_roofline']['mfma_frac']:.1f}",
+    'RND_CPU_TESTS': sys.argv[2] if len(sys.argv) > 2 else '?', 'RND_GPU_TESTS': sys.argv[3] if len(sys.argv) > 3 else '?',
+    'RND_CPU': f"{d['cpu_baseline']['value']:.2f}",
+    'RND_WIDE_MS': f"{d['roofline']['avg_launch_ms']:.4f}", 'RND_WIDE_FRAC': f"{100 * d['roofline']['frac']:.1f} %",
+    'RND_ENTRY': f"{d['entry_side_ms']:.2f}",
+    'RND_KERNEL_TABLE': '\n'.join(rows),
+    'RND_TFR_FRAC': f"{100 * max(t['value'], t['gpu_unfilter_value']) / d['value']:.0f} %",
+    'RND_TFR': f"{t['value'] / 1e3:.1f} k tiles/s with the filters on the host, {t['gpu_unfilter_value'] / 1e3:.1f} k with them on the GPU (photo-like tiles: {t['photo']['value'] / 1e3:.1f} k / {t['photo']['gpu_unfilter_value'] / 1e3:.1f} k)",
+    'RND_DEC': f"{t['decode_only_tiles_per_s'] / 1e3:.1f} k tiles/s ({t['decode_rows_only_tiles_per_s'] / 1e3:.1f} k stopping at the scanlines)",
+    'RND_HOST': f"{d['host_tiles']['value'] / 1e3:.1f} k tiles/s",
 }
 s = open('tools/templates/DESIGN.md.in').read()
 for k in sorted(rep, key=len, reverse=True):
@@ -40,5 +48,5 @@ line = (f"{d['value']:,.0f} tiles/s ({d['ms_per_step']:.2f} ms per batch; bf16 {
         f"exact fp32 kernels, {d['host_tiles']['value'] / 1e3:.1f} k when the decoded tiles start in pageable host memory (the PCIe-inclusive rate), "
         f"{t['value'] / 1e3:.1f} k end to end from PNG TFRecords on {t['host_cores']} host cores ({t['gpu_unfilter_value'] / 1e3:.1f} k with the PNG scanline filters "
         f"reversed on the GPU), against {d['cpu_baseline']['value']:.2f} tiles/s for the PyTorch-CPU restatement on the same {d['cpu_baseline']['cores']} cores")
-open('README.md', 'w').write(r.replace('R05_README_LINE', line))
+open('README.md', 'w').write(r.replace('RND_README_LINE', line))
 print('filled')
