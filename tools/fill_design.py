@@ -48,5 +48,8 @@ line = (f"{d['value']:,.0f} tiles/s ({d['ms_per_step']:.2f} ms per batch; bf16 {
         f"exact fp32 kernels, {d['host_tiles']['value'] / 1e3:.1f} k when the decoded tiles start in pageable host memory (the PCIe-inclusive rate), "
         f"{t['value'] / 1e3:.1f} k end to end from PNG TFRecords on {t['host_cores']} host cores ({t['gpu_unfilter_value'] / 1e3:.1f} k with the PNG scanline filters "
         f"reversed on the GPU), against {d['cpu_baseline']['value']:.2f} tiles/s for the PyTorch-CPU restatement on the same {d['cpu_baseline']['cores']} cores")
-open('README.md', 'w').write(r.replace('RND_README_LINE', line))
+for k, v in (('RND_README_LINE', line), ('RND_TAG', tag), ('RND_CFG3_TABLE', rep['RND_CFG3_TABLE']), ('RND_CFG3_RATIO', rep['RND_CFG3_RATIO']),
+             ('RND_CFG3', rep['RND_CFG3'])):
+    r = r.replace(k, v)
+open('README.md', 'w').write(r)
 print('filled')
