@@ -592,11 +592,38 @@ struct ReinhardConst {
     float m[9];        // XYZ from linear RGB
     float minv[9];     // linear RGB from XYZ
     float white[3];
+    float rwhite[3];   // RN(1 / white): see divc
     float tgt_mean[3];
     float tgt_std[3];
 };
 
 struct Lab { float L, a, b; };
+
+// x / c for a constant c, correctly rounded, in three operations instead of the ~10 of the IEEE division sequence (nine divisions by
+// constants per pixel and pass): q = x * rc with rc = RN(1 / c), the exact residual by fma, one correction -- Markstein's theorem:
+// RN(x / c) whenever rc is the correctly rounded reciprocal and c's significand is not all ones (0.95047, 1.08883, 116, 500, 200,
+// 7.787: checked against the division itself on 56 M values, experiments/r06.md).  The contract of oracle/stain.py -- one float32
+// rounding per operation -- is kept to the bit.
+__device__ __forceinline__ float divc(float x, float c, float rc) {
+    const float q = x * rc;
+    const float r = __builtin_fmaf(-q, c, x);
+    return __builtin_fmaf(r, rc, q);
+}
+
+// cbrt of a float32 t in (0.008856, ~1.1], "evaluated in float64 and rounded to float32" (the contract of oracle/stain.py), without
+// the library's cbrt(double) (~80 double-precision operations): a float32 seed exp2(log2(t) / 3) (relative error ~1e-6), then two
+// Newton steps y -= (y^3 - t) * r in float64 with ONE approximate reciprocal r ~ 1 / (3 y0^2) taken in float32 -- the error contracts
+// by ~1e-6 per step, to the last bits of a double.  The float32 rounding of that differs from the rounding of the exact cube root only
+// where the root lies within ~2e-16 (relative) of a float32 rounding boundary: one evaluation in ~3e8.
+__device__ __forceinline__ float cbrt_f64_rounded(float t) {
+    const float y0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(t) * (1.0f / 3.0f));
+    const double r = (double)__builtin_amdgcn_rcpf(3.0f * y0 * y0);
+    const double td = (double)t;
+    double y = (double)y0;
+    y = __builtin_fma(-(__builtin_fma(y * y, y, -td)), r, y);
+    y = __builtin_fma(-(__builtin_fma(y * y, y, -td)), r, y);
+    return (float)y;
+}
 
 #pragma clang fp contract(off)
 __device__ __forceinline__ Lab rgb_to_lab(const float* __restrict__ lut, const ReinhardConst& k, unsigned r8,
@@ -606,8 +633,8 @@ __device__ __forceinline__ Lab rgb_to_lab(const float* __restrict__ lut, const R
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float xyz = (k.m[3 * i] * r + k.m[3 * i + 1] * g) + k.m[3 * i + 2] * b;
-        const float t = xyz / k.white[i];
-        f[i] = t > 0.008856f ? (float)cbrt((double)t) : 7.787f * t + (float)(16.0 / 116.0);
+        const float t = divc(xyz, k.white[i], k.rwhite[i]);
+        f[i] = t > 0.008856f ? cbrt_f64_rounded(t) : 7.787f * t + (float)(16.0 / 116.0);
     }
     Lab o;
     o.L = 116.0f * f[1] - 16.0f;
@@ -619,44 +646,50 @@ __device__ __forceinline__ Lab rgb_to_lab(const float* __restrict__ lut, const R
 #pragma clang fp contract(off)
 __device__ __forceinline__ void lab_to_rgb8(const ReinhardConst& k, const float* __restrict__ thr, float L, float a,
                                             float b, uint8_t* out) {
-    const float fy = (L + 16.0f) / 116.0f;
-    const float fx = a / 500.0f + fy;
-    const float fz = fy - b / 200.0f;
+    const float fy = divc(L + 16.0f, 116.0f, 1.0f / 116.0f);
+    const float fx = divc(a, 500.0f, 1.0f / 500.0f) + fy;
+    const float fz = fy - divc(b, 200.0f, 1.0f / 200.0f);
     const float fv[3] = {fx, fy, fz};
     float xyz[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float v = fv[i];
-        const float t = v > 0.2068966f ? (v * v) * v : (v - (float)(16.0 / 116.0)) / 7.787f;
+        const float t = v > 0.2068966f ? (v * v) * v : divc(v - (float)(16.0 / 116.0), 7.787f, 1.0f / 7.787f);
         xyz[i] = t * k.white[i];
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float c = (k.minv[3 * i] * xyz[0] + k.minv[3 * i + 1] * xyz[1]) + k.minv[3 * i + 2] * xyz[2];
-        // out = clip(trunc(255 * clip(gamma(c), 0, 1)), 0, 255) is a monotone step function of c: the host
-        // evaluates the reference formula (float64 power rounded to float32, then float32 steps) once per
-        // output level and hands over the 255 switching points, so eight compares replace the power here
-        // and give the formula's result exactly.  thr[v-1] = smallest float32 c whose output is >= v.
-        int lo = 0, hi = 255;                       // invariant: out >= lo, out < hi + 1
+        // out = clip(trunc(255 * clip(gamma(c), 0, 1)), 0, 255) is a monotone step function of c: the host evaluates the reference
+        // formula (float64 power rounded to float32, then float32 steps) once per output level and hands over the 255 switching
+        // points: thr[v-1] = smallest float32 c whose output is >= v.  Round 6: a fast float32 gamma gives the level to within one,
+        // and two corrections against the switching points (two pairs of independent LDS reads) make it the formula's own result --
+        // rounds 2-5 ran a bisection, eight DEPENDENT LDS reads per channel, which was most of this kernel's time.
+        const float gam = c > 0.0031308f ? 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (float)(1.0 / 2.4)) - 0.055f : 12.92f * c;
+        int lo = gam > 0.f ? (int)(255.0f * fminf(gam, 1.0f)) : 0;          // (NaN -> 0, like the clip; and it stays 0 below)
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (c >= thr[mid - 1]) lo = mid; else hi = mid - 1;
+        for (int it = 0; it < 2; ++it) {
+            const float t_hi = thr[lo < 255 ? lo : 254], t_lo = thr[lo > 0 ? lo - 1 : 0];
+            const int up = (lo < 255 && c >= t_hi) ? 1 : 0;
+            const int dn = (lo > 0 && !(c >= t_lo)) ? 1 : 0;
+            lo += up - dn;
         }
-        out[i] = (uint8_t)lo;                       // NaN compares false everywhere -> 0, like the clip
+        out[i] = (uint8_t)lo;
     }
 }
 
 // stats_out (optional): [n][6] = mean L, a, b, std L, a, b.  dst may be null (statistics only) or == src.
-__global__ void __launch_bounds__(512) reinhard_kernel(const uint8_t* __restrict__ tiles, int px,
-                                                       const float* __restrict__ lut, const ReinhardConst k,
-                                                       uint8_t* dst, float* __restrict__ stats_out) {
+// One workgroup of 1 024 threads per tile (round 6: 512 left every SIMD with two waves and the kernel waiting on its own LDS reads).
+constexpr int RH_NT = 1024;
+__global__ void __launch_bounds__(RH_NT) reinhard_kernel(const uint8_t* __restrict__ tiles, int px,
+                                                         const float* __restrict__ lut, const ReinhardConst k,
+                                                         uint8_t* dst, float* __restrict__ stats_out) {
     const int npix = px * px;
     const uint8_t* src = tiles + (size_t)blockIdx.x * npix * 3;
     const int tid = threadIdx.x, nt = blockDim.x;
     __shared__ float slut[256];
     __shared__ float sthr[256];
-    __shared__ double red[6][8];
+    __shared__ double red[6][RH_NT / 64];
     __shared__ float stat[6];
     for (int i = tid; i < 256; i += nt) { slut[i] = lut[i]; sthr[i] = lut[256 + i]; }
     __syncthreads();
@@ -716,9 +749,10 @@ int launch_reinhard(const uint8_t* tiles, int n, int px, const float* d_lut, con
     for (int i = 0; i < 9; ++i) { k.m[i] = consts27[i]; k.minv[i] = consts27[9 + i]; }
     for (int i = 0; i < 3; ++i) {
         k.white[i] = consts27[18 + i];
+        k.rwhite[i] = 1.0f / consts27[18 + i];
         k.tgt_mean[i] = tgt_mean ? tgt_mean[i] : 0.f;
         k.tgt_std[i] = tgt_std ? tgt_std[i] : 1.f;
     }
-    hipLaunchKernelGGL(reinhard_kernel, dim3(n), dim3(512), 0, s, tiles, px, d_lut, k, dst, d_stats);
+    hipLaunchKernelGGL(reinhard_kernel, dim3(n), dim3(RH_NT), 0, s, tiles, px, d_lut, k, dst, d_stats);
     return (int)hipGetLastError();
 }

@@ -597,7 +597,7 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     acc = [None] * len(engines)
     n_batches = 0
     rows_mean, rows_std, rows_slide, rows_true, rows_loc = [], [], [], [], []
-    with_loc = bool(slides) and all(s.loc is not None for s in slides if s.n_tiles)
+    with_loc = any(s.n_tiles for s in slides) and all(s.loc is not None for s in slides if s.n_tiles)    # (every rank decides the same: one header)
     native = save_dir is not None and table_writer == 'native' and table_name.endswith('.csv')
     if table_writer not in ('native', 'pandas'):
         raise ValueError(f"table_writer must be 'native' or 'pandas', not {table_writer!r}")

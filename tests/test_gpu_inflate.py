@@ -199,8 +199,8 @@ def test_evaluate_from_compressed_chunks_equals_host_decoded_tiles(tmp_path, poo
 
 
 def test_a_damaged_stream_fails_the_run_loudly(tmp_path):
-    """One flipped byte inside a tile's zlib stream: the device path raises (at the end of the run, from the status words) --
-    never a silently wrong tile."""
+    """One flipped byte inside a tile's zlib stream: the device path raises (from the status words, looked at one chunk late and at
+    the end of the run) -- never a silently wrong tile."""
     from biscuit_amd import inference as inf
     from biscuit_amd.engine import Engine
     raws = [bytearray(tfr.encode_image(t)) for t in make_tiles(6, seed=5)]
