@@ -564,6 +564,14 @@ def run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks):
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     assert int(res.slide_count.sum()) == NT and np.isfinite(res.slide_pred).all()
+    # what the f16 range monitor costs (evaluate's default: the eight taps on eight tiles every 200 batches, no host sync): the same run
+    # without it
+    barrier()
+    t0 = time.perf_counter()
+    evaluate(pool_e, slides, mc_n=args.mc, seed=1234, batch=B, mc_mode=args.mode, keep_tiles=False, rank=rank, world=world,
+             headroom_every=0)
+    barrier()
+    dt_nomon = max_over_ranks(time.perf_counter() - t0)
     # the same run WITH the path's product: the tile table streamed to disk while the GPU works (every rank its shard, closed before
     # the all-gather; rank 0 splices them into tile_predictions_eval.csv) -- rows written and the file closed inside the timed region
     table = None
@@ -606,6 +614,8 @@ def run_cfg3(args, rank, world, dev, pool_e, pool, barrier, max_over_ranks):
             'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic', 'seconds': dt,
             'with_table_value': table['with_table_value'] if table else None, 'tile_table': table,
+            'range_monitor': {'checks': int(res.f16_checks), 'min_headroom': (None if not np.isfinite(res.f16_headroom) else float(res.f16_headroom)),
+                              'value_without': NT / dt_nomon, 'cost_frac': dt / dt_nomon - 1.0},
             # the slide table every rank holds after the gather, as a digest: equal at every world size (Philox counters are global
             # tile indices, the slide sums order-free fixed point)
             'slide_table_sha256': __import__('hashlib').sha256(np.ascontiguousarray(res.slide_pred).tobytes()

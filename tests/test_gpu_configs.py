@@ -336,6 +336,23 @@ def test_config5_harness_tfrecords_checkpoint_cli_threshold(tmp_path):
     sl = pd.read_csv(f'{d}/eval/slide_predictions_cohort_eval.csv', dtype={'slide': str})
     np.testing.assert_allclose(sl['y_pred'].to_numpy(), mem.slide_pred, atol=1e-9)
     eng.close(); eng01.close()
+    # the same command as THREE ranks (one GPU, gloo): every rank imports the model, calibrates on the same 16 tiles, decodes its
+    # slides' TFRecords and streams its shard; rank 0 splices the table and runs the consumer -- the one-rank run's bytes and numbers
+    port = _free_port()
+    procs = []
+    for r in range(3):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='3', LOCAL_WORLD_SIZE='3', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, '-m', 'biscuit_amd', '--tfrecords', d, '--labels', f'{d}/labels.csv', '--out',
+                                       f'{d}/eval3', '--mc', '8', '--batch', '16', '--model', mdir, '--seed', '1234', '--local-device', '0',
+                                       '--dist-backend', 'gloo'], cwd=ROOT, env=e, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE if r == 0 else None))
+    out0, err0 = procs[0].communicate(timeout=900)
+    assert [q.wait(timeout=300) for q in procs] == [0, 0, 0], err0[-3000:]
+    s3 = json.loads([ln for ln in out0.splitlines() if ln.startswith('{')][-1])
+    assert s3.pop('world') == 3 and summary.pop('world') == 1
+    t3, t1 = s3.pop('tile_table'), summary.pop('tile_table')
+    assert s3 == summary and open(t3, 'rb').read() == open(t1, 'rb').read()
+    assert open(f'{d}/eval3/slide_predictions_cohort_eval.csv', 'rb').read() == open(f'{d}/eval/slide_predictions_cohort_eval.csv', 'rb').read()
 
 
 def test_jpeg_tfrecords_feed_the_same_tiles(tmp_path):
