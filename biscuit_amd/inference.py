@@ -17,8 +17,8 @@ import pandas as pd
 import torch
 
 from . import distributed as D
-from .predictions import (EVAL_NAME, TableWriter, assemble_shards, save_tile_predictions, shard_name, tile_frame,
-                          write_shard_index)
+from .predictions import (EVAL_NAME, TableWriter, assemble_shards, remove_stale_shards, save_tile_predictions, shard_name,
+                          tile_frame, write_shard_index)
 
 
 @dataclass
@@ -604,6 +604,10 @@ def evaluate(engine, slides: Sequence[Slide], outcome='cohort', mc_n=None, seed=
     if save_dir is not None and not native and not keep_tiles:
         raise ValueError('the pandas writer needs keep_tiles=True (it writes the frame after the run)')
     table = None
+    if save_dir is not None and rank == 0:
+        import os
+        if os.path.isdir(save_dir):
+            remove_stale_shards(save_dir, world if world > 1 else 0, table_name)      # (a one-rank run leaves THE table only)
     if native:
         import os
         tpath = os.path.join(save_dir, table_name if world == 1 else shard_name(table_name, rank))

@@ -216,6 +216,17 @@ def write_shard_index(path, rank, world, outcome, with_loc, slides):
     os.replace(tmp, path + '.idx.json')                          # (complete or absent, never half a file)
 
 
+def remove_stale_shards(directory, world, name=EVAL_NAME):
+    """Shards (and their indexes) of ranks >= ``world`` left in ``directory`` by an earlier run of a larger world: rank 0 removes them
+    before it writes (ranks only ever write their own files, so this races with nobody); the splice would refuse the mixture."""
+    import glob
+    import re
+    for path in glob.glob(os.path.join(directory, shard_name(name, '*'))) + glob.glob(os.path.join(directory, shard_name(name, '*') + '.idx.json')):
+        m = re.search(r'\.rank(\d+)\.', os.path.basename(path))
+        if m and int(m.group(1)) >= int(world):
+            os.remove(path)
+
+
 def find_shards(directory, name=EVAL_NAME):
     """[(shard path, its index dict)] sorted by rank, or [] -- raises when the set is not one complete world."""
     import glob

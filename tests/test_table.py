@@ -135,11 +135,15 @@ def test_a_nan_from_the_engine_fails_the_run(tmp_path):
         evaluate(NanEngine(), _slides(COUNTS), mc_n=30, seed=1, batch=8, save_dir=str(tmp_path), keep_tiles=False)
 
 
+PARQUET = 'tile_predictions_eval.parquet.gzip'          # the other on-disk form the reference reads (utils.py:190-228)
+
+
 def _rank(rank, world, port, counts, batch, out_dir, with_loc, writer):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, w, _ = D.init_from_env(device_type='cpu')
     res = evaluate(StandInEngine(), _slides(counts, with_loc), outcome='cohort', mc_n=30, seed=1, batch=batch, save_dir=out_dir,
-                   rank=r, world=w, keep_tiles=(writer == 'pandas'), table_writer=writer)
+                   rank=r, world=w, keep_tiles=(writer != 'native'), table_writer='pandas' if writer == 'parquet' else writer,
+                   table_name=PARQUET if writer == 'parquet' else P.EVAL_NAME)
     assert res.table_rows == sum(counts[i] for i in res.local_slides)
     if r == 0 and writer == 'native':
         assert res.table_path == os.path.join(out_dir, P.EVAL_NAME) and os.path.exists(res.table_path)
@@ -200,9 +204,25 @@ def test_shards_of_a_multi_rank_run_make_the_single_rank_table(tmp_path, world, 
         P.load_tile_predictions(str(tmp_path / 'gap'), 'cohort')
 
 
+def test_a_smaller_world_into_the_same_directory_replaces_the_larger_ones_shards(tmp_path):
+    out = str(tmp_path / 'run')
+    _run(3, COUNTS, 8, out)
+    assert len(P.find_shards(out)) == 3
+    _run(2, COUNTS, 8, out)                                # rank 0 removes rank 2's files of the earlier run before it writes
+    assert [m['world'] for _, m in P.find_shards(out)] == [2, 2]
+    one = evaluate(StandInEngine(), _slides(COUNTS), outcome='cohort', mc_n=30, seed=1, batch=8, save_dir=out)
+    assert P.find_shards(out) == [] and _sha(one.table_path) == _sha(os.path.join(out, P.EVAL_NAME))
+
+
 def test_pandas_shards_are_read_in_dataset_order(tmp_path):
     _run(2, COUNTS, 8, str(tmp_path / 'multi'), writer='pandas')
     one = evaluate(StandInEngine(), _slides(COUNTS), outcome='cohort', mc_n=30, seed=1, batch=8, save_dir=str(tmp_path / 'single'))
     assert P.load_tile_predictions(str(tmp_path / 'multi'), 'cohort').equals(P.load_tile_predictions(one.table_path, 'cohort'))
     with pytest.raises(IOError):
         P.assemble_shards(str(tmp_path / 'multi'))
+    # the parquet form: shards written whole by pandas, read back in dataset order
+    _run(2, COUNTS, 8, str(tmp_path / 'pq'), writer='parquet')
+    onep = evaluate(StandInEngine(), _slides(COUNTS), outcome='cohort', mc_n=30, seed=1, batch=8, save_dir=str(tmp_path / 'pq1'),
+                    table_name=PARQUET)
+    assert onep.table_path.endswith(PARQUET)
+    assert P.load_tile_predictions(str(tmp_path / 'pq'), 'cohort', name=PARQUET).equals(P.load_tile_predictions(onep.table_path, 'cohort'))
