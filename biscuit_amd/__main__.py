@@ -97,6 +97,9 @@ def main(argv=None):
                          'the inference streams inflate them.  For hosts with few free cores per GPU and runs of >= 30 k tiles; '
                          'slower than 16 host threads otherwise (profiles/r05_inflate.txt).  Pins 3 x up to 1 GiB of host memory per rank for the '
                          'compressed ring (4 096-tile chunks) and allocates ~3 GB on the device per chunk in flight')
+    ap.add_argument('--skip-existing', action='store_true',
+                    help='do nothing when OUT already holds tile_predictions_eval.csv (the idempotence of the reference\'s Step 6: '
+                         'utils.eval_exists, biscuit/experiment.py:913-914)')
     ap.add_argument('--detect', action='store_true',
                     help='also run threshold.detect on the tile table (Youden thresholds over every tile of the cohort, threshold.py:364-475)')
     ap.add_argument('--dist-backend', default=None, help='process-group backend for WORLD_SIZE > 1 (default nccl = RCCL; gloo for a rehearsal '
@@ -106,6 +109,11 @@ def main(argv=None):
                     help='f16 with external weights: skip the activation-exponent calibration on the first tiles (the headroom check stays)')
     args = ap.parse_args(argv)
 
+    if args.skip_existing and os.path.exists(os.path.join(args.out, 'tile_predictions_eval.csv')):
+        # (every rank sees the same directory and takes the same way out, before any rendezvous)
+        if int(os.environ.get('RANK', '0')) == 0:
+            print(json.dumps({'skipped': True, 'tile_table': os.path.join(args.out, 'tile_predictions_eval.csv')}))
+        return
     from . import distributed as D, threshold, weights as W
     from .engine import EnginePool
     from .inference import Slide, evaluate, slides_from_tfrecords

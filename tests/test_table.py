@@ -226,3 +226,17 @@ def test_pandas_shards_are_read_in_dataset_order(tmp_path):
                     table_name=PARQUET)
     assert onep.table_path.endswith(PARQUET)
     assert P.load_tile_predictions(str(tmp_path / 'pq'), 'cohort', name=PARQUET).equals(P.load_tile_predictions(onep.table_path, 'cohort'))
+
+
+def test_cli_skips_a_finished_evaluation(tmp_path):
+    """``--skip-existing``: the idempotence of the reference's Step 6 (``utils.eval_exists``, biscuit/experiment.py:913-914) -- a
+    directory that already holds the table is left alone, before anything touches a GPU or a rendezvous (so this runs on CPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / P.EVAL_NAME).write_text('slide,cohort-y_true0\n')
+    p = subprocess.run([sys.executable, '-m', 'biscuit_amd', '--synthetic', '2x2', '--out', str(tmp_path), '--skip-existing'], cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])['skipped'] is True
+    assert (tmp_path / P.EVAL_NAME).read_text() == 'slide,cohort-y_true0\n'
