@@ -21,7 +21,9 @@ t = d['tfrecords']
 c3 = json.load(open(f'profiles/{tag}_bench_cfg3_share.json'))
 wide = next(k for k in ks if k['name'] == d['roofline']['kernel'])
 rep = {
-    'RND_TAG': tag, 'RND_CORES': str(d['cpu_baseline']['cores']),
+    'RND_TAG': tag,
+    'RND_MON_CHECKS': str(c3.get('range_monitor', {}).get('checks', '?')),
+    'RND_MON_COST': (f"{100 * c3['range_monitor']['cost_frac']:+.1f} %" if c3.get('range_monitor') else '?'), 'RND_CORES': str(d['cpu_baseline']['cores']),
     'RND_CFG3_TABLE': f"{c3['with_table_value']:,.0f}", 'RND_CFG3_RATIO': f"{c3['tile_table']['ratio_to_value']:.3f}", 'RND_CFG3': f"{c3['value']:,.0f}",
     'RND_TFR_TABLE': f"{t['with_table_value'] / 1e3:.1f} k",
     'RND_WIDE_SHARE': f"{100 * d['roofline']['share_of_step']:.0f}",
