@@ -165,6 +165,12 @@ def test_eight_rank_rehearsal_on_one_gpu(tmp_path):
     assert w8['n_gpus'] == 8 and w8['scaling'] == 'weak' and w8['value'] > 0
     assert w8['collective'] == {'backend': 'gloo', 'ranks_seen': 8, 'rccl_ranks': 0}
     assert w8['host_cores_of_rank0'] >= 1                       # pin_rank against this box's sysfs: a share, never empty
+    # the DRIVER's form of the same: torchrun starts the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from its environment)
+    tr = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr', '127.0.0.1',
+                         '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1',
+                         *common], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    w4 = _json_line(tr)
+    assert w4['n_gpus'] == 4 and w4['steps'] == 2 and w4['collective']['ranks_seen'] == 4 and w4['value'] > 0
     cfg3 = ['--workload', 'cfg3', '--slides', '19', '--tiles-per-slide', '24', '--ragged']
     s8, s1 = _json_line(run('--gpus', '8', *cfg3)), _json_line(run('--gpus', '1', *cfg3))
     assert s8['n_gpus'] == 8 and s8['config']['ragged'] and sum(s8['config']['slides_per_rank']) == 19
