@@ -3,9 +3,9 @@
 The reference builds ``sf.Heatmap(slide, model, stride_div=1)`` and masks it with the tile-level
 uncertainty threshold (results.py:217-227), then walks the slide's tile grid through
 ``UncertaintyInterface`` and sorts the tiles into ``uq_incl`` / ``uq_excl`` (results.py:234-265).
-Reading the slide itself is Slideflow/libvips work and is not rebuilt here: this front-end takes the
-tiles of a grid (for example one slide's TFRecord with its ``loc_x`` / ``loc_y``) and lays the same
-MC-dropout kernels' outputs out as the two grids the reference uses:
+This front-end takes the tiles of a grid -- one slide's TFRecord with its ``loc_x`` / ``loc_y``, a region in memory
+(``from_region``), or a pyramidal TIFF / SVS slide file through this build's own reader (``from_slide``, ``biscuit_amd/wsi.py``,
+round 6) -- and lays the same MC-dropout kernels' outputs out as the two grids the reference uses:
 
     hm.logits       [gy, gx, 2]   mean class probabilities over the MC passes
     hm.uncertainty  [gy, gx, 2]   their population std
@@ -76,6 +76,21 @@ class Heatmap:
             raise ValueError(f'region {tuple(region.shape[:2])} holds no {tile_px} x {tile_px} tile')
         shape = (int(grid[:, 1].max()) + 1, int(grid[:, 0].max()) + 1)      # (gy, gx) of tile_grid's clamped grid
         return cls(engine, tiles, grid, grid_shape=shape, **kw)
+
+    @classmethod
+    def from_slide(cls, engine, path, tile_px=299, tile_um=302, stride_div=1, mpp=None, **kw):
+        """``sf.Heatmap(slide, model, stride_div=1)`` (results.py:217) for a pyramidal TIFF / SVS slide file: the tile grid of
+        ``wsi.WSI(path, tile_px, tile_um, stride_div)`` through the MC-dropout kernels.  (The reader is this build's own --
+        ``biscuit_amd/wsi.py`` says what it reads and what about it is unpinned.)"""
+        from .wsi import WSI
+        w = WSI(path, tile_px=tile_px, tile_um=tile_um, stride_div=stride_div, mpp=mpp)
+        try:
+            tiles, grid = w.tiles()
+            if len(grid) == 0:
+                raise ValueError(f'{path}: the slide holds no {tile_um} um tile')
+            return cls(engine, tiles, grid, grid_shape=(w.grid_h, w.grid_w), **kw)
+        finally:
+            w.close()
 
     def mask_uncertain(self, tile_uq_thresh):
         """results.py:224-225: ``uq_mask = hm.uncertainty[:, :, 0] > thresh; hm.logits[uq_mask, :] = [-1, -1]``.
