@@ -86,6 +86,14 @@ class TiffSlide:
     def __init__(self, path):
         self.path = path
         self._f = open(path, 'rb')
+        try:
+            self._open()
+        except BaseException:
+            self._f.close()
+            raise
+
+    def _open(self):
+        path = self.path
         head = self._f.read(16)
         if head[:2] == b'II':
             self._e = '<'
