@@ -105,6 +105,10 @@ def main(argv=None):
     ap.add_argument('--dist-backend', default=None, help='process-group backend for WORLD_SIZE > 1 (default nccl = RCCL; gloo for a rehearsal '
                                                           'of several ranks on one GPU)')
     ap.add_argument('--local-device', type=int, default=None, help='HIP device of this rank (default LOCAL_RANK)')
+    ap.add_argument('--unfilter', default='auto', choices=['auto', 'host', 'gpu'],
+                    help="where the PNG scanline filters of TFRecord tiles are reversed: 'auto' (default) decodes 48 tiles of the first "
+                         "slide both ways and takes the GPU where the host alone cannot feed it (same bytes either way; 28.8 k -> 31.9 k "
+                         "tiles/s on 16 cores)")
     ap.add_argument('--no-calibrate', action='store_true',
                     help='f16 with external weights: skip the activation-exponent calibration on the first tiles (the headroom check stays)')
     args = ap.parse_args(argv)
@@ -136,7 +140,8 @@ def main(argv=None):
         labels = dict(zip(lab['slide'], lab['label']))
         patients = dict(zip(lab['slide'], lab['patient'])) if 'patient' in lab.columns else None
         paths = sorted(glob.glob(os.path.join(args.tfrecords, '*.tfrecords')))
-        slides = slides_from_tfrecords(paths, labels, patients, gpu_decode=args.gpu_decode > 0)
+        slides = slides_from_tfrecords(paths, labels, patients, gpu_decode=args.gpu_decode > 0,
+                                       gpu_unfilter={'auto': 'auto', 'host': False, 'gpu': True}[args.unfilter])
     else:
         if 'x' in args.synthetic.lower():
             s, t = (int(x) for x in args.synthetic.lower().split('x'))
