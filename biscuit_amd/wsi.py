@@ -28,6 +28,21 @@ class SlideError(ValueError):
     pass
 
 
+def _guard(fn):
+    """A damaged file must end in SlideError, whatever the parser tripped over."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except SlideError:
+            raise
+        except (struct.error, IndexError, KeyError, TypeError, ValueError, ZeroDivisionError, OverflowError, MemoryError, OSError) as e:
+            raise SlideError(f'damaged or unsupported slide file: {type(e).__name__}: {e}') from None
+    return wrapped
+
+
 _TYPES = {1: ('B', 1), 2: ('c', 1), 3: ('H', 2), 4: ('I', 4), 5: ('II', 8), 6: ('b', 1), 7: ('B', 1), 8: ('h', 2), 9: ('i', 4),
           10: ('ii', 8), 11: ('f', 4), 12: ('d', 8), 13: ('I', 4), 16: ('Q', 8), 17: ('q', 8), 18: ('Q', 8)}
 
@@ -59,6 +74,8 @@ class _Page:
             self.th = int(g(278, (self.height,))[0])
             self.th = min(self.th, self.height)
             self.offsets, self.counts = g(273), g(279)
+        if not (0 < self.width <= 1 << 20 and 0 < self.height <= 1 << 20 and 0 < self.tw <= 1 << 15 and 0 < self.th <= 1 << 15):
+            raise SlideError(f'implausible page geometry {self.width} x {self.height}, segments {self.tw} x {self.th}')
         self.across = -(-self.width // self.tw)
         self.down = -(-self.height // self.th)
 
@@ -92,7 +109,10 @@ class TiffSlide:
             self._f.close()
             raise
 
+    @_guard
     def _open(self):
+        import os
+        self._size = os.fstat(self._f.fileno()).st_size
         path = self.path
         head = self._f.read(16)
         if head[:2] == b'II':
@@ -162,6 +182,8 @@ class TiffSlide:
                 continue
             code, size = _TYPES[typ]
             nbytes = size * cnt
+            if nbytes > self._size:
+                raise SlideError(f'{self.path}: tag {tag} claims {nbytes} bytes in a file of {self._size}')
             if nbytes <= inl:
                 data = ent[esz - inl:esz - inl + nbytes]
             else:
@@ -191,12 +213,15 @@ class TiffSlide:
         return None
 
     # ---- pixels ------------------------------------------------------------------------------------------------------
+    @_guard
     def _segment(self, li, index):
         """Strip / tile ``index`` of level ``li`` decoded to uint8 [th, tw, 3] (a last strip may be shorter)."""
         key = (li, index)
         if key in self._cache:
             return self._cache[key]
         p = self.levels[li]
+        if int(p.counts[index]) > self._size:
+            raise SlideError(f'{self.path}: segment {index} of level {li} claims more bytes than the file holds')
         self._f.seek(int(p.offsets[index]))
         raw = self._f.read(int(p.counts[index]))
         rows = p.th if p.tiled else min(p.th, p.height - (index * p.th))
@@ -240,8 +265,11 @@ class TiffSlide:
         except (OSError, SyntaxError) as e:
             raise SlideError(f'{self.path}: a JPEG tile does not decode: {e}') from None
 
+    @_guard
     def read_region(self, level, x, y, w, h):
         p = self.levels[level]
+        if not (0 < w <= 1 << 16 and 0 < h <= 1 << 16):
+            raise SlideError(f'region of {w} x {h} pixels')
         out = np.full((h, w, 3), 255, np.uint8)
         x0, y0, x1, y1 = max(x, 0), max(y, 0), min(x + w, p.width), min(y + h, p.height)
         if x1 <= x0 or y1 <= y0:
@@ -273,6 +301,7 @@ class WSI:
     from the pyramid level with the largest downsample that still has at least ``tile_px`` pixels per tile and resampled to
     ``tile_px`` (Pillow LANCZOS).  ``roi_method``: only 'ignore' (what the reference passes) is implemented."""
 
+    @_guard
     def __init__(self, path, tile_px=TILE_PX, tile_um=TILE_UM, stride_div=1, roi_method='ignore', mpp=None):
         if roi_method != 'ignore':
             raise NotImplementedError("only roi_method='ignore' (results.py:235)")
@@ -282,6 +311,8 @@ class WSI:
         if not self.mpp:
             raise SlideError(f'{path}: no microns-per-pixel in the file (Aperio "MPP =" or XResolution); pass mpp=')
         self.extract_px = int(self.tile_um / self.mpp)                   # level-0 pixels per tile side
+        if not np.isfinite(self.mpp) or self.mpp <= 0:
+            raise SlideError(f'{path}: implausible microns per pixel {self.mpp}')
         if self.extract_px < 1 or self.stride_div < 1:
             raise SlideError('tile of less than one pixel / bad stride_div')
         self.stride = max(1, self.extract_px // self.stride_div)

@@ -238,3 +238,30 @@ def test_heatmap_from_slide_file(tmp_path):
     incl, excl = hm.split_by_uncertainty(float(np.median(hm.uncertainty[:, :, 0])))
     assert len(incl) + len(excl) == 12
     eng.close()
+
+
+def test_mutated_slide_files_fail_with_slide_errors_only(tmp_path):
+    """Bytes flipped anywhere in a small slide file: the reader answers with pixels or with ``SlideError`` -- never with another
+    exception, a hang or a huge allocation."""
+    path, _ = _slide_file(tmp_path, w=600, h=420)
+    good = bytearray(open(path, 'rb').read())
+    rng = np.random.default_rng(0)
+    # the structure lives at the end (IFDs, tag data): mutate there densely and the pixel data sparsely
+    spots = np.concatenate([rng.integers(0, 16, 40), rng.integers(len(good) - 1200, len(good), 500), rng.integers(0, len(good), 60)])
+    outcomes = {'ok': 0, 'refused': 0}
+    for k, at in enumerate(spots):
+        bad = bytearray(good)
+        bad[int(at)] ^= int(rng.integers(1, 256))
+        if k % 5 == 0:
+            bad = bad[:int(at)]                                   # truncation
+        p = tmp_path / 'm.svs'
+        p.write_bytes(bytes(bad))
+        try:
+            w = WSI(str(p), 299, 302)
+            if w.estimated_num_tiles:
+                next(iter(w.build_generator()()))
+            w.close()
+            outcomes['ok'] += 1
+        except SlideError:
+            outcomes['refused'] += 1
+    assert outcomes['ok'] > 20 and outcomes['refused'] > 20, outcomes
