@@ -590,6 +590,39 @@ def test_headline_mode_at_config2_size_against_the_oracle():
     eng.close()
 
 
+def test_headline_mode_at_config2_size_on_the_worst_stress_draw():
+    """The same 1 000-tile slide on ANOTHER draw of the stress weights -- seed 4, the worst of the eight draws ``tools/parity_seeds.py``
+    compares with the fp32 kernels (4.8e-4) -- against the CPU oracle itself (``oracle/make_producer_cfg2_golden.py --weights 4`` ->
+    ``producer_cfg2_slide_w4.npz``): the f16 path in four batches, tile and slide mean / sigma within 1e-3 of the fp32 oracle and
+    within 5e-4 of the f16-emulating one; bf16 -- the type BASELINE config 2 names -- reported next to it, not asserted under 1e-3."""
+    from biscuit_amd.engine import Engine
+    from oracle.make_producer_cfg2_golden import cfg2_tiles
+    g = np.load(os.path.join(GOLDEN, 'producer_cfg2_slide_w4.npz'))
+    tiles, sidx = cfg2_tiles()
+    tiles = tiles[sidx == 0]
+    assert np.uint64(tiles.astype(np.uint64).sum()) == g['tile_checksum']
+    mc, seed = int(g['cfg_mc_n']), int(g['cfg_dropout_seed'])
+    w = synthetic_weights(int(g['cfg_weight_seed']), hard=True)
+    d = dev(tiles)
+    for dtype in ('f16', 'bf16'):
+        eng = Engine(w, dtype=dtype, max_batch=256, max_mc=mc)
+        ms, ss = [], []
+        for o in range(0, 1000, 256):
+            m, s = eng.mc_infer(d[o:o + 256].contiguous(), mc, seed, tile_idx0=o)
+            ms.append(m); ss.append(s)
+        m, s = torch.cat(ms).cpu().numpy(), torch.cat(ss).cpu().numpy()
+        d32 = (np.abs(m - g['mean_f32']).max(), np.abs(s - g['std_f32']).max(),
+               abs(m[:, 1].astype(np.float64).mean() - float(g['slide_pred_f32'])), abs(s[:, 1].astype(np.float64).mean() - float(g['slide_unc_f32'])))
+        print(f'{dtype} HIP vs fp32 oracle, 1000 tiles, weights seed 4: tile mean {d32[0]:.3e} std {d32[1]:.3e}; slide pred {d32[2]:.3e} unc {d32[3]:.3e}')
+        if dtype == 'f16':
+            demu = max(np.abs(m - g['mean_f16emu']).max(), np.abs(s - g['std_f16emu']).max())
+            print(f'f16 HIP vs the f16-emulating oracle: {demu:.3e}')
+            assert max(d32) < 1e-3 and demu < 5e-4, (d32, demu)
+        else:
+            assert max(d32) < 2e-2                                # (bf16: finite and in the neighbourhood; DESIGN.md section 4 says why not 1e-3)
+        eng.close()
+
+
 @pytest.mark.parametrize('dtype', ['f16', 'bf16'])
 def test_full_size_properties(engines, dtype):
     """BASELINE.json config 2 sizes (1000 tiles/slide, batch 256, MC=30; f16 = the headline mode, bf16 = the type config 2
