@@ -48,6 +48,24 @@ class BundleError(ValueError):
     pass
 
 
+def _guard(fn):
+    """A damaged checkpoint must end in BundleError, whatever the parser tripped over (a protobuf wire type that does not exist, a
+    varint that runs off the buffer, a shape whose product overflows ...)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except BundleError:
+            raise
+        except KeyError:
+            raise                                                   # (tensor(name) of a name that is not there)
+        except (ValueError, IndexError, struct.error, TypeError, OverflowError, MemoryError, UnicodeDecodeError) as e:
+            raise BundleError(f'damaged checkpoint: {type(e).__name__}: {e}') from None
+    return wrapped
+
+
 def _mask(crc):
     return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
 
@@ -245,6 +263,7 @@ class BundleReader:
     ``variables`` directory is accepted too).  ``keys()`` lists tensor names, ``tensor(name)`` returns a
     numpy array (bfloat16 widened to float32; a string tensor as an object array of bytes)."""
 
+    @_guard
     def __init__(self, prefix, verify=True):
         prefix = resolve_prefix(prefix)
         self.prefix = prefix
@@ -273,6 +292,7 @@ class BundleReader:
             self._shards[idx] = np.memmap(path, dtype=np.uint8, mode='r')
         return self._shards[idx]
 
+    @_guard
     def raw(self, name):
         e = self.entries.get(name)
         if e is None:
@@ -291,6 +311,7 @@ class BundleReader:
                 raise BundleError(f'{name}: tensor CRC mismatch (stored {e["crc"]:#x}, computed {got:#x})')
         return e, raw
 
+    @_guard
     def tensor(self, name):
         e, raw = self.raw(name)
         n = int(np.prod(e['shape'], dtype=np.int64)) if e['shape'] else 1

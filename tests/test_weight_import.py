@@ -397,3 +397,40 @@ def test_variables_outside_the_layer_tree(tmp_path, synth):
     assert W.pack_blob(w, 'f16') == W.pack_blob(synth, 'f16')
     with pytest.raises(K.ImportError_, match='outside the layer_with_weights'):
         K.from_bundle(path, strict=True)
+
+
+def test_mutated_bundles_fail_with_bundle_errors_only(tmp_path):
+    """Bytes flipped or cut anywhere in a checkpoint's index and data files: the reader answers with tensors or with
+    ``BundleError`` (CRC mismatches, truncation, corrupt entries) -- never with another exception or a huge allocation."""
+    rng = np.random.default_rng(0)
+    tensors = {f'layer_with_weights-{i}/kernel/.ATTRIBUTES/VARIABLE_VALUE': rng.normal(size=(3, 3, 4, 8)).astype(np.float32) for i in range(12)}
+    tensors['note'] = b'text'
+    prefix = str(tmp_path / 'ck')
+    B.write_bundle(prefix, tensors, block_size=256)
+    idx = bytearray(open(prefix + '.index', 'rb').read())
+    dat = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    outcomes = {'ok': 0, 'refused': 0}
+    for k in range(400):
+        bad_i, bad_d = bytearray(idx), bytearray(dat)
+        if k % 2 == 0:
+            at = int(rng.integers(0, len(bad_i)))
+            bad_i[at] ^= int(rng.integers(1, 256))
+            if k % 10 == 0:
+                bad_i = bad_i[:at]
+        else:
+            at = int(rng.integers(0, len(bad_d)))
+            bad_d[at] ^= int(rng.integers(1, 256))
+            if k % 10 == 1:
+                bad_d = bad_d[:at]
+        p = str(tmp_path / 'm')
+        open(p + '.index', 'wb').write(bytes(bad_i))
+        open(p + '.data-00000-of-00001', 'wb').write(bytes(bad_d))
+        for verify in (True, False):
+            try:
+                r = B.BundleReader(p, verify=verify)
+                for name in r.keys():
+                    r.tensor(name)
+                outcomes['ok'] += 1
+            except B.BundleError:
+                outcomes['refused'] += 1
+    assert outcomes['refused'] > 300 and outcomes['ok'] > 100, outcomes      # (verify=False lets flipped tensor bytes through: that is its meaning)
