@@ -42,3 +42,13 @@ def test_jpeg_decoder_under_sanitizers(tmp_path):
     p = subprocess.run([exe, '6000'] + files, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])        # a sanitizer report aborts with a non-zero status
     assert 'decoded' in p.stdout and 'refused' in p.stdout
+
+
+def test_table_writer_under_sanitizers(tmp_path):
+    """csrc/table_writer.cpp (the output side of libbiscuit_io): the float formatter on 200 000 random doubles / widened float32
+    values (each reads back to the same double), tables with awkward slide names, refusals -- no sanitizer report."""
+    exe = str(tmp_path / 'table_fuzz')
+    _build('table_fuzz.cpp', exe)
+    p = subprocess.run([exe, '200000'], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-2000:])
+    assert p.stdout.strip().endswith('problems 0'), p.stdout[-500:]
